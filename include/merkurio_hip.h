@@ -1,0 +1,244 @@
+/*
+ * merkurio_hip.h -- C ABI of the MI355X-native multi-pattern matcher that replaces
+ * MerKurio's pattern_matching hot path (BNDMq / Aho-Corasick) for `merkurio extract|tag`.
+ *
+ * The reference has no trait / plugin / FFI for this path: its drivers hold
+ * `(Option<AhoCorasick>, Vec<(String, BNDMq)>)` (src/cmd_extract.rs:259, src/cmd_tag.rs:234)
+ * and call the matcher once per record.  A GPU wants batches, so this ABI exposes the same
+ * observable contract per *batch of records*; every entry point below names the reference
+ * interface it replaces (paths relative to the reference repo).  A Rust host binds these
+ * symbols with `extern "C"`.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross the boundary;
+ *  - every function returns 0 (MK_OK) or a negative MK_E_* code; mk_last_error() gives the
+ *    text for the calling thread; nothing throws across the ABI;
+ *  - there is NO CPU fallback: without a usable HIP device creation fails with MK_E_HIP;
+ *  - a matcher handle is bound to one HIP device; scans on a handle are serialised;
+ *    distinct handles (one per GPU / per process) are independent;
+ *  - the caller owns every buffer it passes; the library copies patterns at create time.
+ */
+#ifndef MERKURIO_HIP_H
+#define MERKURIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_ABI_VERSION 1
+
+/* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
+#define MK_OK 0
+#define MK_E_EMPTY_PATTERN (-1)    /* PatternError::EmptyPattern */
+#define MK_E_INVALID_Q (-2)        /* PatternError::InvalidQGramLength(q) */
+#define MK_E_PATTERN_TOO_LONG (-3) /* PatternError::PatternTooLong(len, 64) */
+#define MK_E_NO_PATTERNS (-4)      /* "No k-mers found ..." (src/helpers.rs:128-130,158-160) */
+#define MK_E_NOMEM (-5)
+#define MK_E_PAIR_MISMATCH (-6) /* paired inputs differ in record count (src/cmd_extract.rs:465-468,608-612) */
+#define MK_E_HIP (-7)           /* HIP runtime error / no device */
+#define MK_E_CAPACITY (-8)      /* output buffer too small; required size is reported */
+#define MK_E_INVALID_ARG (-9)
+#define MK_E_UNSUPPORTED (-10)
+
+/* algorithm selector: what the reference's `-a` / `-q` / auto rule decides
+ * (src/cmd_extract.rs:166-171, src/helpers.rs:203-211).  The device scan is the same for
+ * both; the algorithm fixes the EMISSION ORDER and the pattern_hit_counts semantics. */
+#define MK_ALGO_AUTO 0  /* AC iff case-insensitive, or n >= 14, or max_len > 64 */
+#define MK_ALGO_AC 1    /* aho_corasick::AhoCorasick (DFA, overlapping search) */
+#define MK_ALGO_BNDMQ 2 /* pattern_matching::BNDMq, one instance per pattern */
+
+#define MK_FLAG_ASCII_CASE_INSENSITIVE 1u /* AhoCorasickBuilder::ascii_case_insensitive(true) */
+
+/* scan modes = what the reference loops consume from the matcher */
+#define MK_MODE_ANY 0  /* per-record "any hit" flag only  (find_match / first-hit break) */
+#define MK_MODE_HITS 1 /* + every (record, pattern, start) in reference emission order */
+
+typedef struct mk_matcher mk_matcher;
+
+/* one occurrence: pattern `pat` (index into the sorted unique pattern list) starts at byte
+ * `pos` (0-based) of record `rec`.  == (mat.pattern().as_usize(), mat.start()) of
+ * src/cmd_extract.rs:341-342 and the `o` of BNDMq::find_iter (src/cmd_extract.rs:367). */
+typedef struct {
+    uint64_t rec;
+    uint32_t pat;
+    uint32_t pos;
+} mk_hit;
+
+/* one log row: mk_hit plus the file (mate) index; logger.log_fields arguments,
+ * src/logger.rs:41 */
+typedef struct {
+    uint64_t rec;
+    uint32_t pat;
+    uint32_t pos;
+    uint32_t file; /* 0 = file 1, 1 = file 2 */
+    uint32_t _pad;
+} mk_row;
+
+/* the scalar counters of src/cmd_extract.rs:285-289 / src/cmd_tag.rs:360-363 */
+typedef struct {
+    uint64_t nb_records_tot;
+    uint64_t nb_bases;
+    uint64_t nb_hits_tot[2];
+    uint64_t nb_records_hit[2];
+    uint64_t nb_records_extracted;
+} mk_counters;
+
+/* ------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------- */
+int mk_abi_version(void);
+const char *mk_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int mk_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Pattern preparation (host side; defines the pattern index space)
+ * ---------------------------------------------------------------------------------- */
+/* helpers::read_kmers_from_file body, src/helpers.rs:152-156: content -> raw k-mer lines.
+ * Outputs are malloc'd by the library; release with mk_free. */
+int mk_read_kmers_from_text(const uint8_t *content, size_t len, uint8_t **out_bytes, uint32_t **out_off,
+                            uint32_t *out_n);
+/* helpers::parse_pattern_list, src/helpers.rs:76-133: case conversion, reverse-complement
+ * extension (-r) or canonical form (-c), drop empty, sort_unstable, dedup. */
+int mk_parse_pattern_list(const uint8_t *in_bytes, const uint32_t *in_off, uint32_t n_in, int reverse_complement,
+                          int canonical, int lowercase, int uppercase, uint8_t **out_bytes, uint32_t **out_off,
+                          uint32_t *out_n);
+/* needletail Sequence::reverse_complement / sequence::canonical as used at
+ * src/helpers.rs:103,117.  out must hold n bytes. */
+void mk_reverse_complement(const uint8_t *in, size_t n, uint8_t *out);
+void mk_canonical(const uint8_t *in, size_t n, uint8_t *out);
+/* helpers::recommend_aho_corasick, src/helpers.rs:203-211 */
+int mk_recommend_aho_corasick(size_t num_patterns, size_t max_len);
+/* pattern_matching::tune_q_value, src/pattern_matching.rs:213-225 (0 for len >= 65) */
+size_t mk_tune_q_value(size_t pattern_len);
+/* pattern_preprocessing::generate_masks, src/pattern_preprocessing.rs:24-43 */
+int mk_generate_masks(const uint8_t *pattern, size_t m, uint64_t masks[256], uint64_t *accept);
+void mk_free(void *p);
+
+/* ------------------------------------------------------------------------------------
+ * Matcher construction
+ * replaces: BNDMq::new per pattern (src/pattern_matching.rs:61-78, called at
+ * src/cmd_extract.rs:267-276) and AhoCorasick::builder()...build() (src/cmd_extract.rs:260-265,
+ * src/cmd_tag.rs:235-240).
+ *
+ * pat_bytes/pat_off: n_pat patterns, pattern i = pat_bytes[pat_off[i] .. pat_off[i+1]); the
+ * list must already be the sorted unique list of parse_pattern_list (indices are reported
+ * as given).  algo: MK_ALGO_*.  q: BNDMq q-gram length, 0 = tune_q_value per pattern;
+ * ignored for AC.  q has no effect on results, but its validation errors are reproduced
+ * (MK_E_INVALID_Q, MK_E_EMPTY_PATTERN, MK_E_PATTERN_TOO_LONG for BNDMq patterns > 64 B).
+ * flags: MK_FLAG_* (case-insensitive forces AC like src/cmd_extract.rs:166-167).
+ * device: HIP device ordinal.
+ * ---------------------------------------------------------------------------------- */
+int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
+                      uint32_t flags, int32_t device, mk_matcher **out);
+void mk_matcher_destroy(mk_matcher *m);
+/* MK_ALGO_AC or MK_ALGO_BNDMQ after the auto rule was applied */
+uint32_t mk_matcher_algo(const mk_matcher *m);
+uint32_t mk_matcher_num_patterns(const mk_matcher *m);
+/* filter geometry chosen at create time: q-gram length, sampling stride, table entries */
+int mk_matcher_filter_info(const mk_matcher *m, uint32_t *q_gram, uint32_t *stride, uint64_t *entries,
+                           uint64_t *table_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Batched scan, host buffers
+ * replaces, for a whole batch of records: BNDMq::find_match / find_iter / find_all
+ * (src/pattern_matching.rs:128-153) and AhoCorasick::find_overlapping_iter
+ * (src/cmd_extract.rs:332,480,507; src/cmd_tag.rs:393-396).
+ *
+ * record i = seq_bytes[seq_off[i] .. seq_off[i+1]) (newline-free sequence bytes exactly as
+ * needletail's record.seq() / bam's record.sequence() hand them to the matcher).
+ * rec_flags[i] = 1 iff any pattern occurs in record i.
+ * MK_MODE_HITS: hits[0..*n_hits) = every occurrence, in the reference's emission order for
+ * the matcher's algorithm: AC: record, end ascending, start ascending, pattern ascending;
+ * BNDMq: record, pattern ascending, start ascending.
+ * If more than hits_cap occurrences exist: returns MK_E_CAPACITY, *n_hits = required
+ * count, rec_flags valid, hits content unspecified.  Never truncates silently.
+ * ---------------------------------------------------------------------------------- */
+int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint32_t mode,
+                  uint8_t *rec_flags, mk_hit *hits, uint64_t hits_cap, uint64_t *n_hits);
+
+/* ------------------------------------------------------------------------------------
+ * Batched scan, device-resident buffers (the kernel boundary; asynchronous)
+ *
+ * All pointers are device pointers on the matcher's device.  d_seq must be 16-byte aligned;
+ * d_rec_flags 4-byte aligned with its allocation padded to a multiple of 4 bytes.
+ * The call enqueues on `stream` (a hipStream_t, NULL = default stream): clear of
+ * d_rec_flags[0..n_rec) and of *d_n_hits, then the scan kernel.  d_hits may be NULL in
+ * MK_MODE_ANY.  Hits are written UNORDERED (order them with mk_order_hits after copying
+ * back); *d_n_hits counts every occurrence even beyond hits_cap.
+ * d_counters (may be NULL): uint64[n_pat + MK_NUM_SUMMARY] accumulated (+=) by the scan:
+ *   [0, n_pat)            occurrences per pattern (the AC meaning of pattern_hit_counts,
+ *                         src/cmd_extract.rs:353)
+ *   [n_pat + MK_SUM_*]    see below
+ * It is the vector a multi-GPU host sums across ranks (RCCL allReduce) at the end of a job.
+ * ---------------------------------------------------------------------------------- */
+#define MK_NUM_SUMMARY 8
+#define MK_SUM_HITS 0        /* nb_hits_tot */
+#define MK_SUM_RECORDS_HIT 1 /* nb_records_hit */
+#define MK_SUM_RECORDS 2     /* nb_records_tot */
+#define MK_SUM_BASES 3       /* nb_bases */
+#define MK_SUM_CANDIDATES 4  /* filter positives sent to verification (diagnostic) */
+
+int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const void *d_seq_off, uint64_t n_rec,
+                   uint32_t mode, void *d_rec_flags, void *d_hits, uint64_t hits_cap, void *d_n_hits,
+                   void *d_counters, void *stream);
+
+/* Sort hits (host memory) into the reference's emission order for this matcher. */
+int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);
+
+/* name of the scan kernel variant the last mk_scan_device on this handle launched, and its
+ * launch geometry (for profiling / roofline bookkeeping) */
+const char *mk_matcher_kernel_name(const mk_matcher *m);
+
+/* ------------------------------------------------------------------------------------
+ * Driver-loop semantics on batches (host buffers)
+ * These restate what the reference's record loops do with the matcher's answers, so that
+ * counters, log rows and keep/drop decisions are bit-identical.
+ * ---------------------------------------------------------------------------------- */
+/* extract, single file: loop body src/cmd_extract.rs:321-406.
+ * logging == 0: only keep[] and nb_records_extracted are produced (like the reference).
+ * rows (may be NULL when logging == 0) receives the log rows in emission order; on overflow
+ * returns MK_E_CAPACITY with *n_rows = required.  pattern_hit_counts[n_pat] is += updated. */
+int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint64_t n_rec, int logging,
+                      int invert, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
+                      mk_counters *counters, uint32_t *pattern_hit_counts);
+/* extract, paired: loop body src/cmd_extract.rs:463-612.  keep[i] applies to pair i. */
+int mk_extract_paired(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, uint64_t n_rec1,
+                      const uint8_t *seq2, const uint64_t *off2, uint64_t n_rec2, int logging, int invert,
+                      uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *counters,
+                      uint32_t *pattern_hit_counts);
+/* tag: process_record matching + set logic, src/cmd_tag.rs:387-467.
+ * found_off[n_rec+1] / found_pat: CSR of the distinct matched pattern indices per record,
+ * ascending (= kmers_found after sort_unstable + dedup, src/cmd_tag.rs:484-485, before the
+ * merge with a pre-existing tag value).  On found_cap overflow: MK_E_CAPACITY, found_off[n_rec]
+ * = required. */
+int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint64_t n_rec, int logging,
+                   int filter_matching, int invert, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
+                   mk_counters *counters, uint32_t *pattern_hit_counts, uint64_t *found_off, uint32_t *found_pat,
+                   uint64_t found_cap);
+/* tag value, src/cmd_tag.rs:470-490: found patterns merged with an existing tag value
+ * (split on ','), sort_unstable, dedup, join(",").  Writes a NUL-terminated string into
+ * out (cap bytes); returns MK_E_CAPACITY with *out_len = required (excl. NUL) if too small. */
+int mk_tag_value(const mk_matcher *m, const uint32_t *found_pat, uint64_t n_found, const char *existing, char *out,
+                 size_t cap, size_t *out_len);
+
+/* ------------------------------------------------------------------------------------
+ * Synthetic workload generator (device; used by bench.py and the full-size parity tests)
+ * Fills d_seq[0..n_rec*read_len) with uniform ACGT from a counter-based generator
+ * (value at byte i depends only on (seed, i)), writes d_seq_off[i] = i*read_len, and plants
+ * pattern (i * 2654435761 mod n_pat) of the matcher at a hashed offset in every record i
+ * with hash(seed, i) % plant_every == 0 (plant_every == 0: none).
+ * mk_synth_reads_host produces the identical bytes on the CPU for record range [rec0, rec0+n).
+ * ---------------------------------------------------------------------------------- */
+int mk_synth_reads_device(mk_matcher *m, uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every,
+                          void *d_seq, void *d_seq_off, void *stream);
+int mk_synth_reads_host(const mk_matcher *m, uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len,
+                        uint32_t plant_every, uint8_t *seq, uint64_t *seq_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+// filter.hpp -- definitions shared by the host-side pattern compiler and the gfx950 scan kernel.
+//
+// The device scan does not run BNDMq or a DFA.  Both reference matchers report exactly "every
+// occurrence of every pattern" (SURVEY.md §0.4), so the kernel computes that result set with a
+// streaming q-gram filter + exact verification:
+//
+//   * 2-bit code of a byte: code(c) = (c >> 1) & 3  (A,a->0  C,c->1  T,t->2  G,g->3; any other
+//     byte maps somewhere -- the filter only needs  bytes equal => codes equal,  and that
+//     holds for every byte value, and for ASCII case folding too).
+//   * every pattern contributes the S q-grams starting at offsets 0..S-1 of its first
+//     L' = q + S - 1 bytes.  The text is sampled at positions t = 0 mod S.  An occurrence of
+//     pattern P at text position p covers exactly one sampled position t in [p, p+S-1], and
+//     the text q-gram at t equals P's q-gram at offset t-p, so: no false negatives, and every
+//     occurrence is discovered exactly once (t-p is unique).
+//   * level 1 (LDS): blocked Bloom filter over the packed q-gram keys, 2 bits per key inside
+//     one 32-bit word;   level 2 (L2/HBM): open-addressing table key -> (pattern, offset);
+//     level 3: byte-exact (or ASCII-case-folded) comparison against the pattern text, then
+//     the record-boundary check.  Only level 3 decides; levels 1-2 may only over-approximate.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MK_HD __host__ __device__ __forceinline__
+#else
+#define MK_HD inline
+#endif
+
+namespace mk {
+
+constexpr uint32_t kBloomLog2Words = 15;                   // 32768 words
+constexpr uint32_t kBloomWords = 1u << kBloomLog2Words;    // 128 KiB of LDS
+constexpr uint32_t kBloomBytes = kBloomWords * 4;
+constexpr uint32_t kEmptyPat = 0xFFFFFFFFu;
+constexpr int kChunkBytes = 1024;                          // one wave-iteration: 64 lanes x 16 B
+constexpr int kTileChunks = 16;                            // contiguous chunks per wave tile
+constexpr int kBlockThreads = 1024;                        // 16 waves, one workgroup per CU
+
+// one exact-table slot (16 B, one global_load_dwordx4)
+struct alignas(16) TableEntry {
+    uint64_t key;
+    uint32_t pat;  // kEmptyPat = empty slot
+    uint32_t off;  // offset of the q-gram inside the pattern (0..S-1)
+};
+
+MK_HD uint32_t code2(uint8_t c) { return (c >> 1) & 3u; }
+
+// hash for the LDS Bloom filter: (word index, bit a, bit b)
+MK_HD uint32_t bloom_hash(uint32_t lo, uint32_t hi) {
+    uint32_t x = lo ^ (hi * 0x9E3779B1u);
+    return x * 0x85EBCA6Bu;
+}
+MK_HD uint32_t bloom_hash32(uint32_t lo) { return lo * 0x85EBCA6Bu; }
+MK_HD uint32_t bloom_word(uint32_t h) { return h >> (32 - kBloomLog2Words); }
+MK_HD uint32_t bloom_bit_a(uint32_t h) { return (h >> 12) & 31u; }
+MK_HD uint32_t bloom_bit_b(uint32_t h) { return (h >> 7) & 31u; }
+
+// hash for the exact table
+MK_HD uint32_t table_hash(uint64_t key) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(x >> 32) ^ (uint32_t)(x >> 11);
+}
+
+MK_HD uint8_t fold_ascii(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c | 0x20) : c; }
+
+// counter-based synthetic read generator (bench / full-size parity tests)
+MK_HD uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// the 32 bases of block b (bytes 32b .. 32b+31), 2 bits each, base j at bits 2j
+MK_HD uint64_t synth_block(uint64_t seed, uint64_t b) { return splitmix64(seed ^ (b * 0xD1B54A32D192ED03ull)); }
+MK_HD uint8_t synth_base(uint64_t bits, uint32_t j) {
+    const uint32_t lut = ('A') | ('C' << 8) | ('G' << 16) | ((uint32_t)'T' << 24);
+    return (uint8_t)(lut >> (8 * ((bits >> (2 * j)) & 3u)));
+}
+MK_HD uint64_t synth_rec_hash(uint64_t seed, uint64_t rec) { return splitmix64((seed + 0x5851F42D4C957F2Dull) ^ (rec * 0x2545F4914F6CDD1Dull)); }
+
+}  // namespace mk

@@ -1,0 +1,388 @@
+// matcher.cpp -- host side of the C ABI: matcher handle, pattern-set compiler (q-gram filter +
+// exact table), device/host batched scans, emission-order restoration.
+// Reference interfaces replaced: BNDMq::new (src/pattern_matching.rs:61-78), the AhoCorasick
+// builder (src/cmd_extract.rs:260-265), find_match / find_iter / find_overlapping_iter.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_common.h"
+#include "matcher_internal.h"
+#include "scan_kernel.h"
+
+namespace mk {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define MK_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(MK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+// ---- filter geometry -----------------------------------------------------------------------
+// Pick (q, S): sampling stride S in {16,8,4,2,1}, q-gram length q = min(32, Lmin - S + 1).
+// Larger S = fewer probes per base but S x more table entries; keep the Bloom filter sparse
+// (<= ~48k entries in 2^20 bits at 2 bits/key) and q-grams selective (q >= 14) when S > 1.
+static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t *S) {
+    const char *force = getenv("MERKURIO_FORCE_STRIDE");  // tuning / test hook
+    int forced = force ? atoi(force) : 0;
+    for (uint32_t s : {16u, 8u, 4u, 2u, 1u}) {
+        if (s > lmin) continue;
+        uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
+        if (forced) {
+            if ((int)s != forced) continue;
+        } else if (s > 1 && (qq < 14 || n_pat * s > 49152)) {
+            continue;
+        }
+        *q = qq;
+        *S = s;
+        return;
+    }
+    *q = std::min<uint32_t>(32, lmin);
+    *S = 1;
+}
+
+uint64_t pack_qgram(const uint8_t *p, uint32_t q) {
+    uint64_t k = 0;
+    for (uint32_t i = 0; i < q; ++i) k |= (uint64_t)code2(p[i]) << (2 * i);
+    return k;
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+
+static int ensure(void **p, size_t *cap, size_t need) {
+    if (need <= *cap) return MK_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 4 + 4096;
+    MK_HIP(hipMalloc(p, want));
+    *cap = want;
+    return MK_OK;
+}
+
+extern "C" {
+
+int mk_abi_version(void) { return MK_ABI_VERSION; }
+const char *mk_last_error(void) { return g_last_error.c_str(); }
+
+int mk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mk_free(void *p) { free(p); }
+
+int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
+                      uint32_t flags, int32_t device, mk_matcher **out) {
+    if (!out) return fail(MK_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (n_pat == 0 || !pat_off || !pat_bytes) return fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
+    if (algo > MK_ALGO_BNDMQ) return fail(MK_E_INVALID_ARG, "unknown algo %u", algo);
+    const bool ci = flags & MK_FLAG_ASCII_CASE_INSENSITIVE;
+    uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
+    for (uint32_t i = 0; i < n_pat; ++i) {
+        if (pat_off[i + 1] < pat_off[i]) return fail(MK_E_INVALID_ARG, "pattern offsets not monotone");
+        uint32_t len = pat_off[i + 1] - pat_off[i];
+        lmin = std::min(lmin, len);
+        lmax = std::max(lmax, len);
+    }
+    // algorithm selection: src/cmd_extract.rs:166-171, src/helpers.rs:203-211
+    uint32_t use = algo;
+    if (ci)
+        use = MK_ALGO_AC;
+    else if (algo == MK_ALGO_AUTO)
+        use = (q == 0 && mk_recommend_aho_corasick(n_pat, lmax)) ? MK_ALGO_AC : MK_ALGO_BNDMQ;
+    // validation errors of BNDMq::new, in pattern order (src/cmd_extract.rs:267-276)
+    if (use == MK_ALGO_BNDMQ) {
+        for (uint32_t i = 0; i < n_pat; ++i) {
+            size_t len = pat_off[i + 1] - pat_off[i];
+            size_t qq = q ? q : mk_tune_q_value(len);
+            if (!q && len >= 65) return fail(MK_E_PATTERN_TOO_LONG, "Pattern length is too long for BNDMq.");
+            if (len == 0) return fail(MK_E_EMPTY_PATTERN, "Pattern is empty.");
+            if (qq == 0 || qq > len)
+                return fail(MK_E_INVALID_Q, "Invalid q-gram length: %zu. Must be between 1 and pattern length.", qq);
+            if (len > 64)
+                return fail(MK_E_PATTERN_TOO_LONG,
+                            "Pattern length %zu is too large for this architecture when using BNDM (max 64).", len);
+        }
+    } else if (lmin == 0) {
+        return fail(MK_E_EMPTY_PATTERN, "Pattern is empty.");
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MK_E_HIP, "no HIP device available: the MI355X scan path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MK_E_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+    MK_HIP(hipSetDevice(device));
+
+    mk_matcher *m = new mk_matcher();
+    m->device = device;
+    m->algo = use;
+    m->flags = flags;
+    m->n_pat = n_pat;
+    m->pat_bytes.assign(pat_bytes, pat_bytes + pat_off[n_pat]);
+    m->pat_off.assign(pat_off, pat_off + n_pat + 1);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        m->num_cus = prop.multiProcessorCount;
+
+    // ---- compile the pattern set: Bloom filter + exact table
+    choose_geometry(lmin, n_pat, &m->q, &m->S);
+    const uint32_t q_f = m->q, S = m->S;
+    m->entries = (uint64_t)n_pat * S;
+    uint64_t slots = 64;
+    while (slots < 2 * m->entries) slots <<= 1;
+    if (slots > (1ull << 31)) {
+        const unsigned long long ne = m->entries;
+        delete m;
+        return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", ne);
+    }
+    m->table_slots = (uint32_t)slots;
+    std::vector<uint32_t> bloom(kBloomWords, 0);
+    std::vector<TableEntry> table(slots);
+    for (auto &e : table) {
+        e.key = 0;
+        e.pat = kEmptyPat;
+        e.off = 0;
+    }
+    const uint32_t tmask = m->table_slots - 1;
+    for (uint32_t pi = 0; pi < n_pat; ++pi) {
+        const uint8_t *p = pat_bytes + pat_off[pi];
+        for (uint32_t o = 0; o < S; ++o) {
+            const uint64_t key = pack_qgram(p + o, q_f);
+            const uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
+            bloom[bloom_word(h)] |= (1u << bloom_bit_a(h)) | (1u << bloom_bit_b(h));
+            uint32_t slot = table_hash(key) & tmask;
+            while (table[slot].pat != kEmptyPat) slot = (slot + 1) & tmask;
+            table[slot].key = key;
+            table[slot].pat = pi;
+            table[slot].off = o;
+        }
+    }
+    auto bail = [&](int code) {
+        mk_matcher_destroy(m);
+        return code;
+    };
+#define MK_HIP_M(call)                                                                                     \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return bail(fail(MK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); \
+    } while (0)
+    MK_HIP_M(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    MK_HIP_M(hipMalloc((void **)&m->d_bloom, kBloomBytes));
+    MK_HIP_M(hipMalloc((void **)&m->d_table, slots * sizeof(TableEntry)));
+    MK_HIP_M(hipMalloc((void **)&m->d_pat_bytes, m->pat_bytes.size() + 16));
+    MK_HIP_M(hipMalloc((void **)&m->d_pat_off, (n_pat + 1) * sizeof(uint32_t)));
+    MK_HIP_M(hipMalloc((void **)&m->d_nhits, sizeof(unsigned long long)));
+    MK_HIP_M(hipMemcpy(m->d_bloom, bloom.data(), kBloomBytes, hipMemcpyHostToDevice));
+    MK_HIP_M(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
+    MK_HIP_M(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
+    MK_HIP_M(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+#undef MK_HIP_M
+    *out = m;
+    return MK_OK;
+}
+
+void mk_matcher_destroy(mk_matcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
+                    (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+uint32_t mk_matcher_algo(const mk_matcher *m) { return m ? m->algo : 0; }
+uint32_t mk_matcher_num_patterns(const mk_matcher *m) { return m ? m->n_pat : 0; }
+const char *mk_matcher_kernel_name(const mk_matcher *m) { return m ? m->kernel_name : ""; }
+
+int mk_matcher_filter_info(const mk_matcher *m, uint32_t *q_gram, uint32_t *stride, uint64_t *entries,
+                           uint64_t *table_bytes) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (q_gram) *q_gram = m->q;
+    if (stride) *stride = m->S;
+    if (entries) *entries = m->entries;
+    if (table_bytes) *table_bytes = (uint64_t)m->table_slots * sizeof(TableEntry);
+    return MK_OK;
+}
+
+int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const void *d_seq_off, uint64_t n_rec,
+                   uint32_t mode, void *d_rec_flags, void *d_hits, uint64_t hits_cap, void *d_n_hits,
+                   void *d_counters, void *stream) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (mode > MK_MODE_HITS) return fail(MK_E_INVALID_ARG, "unknown mode %u", mode);
+    if (((uintptr_t)d_seq & 15) != 0) return fail(MK_E_INVALID_ARG, "d_seq must be 16-byte aligned");
+    if (((uintptr_t)d_rec_flags & 3) != 0) return fail(MK_E_INVALID_ARG, "d_rec_flags must be 4-byte aligned");
+    if (!d_n_hits || !d_rec_flags || (!d_seq_off && n_rec)) return fail(MK_E_INVALID_ARG, "null device buffer");
+    if (mode == MK_MODE_HITS && !d_hits && hits_cap) return fail(MK_E_INVALID_ARG, "d_hits is null");
+    hipStream_t st = (hipStream_t)stream;
+    MK_HIP(hipSetDevice(m->device));
+    MK_HIP(hipMemsetAsync(d_n_hits, 0, sizeof(unsigned long long), st));
+    if (n_rec) MK_HIP(hipMemsetAsync(d_rec_flags, 0, (n_rec + 3) & ~(uint64_t)3, st));
+    if (n_rec == 0 || n_bytes == 0) return MK_OK;
+    ScanParams p;
+    memset(&p, 0, sizeof(p));
+    p.seq = (const uint8_t *)d_seq;
+    p.n_bytes = n_bytes;
+    p.rec_off = (const uint64_t *)d_seq_off;
+    p.n_rec = n_rec;
+    const uint64_t tile_bytes = (uint64_t)kTileChunks * kChunkBytes;
+    p.n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
+    p.bloom = m->d_bloom;
+    p.table = m->d_table;
+    p.table_mask = m->table_slots - 1;
+    p.pat_bytes = m->d_pat_bytes;
+    p.pat_off = m->d_pat_off;
+    p.n_pat = m->n_pat;
+    p.q = m->q;
+    const uint64_t kmask = m->q >= 32 ? ~0ull : ((1ull << (2 * m->q)) - 1);
+    p.key_mask_lo = (uint32_t)kmask;
+    p.key_mask_hi = (uint32_t)(kmask >> 32);
+    p.case_insensitive = (m->flags & MK_FLAG_ASCII_CASE_INSENSITIVE) ? 1 : 0;
+    p.rec_flags32 = (uint32_t *)d_rec_flags;
+    p.hits = (mk_hit *)d_hits;
+    p.hits_cap = (mode == MK_MODE_HITS) ? hits_cap : 0;
+    p.n_hits = (unsigned long long *)d_n_hits;
+    p.counters = (unsigned long long *)d_counters;
+    const uint64_t waves_per_block = kBlockThreads / 64;
+    uint64_t blocks = (p.n_tiles + waves_per_block - 1) / waves_per_block;
+    if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
+    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, (int)blocks, st);
+    if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);
+    m->kernel_name = name;
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (m->algo == MK_ALGO_AC) {
+        const uint32_t *off = m->pat_off.data();
+        // aho-corasick overlapping DFA search: end ascending; at one end the state's own
+        // patterns (longest, i.e. smallest start) first, pattern id ascending within a state
+        std::sort(hits, hits + n_hits, [off](const mk_hit &a, const mk_hit &b) {
+            if (a.rec != b.rec) return a.rec < b.rec;
+            uint64_t ea = (uint64_t)a.pos + (off[a.pat + 1] - off[a.pat]);
+            uint64_t eb = (uint64_t)b.pos + (off[b.pat + 1] - off[b.pat]);
+            if (ea != eb) return ea < eb;
+            if (a.pos != b.pos) return a.pos < b.pos;
+            return a.pat < b.pat;
+        });
+    } else {
+        // BNDMq driver loop: pattern-major, positions ascending (src/cmd_extract.rs:365-384)
+        std::sort(hits, hits + n_hits, [](const mk_hit &a, const mk_hit &b) {
+            if (a.rec != b.rec) return a.rec < b.rec;
+            if (a.pat != b.pat) return a.pat < b.pat;
+            return a.pos < b.pos;
+        });
+    }
+    return MK_OK;
+}
+
+int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint32_t mode,
+                  uint8_t *rec_flags, mk_hit *hits, uint64_t hits_cap, uint64_t *n_hits) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (n_hits) *n_hits = 0;
+    if (n_rec == 0) return MK_OK;
+    if (!seq_off || !rec_flags) return fail(MK_E_INVALID_ARG, "null buffer");
+    const uint64_t base = seq_off[0];
+    const uint64_t n_bytes = seq_off[n_rec] - base;
+    if (n_bytes && !seq_bytes) return fail(MK_E_INVALID_ARG, "null sequence buffer");
+    MK_HIP(hipSetDevice(m->device));
+    int rc;
+    if ((rc = ensure((void **)&m->d_seq, &m->d_seq_cap, n_bytes + 64))) return rc;
+    if ((rc = ensure((void **)&m->d_off, &m->d_off_cap, (n_rec + 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure((void **)&m->d_flags, &m->d_flags_cap, n_rec + 8))) return rc;
+    std::vector<uint64_t> rel;
+    const uint64_t *off_src = seq_off;
+    if (base != 0) {  // device offsets are relative to the first byte uploaded
+        rel.resize(n_rec + 1);
+        for (uint64_t i = 0; i <= n_rec; ++i) rel[i] = seq_off[i] - base;
+        off_src = rel.data();
+    }
+    if (n_bytes) MK_HIP(hipMemcpyAsync(m->d_seq, seq_bytes + base, n_bytes, hipMemcpyHostToDevice, m->stream));
+    MK_HIP(hipMemcpyAsync(m->d_off, off_src, (n_rec + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+    uint64_t cap = (mode == MK_MODE_HITS) ? std::max<uint64_t>(hits_cap, 1024) : 0;
+    unsigned long long found = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (cap && (rc = ensure((void **)&m->d_hits, &m->d_hits_cap, cap * sizeof(mk_hit)))) return rc;
+        rc = mk_scan_device(m, m->d_seq, n_bytes, m->d_off, n_rec, mode, m->d_flags, m->d_hits, cap, m->d_nhits, nullptr,
+                            m->stream);
+        if (rc) return rc;
+        MK_HIP(hipMemcpyAsync(&found, m->d_nhits, sizeof(found), hipMemcpyDeviceToHost, m->stream));
+        MK_HIP(hipStreamSynchronize(m->stream));
+        if (mode != MK_MODE_HITS || found <= cap || found > hits_cap) break;
+        cap = found;  // device buffer was the limit, the caller's buffer is big enough: rescan
+    }
+    MK_HIP(hipMemcpy(rec_flags, m->d_flags, n_rec, hipMemcpyDeviceToHost));
+    if (mode == MK_MODE_HITS) {
+        if (n_hits) *n_hits = found;
+        if (found > hits_cap)
+            return fail(MK_E_CAPACITY, "hits buffer too small: %llu occurrences, capacity %llu", found,
+                        (unsigned long long)hits_cap);
+        if (found) {
+            MK_HIP(hipMemcpy(hits, m->d_hits, found * sizeof(mk_hit), hipMemcpyDeviceToHost));
+            mk_order_hits(m, hits, found);
+        }
+    }
+    return MK_OK;
+}
+
+int mk_synth_reads_device(mk_matcher *m, uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every,
+                          void *d_seq, void *d_seq_off, void *stream) {
+    if (!m || !d_seq || !d_seq_off) return fail(MK_E_INVALID_ARG, "null argument");
+    MK_HIP(hipSetDevice(m->device));
+    launch_synth(seed, n_rec, read_len, plant_every, m->d_pat_bytes, m->d_pat_off, m->n_pat, (uint8_t *)d_seq,
+                 (uint64_t *)d_seq_off, (hipStream_t)stream);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int mk_synth_reads_host(const mk_matcher *m, uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len,
+                        uint32_t plant_every, uint8_t *seq, uint64_t *seq_off) {
+    if (!m || !seq || !seq_off) return fail(MK_E_INVALID_ARG, "null argument");
+    for (uint64_t r = 0; r <= n_rec; ++r) seq_off[r] = r * read_len;
+    const uint64_t g0 = rec0 * read_len, nb = n_rec * read_len;
+    for (uint64_t i = 0; i < nb; ++i) {
+        const uint64_t g = g0 + i;
+        seq[i] = synth_base(synth_block(seed, g >> 5), (uint32_t)(g & 31));
+    }
+    if (plant_every) {
+        for (uint64_t k = 0; k < n_rec; ++k) {
+            const uint64_t r = rec0 + k;
+            const uint64_t h = synth_rec_hash(seed, r);
+            if (h % plant_every != 0) continue;
+            const uint32_t pat = (uint32_t)((r * 2654435761ull) % m->n_pat);
+            const uint32_t a = m->pat_off[pat], len = m->pat_off[pat + 1] - a;
+            if (len > read_len) continue;
+            const uint32_t o = (uint32_t)((h >> 32) % (read_len - len + 1));
+            memcpy(seq + k * read_len + o, m->pat_bytes.data() + a, len);
+        }
+    }
+    return MK_OK;
+}
+
+}  // extern "C"

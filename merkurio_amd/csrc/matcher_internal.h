@@ -1,0 +1,38 @@
+// matcher_internal.h -- the opaque mk_matcher handle (shared by the host translation units)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "filter.hpp"
+#include "host_common.h"
+
+struct mk_matcher {
+    int device = 0;
+    int num_cus = 256;
+    uint32_t algo = MK_ALGO_AC;
+    uint32_t flags = 0;
+    uint32_t n_pat = 0;
+    std::vector<uint8_t> pat_bytes;
+    std::vector<uint32_t> pat_off;
+    // filter
+    uint32_t q = 0, S = 1;
+    uint64_t entries = 0;
+    uint32_t table_slots = 0;
+    uint32_t *d_bloom = nullptr;
+    mk::TableEntry *d_table = nullptr;
+    uint8_t *d_pat_bytes = nullptr;
+    uint32_t *d_pat_off = nullptr;
+    // workspace of the host-buffer API
+    hipStream_t stream = nullptr;
+    uint8_t *d_seq = nullptr;
+    size_t d_seq_cap = 0;
+    uint64_t *d_off = nullptr;
+    size_t d_off_cap = 0;
+    uint8_t *d_flags = nullptr;
+    size_t d_flags_cap = 0;
+    mk_hit *d_hits = nullptr;
+    size_t d_hits_cap = 0;
+    unsigned long long *d_nhits = nullptr;
+    const char *kernel_name = "";
+};

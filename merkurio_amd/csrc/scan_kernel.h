@@ -1,0 +1,44 @@
+// scan_kernel.h -- host-visible declarations of the gfx950 scan kernels (scan_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/merkurio_hip.h"
+#include "filter.hpp"
+
+namespace mk {
+
+struct ScanParams {
+    // text: concatenated records
+    const uint8_t *seq;       // 16-byte aligned
+    uint64_t n_bytes;         // == rec_off[n_rec]
+    const uint64_t *rec_off;  // n_rec + 1
+    uint64_t n_rec;
+    uint64_t n_tiles;  // ceil(n_bytes / (kTileChunks * kChunkBytes))
+    // compiled pattern set
+    const uint32_t *bloom;    // kBloomWords
+    const TableEntry *table;  // table_mask + 1 slots
+    uint32_t table_mask;
+    const uint8_t *pat_bytes;
+    const uint32_t *pat_off;  // n_pat + 1
+    uint32_t n_pat;
+    uint32_t q;           // q-gram length (1..32)
+    uint32_t key_mask_lo;  // low / high 32 bits of the 2q-bit key mask
+    uint32_t key_mask_hi;
+    uint32_t case_insensitive;
+    // outputs
+    uint32_t *rec_flags32;  // rec_flags viewed as 32-bit words (byte r = record r)
+    mk_hit *hits;           // may be null when !EMIT
+    uint64_t hits_cap;
+    unsigned long long *n_hits;    // device counter (every occurrence, even beyond hits_cap)
+    unsigned long long *counters;  // n_pat + MK_NUM_SUMMARY, may be null
+};
+
+// S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
+// Returns the kernel's name (static storage) or nullptr for an unsupported S.
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream);
+
+void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
+                  const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream);
+
+}  // namespace mk

@@ -1,0 +1,282 @@
+// scan_kernel.hip -- hand-written gfx950 (CDNA4, wave64) multi-pattern scan kernel.
+//
+// Replaces, for a whole batch of records at once, the reference's per-record matcher calls:
+//   BNDMq::find_match / find_iter        src/pattern_matching.rs:82-209
+//   AhoCorasick::find_overlapping_iter   src/cmd_extract.rs:332,480,507; src/cmd_tag.rs:393-396
+// Result set = every (record, pattern, start) occurrence + per-record any-hit flags
+// (bit-exact vs the oracle); emission ORDER is restored on the host (matcher.cpp).
+//
+// Shape of the work (integer, HBM-streaming; no MFMA):
+//   * one persistent 1024-thread workgroup per CU (16 waves); the 128 KiB q-gram Bloom filter
+//     of the pattern set lives in LDS for the life of the workgroup;
+//   * the concatenated text is cut into 16 KiB tiles; a wave walks a tile in 1 KiB chunks:
+//     each lane issues ONE global_load_dwordx4 (64 lanes x 16 B = 1 KiB, fully coalesced) per
+//     chunk, the next chunk's load is in flight while the current one is processed;
+//   * a lane 2-bit-packs its 16 bytes into one dword, gets the 32-base halo from lanes +1/+2
+//     (cross-lane, no LDS memory traffic), forms the 16/S sampled q-gram keys with
+//     v_alignbit, hashes, and probes the LDS filter (one ds_read_b32 per sample);
+//   * filter positives (rare) take a divergent slow path: exact table in L2/HBM -> byte-exact
+//     verification against the pattern text -> binary search of the record offsets ->
+//     boundary check -> flag / hit tuple / counters via atomics (wave-aggregated by the
+//     compiler's atomic optimizer).
+#include "scan_kernel.h"
+
+namespace mk {
+
+// 4 ASCII bytes (little endian in d) -> 8 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3
+__device__ __forceinline__ uint32_t pack4(uint32_t d) {
+    uint32_t x = d & 0x06060606u;
+    uint32_t y = x | (x >> 6);
+    uint32_t z = y | (y >> 12);
+    return (z >> 1) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t pack16(uint4 v) {
+    return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+}
+
+// 16 bytes at text position pos (pos % 16 == 0); bytes at or beyond n read as 0
+__device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ seq, uint64_t pos, uint64_t n) {
+    if (pos + 16 <= n) return *reinterpret_cast<const uint4 *>(seq + pos);
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (pos < n) {
+        uint32_t rem = (uint32_t)(n - pos);
+        for (uint32_t i = 0; i < rem; ++i) w[i >> 2] |= (uint32_t)seq[pos + i] << (8 * (i & 3));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- slow path -------------------------------------------------------------------------
+template <bool EMIT>
+__device__ __noinline__ void verify_candidate(const ScanParams &P, uint64_t key, uint64_t t) {
+    if (P.counters) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], 1ull);
+    uint32_t slot = table_hash(key) & P.table_mask;
+    for (;;) {
+        const TableEntry e = P.table[slot];
+        if (e.pat == kEmptyPat) break;
+        slot = (slot + 1) & P.table_mask;
+        if (e.key != key) continue;
+        // level 3: exact comparison of the whole pattern at p = t - off
+        if (t < e.off) continue;
+        const uint64_t p = t - e.off;
+        const uint32_t a = P.pat_off[e.pat];
+        const uint32_t len = P.pat_off[e.pat + 1] - a;
+        if (p + len > P.n_bytes) continue;
+        bool eq = true;
+        if (P.case_insensitive) {
+            for (uint32_t i = 0; i < len; ++i)
+                if (fold_ascii(P.seq[p + i]) != fold_ascii(P.pat_bytes[a + i])) {
+                    eq = false;
+                    break;
+                }
+        } else {
+            for (uint32_t i = 0; i < len; ++i)
+                if (P.seq[p + i] != P.pat_bytes[a + i]) {
+                    eq = false;
+                    break;
+                }
+        }
+        if (!eq) continue;
+        // record containing p: largest r with rec_off[r] <= p
+        if (p < P.rec_off[0]) continue;
+        uint64_t lo = 0, hi = P.n_rec;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (P.rec_off[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint64_t rstart = P.rec_off[lo];
+        if (p + len > P.rec_off[lo + 1]) continue;  // occurrence would cross a record boundary
+        // ---- a true occurrence
+        const uint32_t sh = (uint32_t)(lo & 3) * 8;
+        const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << sh);
+        if (P.counters) {
+            if (((old >> sh) & 0xFFu) == 0) atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS_HIT], 1ull);
+            atomicAdd(&P.counters[e.pat], 1ull);
+            atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], 1ull);
+        }
+        if (EMIT) {
+            const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
+            if (idx < P.hits_cap) {
+                mk_hit h;
+                h.rec = lo;
+                h.pat = e.pat;
+                h.pos = (uint32_t)(p - rstart);
+                P.hits[idx] = h;
+            }
+        }
+    }
+}
+
+// ---- main kernel -----------------------------------------------------------------------
+template <int S, bool WIDE, bool EMIT>
+__global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
+    extern __shared__ uint32_t bloom[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
+        uint4 *dst = reinterpret_cast<uint4 *>(bloom);
+        for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    if (P.counters && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS], (unsigned long long)P.n_rec);
+        atomicAdd(&P.counters[P.n_pat + MK_SUM_BASES], (unsigned long long)P.n_bytes);
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kBlockThreads / 64);
+    constexpr int NS = 16 / S;
+    const uint32_t mask_lo = P.key_mask_lo, mask_hi = P.key_mask_hi;
+
+    for (uint64_t tile = wave_id; tile < P.n_tiles; tile += n_waves) {
+        const uint64_t base = tile * (uint64_t)(kTileChunks * kChunkBytes);
+        uint32_t pk_cur = pack16(load16(P.seq, base + lane * 16, P.n_bytes));
+        for (int c = 0; c < kTileChunks; ++c) {
+            const uint64_t cpos = base + (uint64_t)c * kChunkBytes;
+            if (cpos >= P.n_bytes) break;  // wave-uniform
+            // next chunk (possibly the first chunk of the following tile): halo + pipeline
+            const uint32_t pk_nxt = pack16(load16(P.seq, cpos + kChunkBytes + lane * 16, P.n_bytes));
+            const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
+            const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
+            const uint32_t w0 = pk_cur;
+            uint32_t w1 = __shfl_down(pk_cur, 1);
+            uint32_t w2 = __shfl_down(pk_cur, 2);
+            if (lane == 63) w1 = n0;
+            if (lane == 62) w2 = n0;
+            if (lane == 63) w2 = n1;
+
+            uint32_t cand = 0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int sh = 2 * j * S;  // constant after unrolling
+                uint32_t lo = sh ? __builtin_amdgcn_alignbit(w1, w0, sh) : w0;
+                uint32_t h;
+                if (WIDE) {
+                    uint32_t hi = (sh ? __builtin_amdgcn_alignbit(w2, w1, sh) : w1) & mask_hi;
+                    h = bloom_hash(lo, hi);
+                } else {
+                    lo &= mask_lo;
+                    h = bloom_hash32(lo);
+                }
+                const uint32_t w = bloom[bloom_word(h)];
+                const uint32_t tbit = (w >> bloom_bit_a(h)) & (w >> bloom_bit_b(h)) & 1u;
+                cand |= tbit << j;
+            }
+
+            // slow path: divergent, rare
+            while (cand) {
+                const int j = __ffs(cand) - 1;
+                cand &= cand - 1;
+                const uint32_t sh = 2u * (uint32_t)j * S;
+                const uint64_t lo64 = (((uint64_t)w1 << 32) | w0) >> sh;
+                const uint64_t hi64 = (((uint64_t)w2 << 32) | w1) >> sh;
+                const uint64_t key = ((uint64_t)((uint32_t)lo64 & mask_lo)) | ((uint64_t)((uint32_t)hi64 & mask_hi) << 32);
+                const uint64_t t = cpos + lane * 16 + (uint64_t)j * S;
+                if (t < P.n_bytes) verify_candidate<EMIT>(P, key, t);
+            }
+            pk_cur = pk_nxt;
+        }
+    }
+}
+
+template <int S>
+static const char *launch_s(const ScanParams &p, bool wide, bool emit, int grid, hipStream_t st) {
+    dim3 g(grid), b(kBlockThreads);
+#define MK_LAUNCH(W, E)                                                                                        \
+    do {                                                                                                       \
+        static bool attr_done = false;                                                                         \
+        if (!attr_done) {                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mk_scan_kernel<S, W, E>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBloomBytes);           \
+            attr_done = true;                                                                                  \
+        }                                                                                                      \
+        hipLaunchKernelGGL((mk_scan_kernel<S, W, E>), g, b, kBloomBytes, st, p);                               \
+    } while (0)
+    if (wide) {
+        if (emit)
+            MK_LAUNCH(true, true);
+        else
+            MK_LAUNCH(true, false);
+    } else {
+        if (emit)
+            MK_LAUNCH(false, true);
+        else
+            MK_LAUNCH(false, false);
+    }
+#undef MK_LAUNCH
+    static const char *names[5][2][2] = {
+        {{"mk_scan_kernel<1,false,false>", "mk_scan_kernel<1,false,true>"},
+         {"mk_scan_kernel<1,true,false>", "mk_scan_kernel<1,true,true>"}},
+        {{"mk_scan_kernel<2,false,false>", "mk_scan_kernel<2,false,true>"},
+         {"mk_scan_kernel<2,true,false>", "mk_scan_kernel<2,true,true>"}},
+        {{"mk_scan_kernel<4,false,false>", "mk_scan_kernel<4,false,true>"},
+         {"mk_scan_kernel<4,true,false>", "mk_scan_kernel<4,true,true>"}},
+        {{"mk_scan_kernel<8,false,false>", "mk_scan_kernel<8,false,true>"},
+         {"mk_scan_kernel<8,true,false>", "mk_scan_kernel<8,true,true>"}},
+        {{"mk_scan_kernel<16,false,false>", "mk_scan_kernel<16,false,true>"},
+         {"mk_scan_kernel<16,true,false>", "mk_scan_kernel<16,true,true>"}},
+    };
+    const int si = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
+    return names[si][wide ? 1 : 0][emit ? 1 : 0];
+}
+
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream) {
+    switch (S) {
+        case 1: return launch_s<1>(p, wide, emit, grid_blocks, stream);
+        case 2: return launch_s<2>(p, wide, emit, grid_blocks, stream);
+        case 4: return launch_s<4>(p, wide, emit, grid_blocks, stream);
+        case 8: return launch_s<8>(p, wide, emit, grid_blocks, stream);
+        case 16: return launch_s<16>(p, wide, emit, grid_blocks, stream);
+        default: return nullptr;
+    }
+}
+
+// ---- synthetic reads (bench / full-size parity tests) ----------------------------------
+__global__ void mk_synth_fill_kernel(uint64_t seed, uint64_t n_bytes, uint8_t *__restrict__ seq) {
+    const uint64_t n16 = (n_bytes + 15) / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t bits = synth_block(seed, i >> 1) >> (32 * (i & 1));
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (uint32_t)synth_base(bits, 4 * k + b) << (8 * b);
+            w[k] = v;
+        }
+        const uint64_t pos = i * 16;
+        if (pos + 16 <= n_bytes) {
+            *reinterpret_cast<uint4 *>(seq + pos) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (uint64_t k = 0; pos + k < n_bytes; ++k) seq[pos + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        }
+    }
+}
+
+__global__ void mk_synth_off_plant_kernel(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every,
+                                          const uint8_t *__restrict__ pat_bytes, const uint32_t *__restrict__ pat_off,
+                                          uint32_t n_pat, uint8_t *__restrict__ seq, uint64_t *__restrict__ seq_off) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
+        seq_off[r] = r * read_len;
+        if (r == n_rec || plant_every == 0) continue;
+        const uint64_t h = synth_rec_hash(seed, r);
+        if (h % plant_every != 0) continue;
+        const uint32_t pat = (uint32_t)((r * 2654435761ull) % n_pat);
+        const uint32_t a = pat_off[pat], len = pat_off[pat + 1] - a;
+        if (len > read_len) continue;
+        const uint32_t o = (uint32_t)((h >> 32) % (read_len - len + 1));
+        for (uint32_t i = 0; i < len; ++i) seq[r * read_len + o + i] = pat_bytes[a + i];
+    }
+}
+
+void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
+                  const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream) {
+    const uint64_t n_bytes = n_rec * read_len;
+    hipLaunchKernelGGL(mk_synth_fill_kernel, dim3(2048), dim3(256), 0, stream, seed, n_bytes, d_seq);
+    hipLaunchKernelGGL(mk_synth_off_plant_kernel, dim3(2048), dim3(256), 0, stream, seed, n_rec, read_len, plant_every,
+                       d_pat_bytes, d_pat_off, n_pat, d_seq, d_seq_off);
+}
+
+}  // namespace mk

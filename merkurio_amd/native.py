@@ -1,0 +1,430 @@
+"""ctypes binding of libmerkurio_hip.so (include/merkurio_hip.h) and a thin Python mirror of the
+reference's matcher surface, so tests read like the reference's own tests:
+
+    BNDMq(pattern, q).find_iter(text) / find_all / find_match   src/pattern_matching.rs:61-153
+    AhoCorasick(patterns, ascii_case_insensitive).find_overlapping_iter(text)
+                                                                 src/cmd_extract.rs:260-265,332
+    parse_pattern_list / read_kmers_from_file / recommend_aho_corasick / tune_q_value /
+    generate_masks                                               src/helpers.rs, pattern_*.rs
+    Matcher(...).extract_single / extract_paired / tag_records   the record loops of cmd_*.rs
+
+Everything that searches text runs in the gfx950 kernels; there is no CPU fallback here: if
+the library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MK_OK = 0
+MK_E_EMPTY_PATTERN = -1
+MK_E_INVALID_Q = -2
+MK_E_PATTERN_TOO_LONG = -3
+MK_E_NO_PATTERNS = -4
+MK_E_NOMEM = -5
+MK_E_PAIR_MISMATCH = -6
+MK_E_HIP = -7
+MK_E_CAPACITY = -8
+MK_E_INVALID_ARG = -9
+MK_E_UNSUPPORTED = -10
+
+MK_ALGO_AUTO, MK_ALGO_AC, MK_ALGO_BNDMQ = 0, 1, 2
+MK_FLAG_ASCII_CASE_INSENSITIVE = 1
+MK_MODE_ANY, MK_MODE_HITS = 0, 1
+MK_NUM_SUMMARY = 8
+MK_SUM_HITS, MK_SUM_RECORDS_HIT, MK_SUM_RECORDS, MK_SUM_BASES, MK_SUM_CANDIDATES = 0, 1, 2, 3, 4
+
+HIT_DTYPE = np.dtype([("rec", "<u8"), ("pat", "<u4"), ("pos", "<u4")])
+ROW_DTYPE = np.dtype([("rec", "<u8"), ("pat", "<u4"), ("pos", "<u4"), ("file", "<u4"), ("_pad", "<u4")])
+
+EXPORTS = [
+    "mk_abi_version", "mk_last_error", "mk_device_count", "mk_read_kmers_from_text", "mk_parse_pattern_list",
+    "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
+    "mk_free", "mk_matcher_create", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
+    "mk_matcher_filter_info", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
+    "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
+    "mk_synth_reads_host",
+]
+
+
+class MerkurioError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class PatternError(MerkurioError):
+    """src/pattern_matching.rs:28-36"""
+    KINDS = {MK_E_EMPTY_PATTERN: "EmptyPattern", MK_E_INVALID_Q: "InvalidQGramLength",
+             MK_E_PATTERN_TOO_LONG: "PatternTooLong"}
+
+    @property
+    def kind(self):
+        return self.KINDS.get(self.code, "?")
+
+
+class Counters(C.Structure):
+    _fields_ = [("nb_records_tot", C.c_uint64), ("nb_bases", C.c_uint64), ("nb_hits_tot", C.c_uint64 * 2),
+                ("nb_records_hit", C.c_uint64 * 2), ("nb_records_extracted", C.c_uint64)]
+
+    def as_dict(self, counts):
+        return {"records": self.nb_records_tot, "bases": self.nb_bases,
+                "hits": (self.nb_hits_tot[0], self.nb_hits_tot[1]),
+                "records_hit": (self.nb_records_hit[0], self.nb_records_hit[1]),
+                "extracted": self.nb_records_extracted, "pattern_hit_counts": counts.tolist()}
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load(build_if_missing=True):
+    """Loads the shared library (building it in-tree with hipcc first if needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        _build.build_lib()
+    if not os.path.exists(_build.LIB_PATH):
+        raise MerkurioError(MK_E_HIP, f"{_build.LIB_PATH} is missing: run `python -m merkurio_amd.build`")
+    L = C.CDLL(_build.LIB_PATH)
+    L.mk_last_error.restype = C.c_char_p
+    L.mk_matcher_kernel_name.restype = C.c_char_p
+    L.mk_matcher_kernel_name.argtypes = [C.c_void_p]
+    L.mk_tune_q_value.restype = C.c_size_t
+    L.mk_tune_q_value.argtypes = [C.c_size_t]
+    L.mk_recommend_aho_corasick.argtypes = [C.c_size_t, C.c_size_t]
+    L.mk_free.argtypes = [C.c_void_p]
+    L.mk_matcher_destroy.argtypes = [C.c_void_p]
+    L.mk_matcher_algo.argtypes = [C.c_void_p]
+    L.mk_matcher_algo.restype = C.c_uint32
+    L.mk_matcher_num_patterns.argtypes = [C.c_void_p]
+    L.mk_matcher_num_patterns.restype = C.c_uint32
+    L.mk_matcher_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
+                                    C.POINTER(C.c_void_p)]
+    L.mk_scan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                C.c_uint64, C.POINTER(C.c_uint64)]
+    L.mk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mk_order_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mk_extract_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p]
+    L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                    C.POINTER(Counters), C.c_void_p]
+    L.mk_tag_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mk_tag_value.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t,
+                               C.POINTER(C.c_size_t)]
+    L.mk_synth_reads_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    L.mk_synth_reads_host.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                      C.c_void_p, C.c_void_p]
+    L.mk_read_kmers_from_text.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint32)]
+    L.mk_parse_pattern_list.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+    L.mk_reverse_complement.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.mk_canonical.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.mk_generate_masks.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc == MK_OK:
+        return
+    msg = load().mk_last_error().decode(errors="replace")
+    if rc in PatternError.KINDS:
+        raise PatternError(rc, msg)
+    raise MerkurioError(rc, msg)
+
+
+def device_count():
+    return load().mk_device_count()
+
+
+# ------------------------------------------------------------------ packing helpers
+def pack_list(items):
+    items = [bytes(x) for x in items]
+    off = np.zeros(len(items) + 1, dtype=np.uint32)
+    if items:
+        off[1:] = np.cumsum([len(x) for x in items])
+    data = np.frombuffer(b"".join(items) + b"\0", dtype=np.uint8).copy()
+    return data, off
+
+
+def pack_records(seqs):
+    seqs = [bytes(x) for x in seqs]
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if seqs:
+        off[1:] = np.cumsum([len(x) for x in seqs], dtype=np.uint64)
+    data = np.frombuffer(b"".join(seqs) + b"\0", dtype=np.uint8).copy()
+    return data, off
+
+
+def _take_list(pb, po, n):
+    L = load()
+    off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(n.value + 1,)).copy()
+    total = int(off[-1])
+    data = C.string_at(pb, total) if total else b""
+    L.mk_free(pb)
+    L.mk_free(po)
+    return [data[off[i]:off[i + 1]] for i in range(n.value)]
+
+
+# ------------------------------------------------------------------ pattern preparation
+def read_kmers_from_text(content: bytes):
+    """helpers::read_kmers_from_file body (src/helpers.rs:152-156)"""
+    pb, po, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+    buf = np.frombuffer(bytes(content) + b"\0", dtype=np.uint8)
+    _check(load().mk_read_kmers_from_text(buf.ctypes.data, len(content), C.byref(pb), C.byref(po), C.byref(n)))
+    return _take_list(pb, po, n)
+
+
+def read_kmers_from_file(path):
+    with open(path, "rb") as f:
+        return read_kmers_from_text(f.read())
+
+
+def parse_pattern_list(kmer_file=None, kmer_seq=None, reverse_complement=False, canonical=False, lowercase=False,
+                       uppercase=False):
+    """helpers::parse_pattern_list (src/helpers.rs:76-133); the file has priority over kmer_seq"""
+    if kmer_file is not None:
+        raw = read_kmers_from_file(kmer_file)
+    elif kmer_seq is not None:
+        raw = [s.encode() if isinstance(s, str) else bytes(s) for s in kmer_seq]
+    else:
+        raise MerkurioError(MK_E_NO_PATTERNS, "No k-mer sequence provided.")
+    data, off = pack_list(raw)
+    pb, po, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+    _check(load().mk_parse_pattern_list(data.ctypes.data, off.ctypes.data, len(raw), int(reverse_complement),
+                                        int(canonical), int(lowercase), int(uppercase), C.byref(pb), C.byref(po),
+                                        C.byref(n)))
+    return _take_list(pb, po, n)
+
+
+def reverse_complement(s: bytes) -> bytes:
+    src = np.frombuffer(bytes(s) + b"\0", dtype=np.uint8)
+    out = np.zeros(len(s) + 1, dtype=np.uint8)
+    load().mk_reverse_complement(src.ctypes.data, len(s), out.ctypes.data)
+    return out[:len(s)].tobytes()
+
+
+def canonical(s: bytes) -> bytes:
+    src = np.frombuffer(bytes(s) + b"\0", dtype=np.uint8)
+    out = np.zeros(len(s) + 1, dtype=np.uint8)
+    load().mk_canonical(src.ctypes.data, len(s), out.ctypes.data)
+    return out[:len(s)].tobytes()
+
+
+def recommend_aho_corasick(pattern_list) -> bool:
+    return bool(load().mk_recommend_aho_corasick(len(pattern_list), max(len(p) for p in pattern_list)))
+
+
+def tune_q_value(pattern) -> int:
+    q = load().mk_tune_q_value(len(pattern))
+    if q == 0:
+        raise MerkurioError(MK_E_PATTERN_TOO_LONG, "Pattern length is too long for BNDMq.")
+    return q
+
+
+def generate_masks(pattern: bytes):
+    src = np.frombuffer(bytes(pattern) + b"\0", dtype=np.uint8)
+    masks = np.zeros(256, dtype=np.uint64)
+    accept = C.c_uint64()
+    _check(load().mk_generate_masks(src.ctypes.data, len(pattern), masks.ctypes.data, C.byref(accept)))
+    return masks.tolist(), accept.value
+
+
+# ------------------------------------------------------------------ matcher handle
+class Matcher:
+    """The matcher bundle the reference drivers hold (src/cmd_extract.rs:259): construction
+    applies the reference's algorithm-selection rule; scans run on the GPU."""
+
+    def __init__(self, patterns, algo=MK_ALGO_AUTO, q=0, case_insensitive=False, device=0):
+        self.patterns = [p.encode() if isinstance(p, str) else bytes(p) for p in patterns]
+        data, off = pack_list(self.patterns)
+        self._h = C.c_void_p()
+        flags = MK_FLAG_ASCII_CASE_INSENSITIVE if case_insensitive else 0
+        _check(load().mk_matcher_create(data.ctypes.data, off.ctypes.data, len(self.patterns), algo, q, flags, device,
+                                        C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().mk_matcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def algo(self):
+        return load().mk_matcher_algo(self._h)
+
+    @property
+    def use_ac(self):
+        return self.algo == MK_ALGO_AC
+
+    @property
+    def kernel_name(self):
+        return load().mk_matcher_kernel_name(self._h).decode()
+
+    def filter_info(self):
+        q, s, e, tb = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(load().mk_matcher_filter_info(self._h, C.byref(q), C.byref(s), C.byref(e), C.byref(tb)))
+        return {"q_gram": q.value, "stride": s.value, "entries": e.value, "table_bytes": tb.value}
+
+    # ---- batched scan, host buffers
+    def scan(self, seqs, mode=MK_MODE_HITS, hits_cap=None):
+        """-> (flags: np.bool_[n], hits: structured array in reference emission order)"""
+        data, off = pack_records(seqs)
+        return self.scan_packed(data, off, mode, hits_cap)
+
+    def scan_packed(self, data, off, mode=MK_MODE_HITS, hits_cap=None):
+        n = len(off) - 1
+        flags = np.zeros(max(1, n), dtype=np.uint8)
+        nh = C.c_uint64()
+        cap = 1024 if hits_cap is None else hits_cap
+        while True:
+            hits = np.zeros(max(1, cap), dtype=HIT_DTYPE)
+            rc = load().mk_scan_batch(self._h, data.ctypes.data, off.ctypes.data, n, mode, flags.ctypes.data,
+                                      hits.ctypes.data, cap, C.byref(nh))
+            if rc == MK_E_CAPACITY and hits_cap is None:
+                cap = nh.value
+                continue
+            _check(rc)
+            return flags[:n].astype(bool), hits[:nh.value]
+
+    # ---- driver loops
+    def _rows(self, call):
+        cap = 4096
+        while True:
+            rows = np.zeros(cap, dtype=ROW_DTYPE)
+            n_rows = C.c_uint64()
+            rc = call(rows, cap, n_rows)
+            if rc == MK_E_CAPACITY and n_rows.value > cap:
+                cap = n_rows.value
+                continue
+            _check(rc)
+            r = rows[:n_rows.value]
+            return [(int(f), int(rec), int(p), int(pos)) for f, rec, p, pos in zip(r["file"], r["rec"], r["pat"], r["pos"])]
+
+    def extract_single(self, seqs, logging=True, invert=False):
+        data, off = pack_records(seqs)
+        n = len(seqs)
+        keep = np.zeros(max(1, n), dtype=np.uint8)
+        res = {}
+
+        def call(rows, cap, n_rows):
+            res["c"], res["counts"] = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+            return load().mk_extract_single(self._h, data.ctypes.data, off.ctypes.data, n, int(logging), int(invert),
+                                            keep.ctypes.data, rows.ctypes.data, cap, C.byref(n_rows),
+                                            C.byref(res["c"]), res["counts"].ctypes.data)
+        rows = self._rows(call)
+        return keep[:n].astype(bool).tolist(), rows, res["c"].as_dict(res["counts"])
+
+    def extract_paired(self, seqs1, seqs2, logging=True, invert=False):
+        d1, o1 = pack_records(seqs1)
+        d2, o2 = pack_records(seqs2)
+        n = len(seqs1)
+        keep = np.zeros(max(1, n), dtype=np.uint8)
+        res = {}
+
+        def call(rows, cap, n_rows):
+            res["c"], res["counts"] = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+            return load().mk_extract_paired(self._h, d1.ctypes.data, o1.ctypes.data, len(seqs1), d2.ctypes.data,
+                                            o2.ctypes.data, len(seqs2), int(logging), int(invert), keep.ctypes.data,
+                                            rows.ctypes.data, cap, C.byref(n_rows), C.byref(res["c"]),
+                                            res["counts"].ctypes.data)
+        rows = self._rows(call)
+        return keep[:n].astype(bool).tolist(), rows, res["c"].as_dict(res["counts"])
+
+    def tag_records(self, seqs, logging=True, filter_matching=False, invert=False):
+        data, off = pack_records(seqs)
+        n = len(seqs)
+        keep = np.zeros(max(1, n), dtype=np.uint8)
+        foff = np.zeros(n + 1, dtype=np.uint64)
+        res = {"fcap": 4096}
+
+        def call(rows, cap, n_rows):
+            while True:
+                res["c"], res["counts"] = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+                res["fpat"] = np.zeros(res["fcap"], dtype=np.uint32)
+                rc = load().mk_tag_records(self._h, data.ctypes.data, off.ctypes.data, n, int(logging),
+                                           int(filter_matching), int(invert), keep.ctypes.data, rows.ctypes.data, cap,
+                                           C.byref(n_rows), C.byref(res["c"]), res["counts"].ctypes.data,
+                                           foff.ctypes.data, res["fpat"].ctypes.data, res["fcap"])
+                if rc == MK_E_CAPACITY and int(foff[n]) > res["fcap"]:
+                    res["fcap"] = int(foff[n])
+                    continue
+                return rc
+        rows = self._rows(call)
+        found = [res["fpat"][int(foff[i]):int(foff[i + 1])].tolist() for i in range(n)]
+        return keep[:n].astype(bool).tolist(), rows, res["c"].as_dict(res["counts"]), found
+
+    def tag_value(self, found, existing=None) -> bytes:
+        arr = np.asarray(list(found) + [0], dtype=np.uint32)
+        cap = 256
+        while True:
+            out = C.create_string_buffer(cap)
+            n = C.c_size_t()
+            rc = load().mk_tag_value(self._h, arr.ctypes.data, len(found), existing, out, cap, C.byref(n))
+            if rc == MK_E_CAPACITY:
+                cap = n.value + 1
+                continue
+            _check(rc)
+            return out.value
+
+
+# ------------------------------------------------------------------ reference-shaped single matchers
+class BNDMq:
+    """pattern_matching::BNDMq (src/pattern_matching.rs:42-153): one pattern, q-gram length q.
+    q is validated like the reference and has no effect on results."""
+
+    def __init__(self, pattern: bytes, q: int, device=0):
+        if len(pattern) == 0:
+            raise PatternError(MK_E_EMPTY_PATTERN, "Pattern is empty.")
+        if q == 0:
+            raise PatternError(MK_E_INVALID_Q, "Invalid q-gram length: 0. Must be between 1 and pattern length.")
+        self._m = Matcher([pattern], MK_ALGO_BNDMQ, q, False, device)
+
+    def find_all(self, text: bytes):
+        _, hits = self._m.scan([text], MK_MODE_HITS)
+        return hits["pos"].tolist()
+
+    def find_iter(self, text: bytes):
+        return iter(self.find_all(text))
+
+    def find_match(self, text: bytes) -> bool:
+        flags, _ = self._m.scan([text], MK_MODE_ANY)
+        return bool(flags[0])
+
+
+class AhoCorasick:
+    """AhoCorasick::builder().kind(DFA).ascii_case_insensitive(ci).build(patterns) with the
+    overlapping iterator (src/cmd_extract.rs:260-265,332)."""
+
+    def __init__(self, patterns, ascii_case_insensitive=False, device=0):
+        self._m = Matcher(patterns, MK_ALGO_AC, 0, ascii_case_insensitive, device)
+
+    def find_overlapping_iter(self, text: bytes):
+        """yields (pattern_index, start) in the crate's emission order"""
+        _, hits = self._m.scan([text], MK_MODE_HITS)
+        return iter(list(zip(hits["pat"].tolist(), hits["pos"].tolist())))
+
+    def is_match(self, text: bytes) -> bool:
+        flags, _ = self._m.scan([text], MK_MODE_ANY)
+        return bool(flags[0])

@@ -1,0 +1,97 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/merkurio_hip.h
+declares, its host logic (pattern-list preparation, pure helper functions) agrees with the
+oracle and the reference KATs, and it fails loudly without a GPU (no CPU fallback)."""
+import os
+import random
+import re
+
+import pytest
+
+import oracle_binding as ob
+from merkurio_amd import native as mk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "merkurio_hip.h")).read()
+    declared = set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mk_matcher", "mk_hit", "mk_row", "mk_counters"}
+    assert declared == set(mk.EXPORTS), declared ^ set(mk.EXPORTS)
+    L = mk.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.mk_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    if mk.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(mk.MerkurioError) as e:
+        mk.Matcher([b"ACG"])
+    assert e.value.code == mk.MK_E_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_matcher_validation_precedes_device_use():
+    # PatternError mapping does not need a GPU (src/pattern_matching.rs:61-78)
+    with pytest.raises(mk.PatternError) as e:
+        mk.Matcher([b"abc"], algo=mk.MK_ALGO_BNDMQ, q=4)
+    assert e.value.kind == "InvalidQGramLength"
+    with pytest.raises(mk.PatternError) as e:
+        mk.Matcher([b"a" * 70], algo=mk.MK_ALGO_BNDMQ, q=3)
+    assert e.value.kind == "PatternTooLong"
+    with pytest.raises(mk.PatternError) as e:
+        mk.Matcher([b"a" * 70], algo=mk.MK_ALGO_BNDMQ)  # tune_q_value bails
+    assert e.value.kind == "PatternTooLong"
+    with pytest.raises(mk.MerkurioError) as e:
+        mk.Matcher([])
+    assert e.value.code == mk.MK_E_NO_PATTERNS
+
+
+def test_pure_helpers_match_reference_kats():
+    masks, accept = mk.generate_masks(b"abc")  # src/pattern_preprocessing.rs:54-68
+    assert accept == 4 and (masks[97], masks[98], masks[99]) == (4, 2, 1)
+    masks, accept = mk.generate_masks(b"3$$X3")
+    assert (masks[51], masks[36], masks[88], accept) == (17, 12, 2, 16)
+    with pytest.raises(mk.PatternError):
+        mk.generate_masks(b"x" * 65)
+    assert mk.tune_q_value("AAAAAAAACCCCCCCCGGGGGGGGTTTTTTT") == 5  # src/pattern_matching.rs:485-488
+    assert [mk.tune_q_value("x" * n) for n in (1, 2, 3, 4, 8, 9, 30, 31, 55, 56, 64)] == [1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6]
+    with pytest.raises(mk.MerkurioError):
+        mk.tune_q_value("x" * 65)
+    assert mk.recommend_aho_corasick([b"AAA", b"CCC"]) is False  # src/helpers.rs:555-567
+    assert mk.recommend_aho_corasick([b"A" * 65]) is True
+    assert mk.recommend_aho_corasick([b"A"] * 14) is True
+
+
+def test_pattern_list_matches_oracle_and_kats(golden):
+    d = os.path.join(golden, "data")
+    three = [b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", b"AAAATTGCATGAATATTGTAGATCAAAGCACA", b"CTCCGAAGAAGTTGCTGTTCTTGATGGTTATT"]
+    assert mk.parse_pattern_list(kmer_file=os.path.join(d, "kmers.txt")) == three  # helpers.rs:334-348
+    assert sorted(mk.read_kmers_from_file(os.path.join(d, "kmers.fasta"))) == three
+    assert len(mk.parse_pattern_list(kmer_file=os.path.join(d, "kmers-duplicates.txt"), reverse_complement=True)) == 4
+    assert len(mk.parse_pattern_list(kmer_file=os.path.join(d, "kmers.txt"), reverse_complement=True)) == 6
+    assert b"AATAACCATCAAGAACAGCAACTTCTTCGGAG" in mk.parse_pattern_list(kmer_file=os.path.join(d, "kmers.txt"), canonical=True)
+    assert mk.parse_pattern_list(kmer_file=os.path.join(d, "kmers-messy.txt")) == \
+        [b"AAAAAAAAAAAAAAAAAAAAAAAAAAAA", b"CTCCGAAGAAGTTGCTGTTCTTGATGGTTATT", b"TTGCATGAATATTGTA"]
+    for bad in (lambda: mk.parse_pattern_list(kmer_seq=[""]), lambda: mk.read_kmers_from_file(os.path.join(d, "kmers-empty.txt"))):
+        with pytest.raises(mk.MerkurioError) as e:
+            bad()
+        assert e.value.code == mk.MK_E_NO_PATTERNS
+    # randomized agreement with the oracle, all flag combinations
+    rnd = random.Random(7)
+    alpha = b"ACGTacgtNRYKMBVDHSWn-*U"
+    for _ in range(300):
+        raw = [bytes(rnd.choice(alpha) for _ in range(rnd.randrange(0, 12))) for _ in range(rnd.randrange(1, 12))]
+        kw = dict(reverse_complement=rnd.random() < .5, canonical=rnd.random() < .3, lowercase=rnd.random() < .3,
+                  uppercase=rnd.random() < .3)
+        rc, exp = ob.parse_pattern_list(raw, **kw)
+        if rc:
+            with pytest.raises(mk.MerkurioError):
+                mk.parse_pattern_list(kmer_seq=raw, **kw)
+        else:
+            assert mk.parse_pattern_list(kmer_seq=raw, **kw) == exp
+        s = raw[0]
+        assert mk.reverse_complement(s) == ob.reverse_complement(s) and mk.canonical(s) == ob.canonical(s)
+    txt = b"AC\n   \n#x\n>y\n  #notcomment\nGT\r\n\nTT"
+    assert mk.read_kmers_from_text(txt) == ob.read_kmers_from_text(txt)[1]
