@@ -12,6 +12,7 @@ Everything that searches text runs in the gfx950 kernels; there is no CPU fallba
 the library or a GPU is missing, construction raises.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -83,11 +84,33 @@ def lib_path():
     return _build.LIB_PATH
 
 
+def _bind_to_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same soname,
+    libamdhip64.so.7, as /opt/rocm's); two runtimes in one process each try to own the GPU and the
+    second one finds none.  If PyTorch is installed, load ITS runtime first so that
+    libmerkurio_hip.so's DT_NEEDED binds to it and a later `import torch` shares it.  A host
+    without PyTorch (the C++ CLI, a Rust host) uses the system runtime.
+    Set MERKURIO_SYSTEM_HIP=1 to skip."""
+    if os.environ.get("MERKURIO_SYSTEM_HIP") == "1":
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load(build_if_missing=True):
     """Loads the shared library (building it in-tree with hipcc first if needed)."""
     global _lib
     if _lib is not None:
         return _lib
+    _bind_to_torch_hip_runtime()
     if build_if_missing:
         _build.build_lib()
     if not os.path.exists(_build.LIB_PATH):

@@ -54,7 +54,8 @@ def test_bndmq_kats_gpu(mk):
 def test_algorithm_selection_gpu(mk):
     assert mk.Matcher([b"AAA", b"CCC"]).use_ac is False  # helpers.rs:555-558
     assert mk.Matcher([b"A" * 65]).use_ac is True  # :561-567
-    pats = sorted({bytes(random.Random(i).choice(b"ACGT") for _ in range(9)) for i in range(14)})
+    rnd = random.Random(1)
+    pats = sorted({bytes(rnd.choice(b"ACGT") for _ in range(9)) for _ in range(14)})
     assert len(pats) == 14 and mk.Matcher(pats).use_ac is True
     assert mk.Matcher(pats, q=3).use_ac is False  # -q given => BNDMq (cmd_extract.rs:169)
     assert mk.Matcher([b"ACG"], case_insensitive=True).use_ac is True  # :166-167
