@@ -192,6 +192,13 @@ int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);
 /* name of the scan kernel variant the last mk_scan_device on this handle launched, and its
  * launch geometry (for profiling / roofline bookkeeping) */
 const char *mk_matcher_kernel_name(const mk_matcher *m);
+int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t *block_threads, uint32_t *lds_bytes);
+/* Per-launch kernel timing with hipEvents recorded on the launch stream immediately before
+ * and after the scan kernel (not around the buffer clears).  enable_timing(slots) keeps the
+ * last `slots` launches; kernel_times() waits for them, returns their durations in ms
+ * (oldest first) and resets the window.  slots == 0 disables. */
+int mk_matcher_enable_timing(mk_matcher *m, uint32_t slots);
+int mk_matcher_kernel_times(mk_matcher *m, float *ms, uint32_t cap, uint32_t *n_out);
 
 /* ------------------------------------------------------------------------------------
  * Driver-loop semantics on batches (host buffers)

@@ -209,6 +209,8 @@ void mk_matcher_destroy(mk_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (auto e : m->ev_start) (void)hipEventDestroy(e);
+    for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits})
         if (p) (void)hipFree(p);
@@ -270,10 +272,59 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t waves_per_block = kBlockThreads / 64;
     uint64_t blocks = (p.n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
+    const size_t slots = m->ev_start.size();
+    const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
+    if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
     const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, (int)blocks, st);
     if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);
+    if (slots) {
+        MK_HIP(hipEventRecord(m->ev_stop[slot], st));
+        m->timed_launches++;
+    }
     m->kernel_name = name;
+    m->last_grid = (int)blocks;
     MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int mk_matcher_enable_timing(mk_matcher *m, uint32_t slots) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    MK_HIP(hipSetDevice(m->device));
+    for (auto e : m->ev_start) (void)hipEventDestroy(e);
+    for (auto e : m->ev_stop) (void)hipEventDestroy(e);
+    m->ev_start.assign(slots, nullptr);
+    m->ev_stop.assign(slots, nullptr);
+    m->timed_launches = 0;
+    for (uint32_t i = 0; i < slots; ++i) {
+        MK_HIP(hipEventCreate(&m->ev_start[i]));
+        MK_HIP(hipEventCreate(&m->ev_stop[i]));
+    }
+    return MK_OK;
+}
+
+int mk_matcher_kernel_times(mk_matcher *m, float *ms, uint32_t cap, uint32_t *n_out) {
+    if (!m || !n_out) return fail(MK_E_INVALID_ARG, "null argument");
+    const uint64_t slots = m->ev_start.size();
+    const uint64_t n = std::min<uint64_t>(m->timed_launches, slots);
+    *n_out = (uint32_t)n;
+    if (n > cap) return fail(MK_E_CAPACITY, "need room for %llu timings", (unsigned long long)n);
+    MK_HIP(hipSetDevice(m->device));
+    // oldest retained launch first
+    const uint64_t first = m->timed_launches - n;
+    for (uint64_t i = 0; i < n; ++i) {
+        const size_t slot = (size_t)((first + i) % slots);
+        MK_HIP(hipEventSynchronize(m->ev_stop[slot]));
+        MK_HIP(hipEventElapsedTime(&ms[i], m->ev_start[slot], m->ev_stop[slot]));
+    }
+    m->timed_launches = 0;
+    return MK_OK;
+}
+
+int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t *block_threads, uint32_t *lds_bytes) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (grid_blocks) *grid_blocks = (uint32_t)m->last_grid;
+    if (block_threads) *block_threads = kBlockThreads;
+    if (lds_bytes) *lds_bytes = kBloomBytes;
     return MK_OK;
 }
 

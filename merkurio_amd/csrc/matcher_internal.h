@@ -35,4 +35,9 @@ struct mk_matcher {
     size_t d_hits_cap = 0;
     unsigned long long *d_nhits = nullptr;
     const char *kernel_name = "";
+    int last_grid = 0;
+    // optional per-launch kernel timing (hipEvents recorded on the launch stream, tightly
+    // around the scan kernel): bench.py's roofline figure
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    uint64_t timed_launches = 0;
 };

@@ -45,6 +45,7 @@ EXPORTS = [
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
     "mk_free", "mk_matcher_create", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
+    "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
     "mk_synth_reads_host",
 ]
@@ -135,6 +136,9 @@ def load(build_if_missing=True):
     L.mk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mk_order_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mk_matcher_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.mk_matcher_enable_timing.argtypes = [C.c_void_p, C.c_uint32]
+    L.mk_matcher_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mk_extract_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
@@ -304,6 +308,23 @@ class Matcher:
     @property
     def kernel_name(self):
         return load().mk_matcher_kernel_name(self._h).decode()
+
+    def launch_info(self):
+        g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(load().mk_matcher_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)))
+        return {"grid_blocks": g.value, "block_threads": b.value, "lds_bytes": l.value}
+
+    def enable_timing(self, slots):
+        _check(load().mk_matcher_enable_timing(self._h, slots))
+        self._timing_slots = slots
+
+    def kernel_times_ms(self):
+        """durations of the retained scan-kernel launches (hipEvents on the launch stream)"""
+        cap = max(1, getattr(self, "_timing_slots", 0))
+        ms = np.zeros(cap, dtype=np.float32)
+        n = C.c_uint32()
+        _check(load().mk_matcher_kernel_times(self._h, ms.ctypes.data, cap, C.byref(n)))
+        return ms[:n.value].tolist()
 
     def filter_info(self):
         q, s, e, tb = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()

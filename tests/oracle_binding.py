@@ -282,6 +282,25 @@ def extract_single(m: Matcher, seqs, logging=True, invert=False):
     return keep[:n].astype(bool).tolist(), _rows_list(rows), _counters_dict(c, counts)
 
 
+def extract_single_packed(m: Matcher, data, off, logging=False, invert=False):
+    """same as extract_single on an already packed batch (uint8 bytes, uint64 offsets);
+    returns (keep: np.uint8[n], counters dict) -- used by bench.py's cpu_baseline leg"""
+    assert m.rc == 0
+    n = len(off) - 1
+    keep = np.zeros(max(1, n), dtype=np.uint8)
+    rows, c = _Rows(), _Counters()
+    counts = np.zeros(len(m.patterns), dtype=np.uint32)
+    rc = lib().mko_extract_single(C.byref(m._m), data.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                  off.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(n), int(logging),
+                                  int(invert), keep.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                  C.byref(rows) if logging else None, C.byref(c),
+                                  counts.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc == 0
+    if logging:
+        lib().mko_rows_free(C.byref(rows))
+    return keep[:n], _counters_dict(c, counts)
+
+
 def extract_paired(m: Matcher, seqs1, seqs2, logging=True, invert=False):
     assert m.rc == 0
     d1, o1 = pack_records(seqs1)
