@@ -44,12 +44,16 @@ struct alignas(16) TableEntry {
 
 MK_HD uint32_t code2(uint8_t c) { return (c >> 1) & 3u; }
 
-// hash for the LDS Bloom filter: (word index, bit a, bit b)
+// hash for the LDS Bloom filter: (word index, bit a, bit b) from a 64-bit key (lo, hi).
+// Two 24x24-bit multiply-adds (v_mad_u32_u24, full rate on CDNA4; v_mul_lo_u32 is quarter
+// rate): t = key >> 24;  h = lo[0:24) * C1 + t;  h = t[0:24) * C2 + h.   Every key bit
+// reaches the high (word-index) bits through a multiply or the additive t.
 MK_HD uint32_t bloom_hash(uint32_t lo, uint32_t hi) {
-    uint32_t x = lo ^ (hi * 0x9E3779B1u);
-    return x * 0x85EBCA6Bu;
+    const uint32_t t = (lo >> 24) | (hi << 8);
+    uint32_t h = (lo & 0xFFFFFFu) * 0x9E3779u + t;
+    h = (t & 0xFFFFFFu) * 0x85EBCBu + h;
+    return h;
 }
-MK_HD uint32_t bloom_hash32(uint32_t lo) { return lo * 0x85EBCA6Bu; }
 MK_HD uint32_t bloom_word(uint32_t h) { return h >> (32 - kBloomLog2Words); }
 MK_HD uint32_t bloom_bit_a(uint32_t h) { return (h >> 12) & 31u; }
 MK_HD uint32_t bloom_bit_b(uint32_t h) { return (h >> 7) & 31u; }

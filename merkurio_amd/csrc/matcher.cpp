@@ -324,7 +324,7 @@ int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t 
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     if (grid_blocks) *grid_blocks = (uint32_t)m->last_grid;
     if (block_threads) *block_threads = kBlockThreads;
-    if (lds_bytes) *lds_bytes = kBloomBytes;
+    if (lds_bytes) *lds_bytes = kBloomBytes + (kBlockThreads / 64) * 128 * 16;
     return MK_OK;
 }
 

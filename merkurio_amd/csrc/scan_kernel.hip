@@ -45,10 +45,17 @@ __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ seq, uint64_
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// one filter positive waiting for verification: packed q-gram key + absolute text position
+struct alignas(16) CandEntry {
+    uint64_t key;
+    uint64_t t;
+};
+constexpr uint32_t kRingEntries = 128;  // per wave; < 64 pending before an append of <= 64
+constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry);  // 160 KiB
+
 // ---- slow path -------------------------------------------------------------------------
 template <bool EMIT>
-__device__ __noinline__ void verify_candidate(const ScanParams &P, uint64_t key, uint64_t t) {
-    if (P.counters) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], 1ull);
+__device__ __forceinline__ void verify_candidate(const ScanParams &P, uint64_t key, uint64_t t) {
     uint32_t slot = table_hash(key) & P.table_mask;
     for (;;) {
         const TableEntry e = P.table[slot];
@@ -109,6 +116,15 @@ __device__ __noinline__ void verify_candidate(const ScanParams &P, uint64_t key,
     }
 }
 
+// device form of filter.hpp's bloom_hash (identical value; spelled with the 24-bit multiply
+// intrinsics so that hipcc emits v_alignbit + 2 x v_mad_u32_u24)
+__device__ __forceinline__ uint32_t bloom_hash_dev(uint32_t lo, uint32_t hi) {
+    const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 24);
+    uint32_t h = __umul24(lo, 0x9E3779u) + t;
+    h = __umul24(t, 0x85EBCBu) + h;
+    return h;
+}
+
 // ---- main kernel -----------------------------------------------------------------------
 template <int S, bool WIDE, bool EMIT>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
@@ -125,19 +141,28 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         atomicAdd(&P.counters[P.n_pat + MK_SUM_BASES], (unsigned long long)P.n_bytes);
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlockThreads / 64) + wave_in_block;
     const uint64_t n_waves = (uint64_t)gridDim.x * (kBlockThreads / 64);
     constexpr int NS = 16 / S;
     const uint32_t mask_lo = P.key_mask_lo, mask_hi = P.key_mask_hi;
+    const uint8_t *__restrict__ seq = P.seq;
+    const uint64_t n_bytes = P.n_bytes;
+    CandEntry *ring = reinterpret_cast<CandEntry *>(bloom + kBloomWords) + wave_in_block * kRingEntries;
+    uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
 
     for (uint64_t tile = wave_id; tile < P.n_tiles; tile += n_waves) {
         const uint64_t base = tile * (uint64_t)(kTileChunks * kChunkBytes);
-        uint32_t pk_cur = pack16(load16(P.seq, base + lane * 16, P.n_bytes));
+        // wave-uniform: the tile and the halo chunk behind it lie entirely inside the text
+        const bool full = base + (uint64_t)(kTileChunks + 1) * kChunkBytes <= n_bytes;
+        uint32_t pk_cur = pack16(full ? *reinterpret_cast<const uint4 *>(seq + base + lane * 16)
+                                      : load16(seq, base + lane * 16, n_bytes));
         for (int c = 0; c < kTileChunks; ++c) {
             const uint64_t cpos = base + (uint64_t)c * kChunkBytes;
-            if (cpos >= P.n_bytes) break;  // wave-uniform
+            if (!full && cpos >= n_bytes) break;  // wave-uniform
             // next chunk (possibly the first chunk of the following tile): halo + pipeline
-            const uint32_t pk_nxt = pack16(load16(P.seq, cpos + kChunkBytes + lane * 16, P.n_bytes));
+            const uint32_t pk_nxt = pack16(full ? *reinterpret_cast<const uint4 *>(seq + cpos + kChunkBytes + lane * 16)
+                                                : load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
             const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
             const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
             const uint32_t w0 = pk_cur;
@@ -155,30 +180,59 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 uint32_t h;
                 if (WIDE) {
                     uint32_t hi = (sh ? __builtin_amdgcn_alignbit(w2, w1, sh) : w1) & mask_hi;
-                    h = bloom_hash(lo, hi);
+                    h = bloom_hash_dev(lo, hi);
                 } else {
                     lo &= mask_lo;
-                    h = bloom_hash32(lo);
+                    h = bloom_hash_dev(lo, 0u);
                 }
                 const uint32_t w = bloom[bloom_word(h)];
                 const uint32_t tbit = (w >> bloom_bit_a(h)) & (w >> bloom_bit_b(h)) & 1u;
                 cand |= tbit << j;
             }
 
-            // slow path: divergent, rare
-            while (cand) {
-                const int j = __ffs(cand) - 1;
-                cand &= cand - 1;
-                const uint32_t sh = 2u * (uint32_t)j * S;
-                const uint64_t lo64 = (((uint64_t)w1 << 32) | w0) >> sh;
-                const uint64_t hi64 = (((uint64_t)w2 << 32) | w1) >> sh;
-                const uint64_t key = ((uint64_t)((uint32_t)lo64 & mask_lo)) | ((uint64_t)((uint32_t)hi64 & mask_hi) << 32);
-                const uint64_t t = cpos + lane * 16 + (uint64_t)j * S;
-                if (t < P.n_bytes) verify_candidate<EMIT>(P, key, t);
+            // filter positives -> per-wave LDS ring (ballot/popcount compaction); verified 64
+            // at a time so that the L2 round trip is paid once per 64 candidates, not per chunk
+            uint64_t any = __ballot(cand != 0);
+            while (any) {  // wave-uniform
+                const bool has = cand != 0;
+                if (has) {
+                    const int j = __ffs(cand) - 1;
+                    cand &= cand - 1;
+                    const uint32_t sh = 2u * (uint32_t)j * S;
+                    const uint64_t lo64 = (((uint64_t)w1 << 32) | w0) >> sh;
+                    const uint64_t hi64 = (((uint64_t)w2 << 32) | w1) >> sh;
+                    CandEntry e;
+                    e.key = ((uint64_t)((uint32_t)lo64 & mask_lo)) | ((uint64_t)((uint32_t)hi64 & mask_hi) << 32);
+                    e.t = cpos + lane * 16 + (uint64_t)j * S;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                    ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
+                }
+                q_count += (uint32_t)__popcll(any);
+                n_cand += (uint32_t)__popcll(any);
+                if (q_count >= 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
+                    verify_candidate<EMIT>(P, e.key, e.t);
+                    __builtin_amdgcn_wave_barrier();
+                    q_head = (q_head + 64) & (kRingEntries - 1);
+                    q_count -= 64;
+                }
+                any = __ballot(cand != 0);
             }
             pk_cur = pk_nxt;
         }
     }
+    // drain what is left in this wave's ring
+    if (q_count) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < q_count) {
+            const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
+            verify_candidate<EMIT>(P, e.key, e.t);
+        }
+    }
+    if (P.counters && lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
 }
 
 template <int S>
@@ -189,10 +243,10 @@ static const char *launch_s(const ScanParams &p, bool wide, bool emit, int grid,
         static bool attr_done = false;                                                                         \
         if (!attr_done) {                                                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mk_scan_kernel<S, W, E>),                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBloomBytes);           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);           \
             attr_done = true;                                                                                  \
         }                                                                                                      \
-        hipLaunchKernelGGL((mk_scan_kernel<S, W, E>), g, b, kBloomBytes, st, p);                               \
+        hipLaunchKernelGGL((mk_scan_kernel<S, W, E>), g, b, kLdsBytes, st, p);                               \
     } while (0)
     if (wide) {
         if (emit)
