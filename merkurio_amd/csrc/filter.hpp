@@ -32,7 +32,7 @@ constexpr uint32_t kBloomWords = 1u << kBloomLog2Words;    // 128 KiB of LDS
 constexpr uint32_t kBloomBytes = kBloomWords * 4;
 constexpr uint32_t kEmptyPat = 0xFFFFFFFFu;
 constexpr int kChunkBytes = 1024;                          // one wave-iteration: 64 lanes x 16 B
-constexpr int kTileChunks = 16;                            // contiguous chunks per wave tile
+constexpr int kTileChunks = 31;                            // scanned chunks per wave tile (+1 halo chunk = 32 loads)
 constexpr int kBlockThreads = 1024;                        // 16 waves, one workgroup per CU
 
 // one exact-table slot (16 B, one global_load_dwordx4)

@@ -145,84 +145,134 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlockThreads / 64) + wave_in_block;
     const uint64_t n_waves = (uint64_t)gridDim.x * (kBlockThreads / 64);
     constexpr int NS = 16 / S;
+    constexpr uint64_t kTileBytes = (uint64_t)kTileChunks * kChunkBytes;
     const uint32_t mask_lo = P.key_mask_lo, mask_hi = P.key_mask_hi;
     const uint8_t *__restrict__ seq = P.seq;
     const uint64_t n_bytes = P.n_bytes;
     CandEntry *ring = reinterpret_cast<CandEntry *>(bloom + kBloomWords) + wave_in_block * kRingEntries;
     uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
 
-    for (uint64_t tile = wave_id; tile < P.n_tiles; tile += n_waves) {
-        const uint64_t base = tile * (uint64_t)(kTileChunks * kChunkBytes);
-        // wave-uniform: the tile and the halo chunk behind it lie entirely inside the text
-        const bool full = base + (uint64_t)(kTileChunks + 1) * kChunkBytes <= n_bytes;
-        uint32_t pk_cur = pack16(full ? *reinterpret_cast<const uint4 *>(seq + base + lane * 16)
-                                      : load16(seq, base + lane * 16, n_bytes));
-        for (int c = 0; c < kTileChunks; ++c) {
-            const uint64_t cpos = base + (uint64_t)c * kChunkBytes;
-            if (!full && cpos >= n_bytes) break;  // wave-uniform
-            // next chunk (possibly the first chunk of the following tile): halo + pipeline
-            const uint32_t pk_nxt = pack16(full ? *reinterpret_cast<const uint4 *>(seq + cpos + kChunkBytes + lane * 16)
-                                                : load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
-            const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
-            const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
-            const uint32_t w0 = pk_cur;
-            uint32_t w1 = __shfl_down(pk_cur, 1);
-            uint32_t w2 = __shfl_down(pk_cur, 2);
-            if (lane == 63) w1 = n0;
-            if (lane == 62) w2 = n0;
-            if (lane == 63) w2 = n1;
+    // ---- scan of one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
+    // packed chunk that follows in the text (halo source for lanes 62/63)
+    auto scan_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint64_t cpos) {
+        const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
+        const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
+        const uint32_t w0 = pk_cur;
+        uint32_t w1 = __shfl_down(pk_cur, 1);
+        uint32_t w2 = __shfl_down(pk_cur, 2);
+        if (lane == 63) w1 = n0;
+        if (lane == 62) w2 = n0;
+        if (lane == 63) w2 = n1;
 
-            uint32_t cand = 0;
+        uint32_t cand = 0;
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int sh = 2 * j * S;  // constant after unrolling
-                uint32_t lo = sh ? __builtin_amdgcn_alignbit(w1, w0, sh) : w0;
-                uint32_t h;
-                if (WIDE) {
-                    uint32_t hi = (sh ? __builtin_amdgcn_alignbit(w2, w1, sh) : w1) & mask_hi;
-                    h = bloom_hash_dev(lo, hi);
-                } else {
-                    lo &= mask_lo;
-                    h = bloom_hash_dev(lo, 0u);
-                }
-                const uint32_t w = bloom[bloom_word(h)];
-                const uint32_t tbit = (w >> bloom_bit_a(h)) & (w >> bloom_bit_b(h)) & 1u;
-                cand |= tbit << j;
+        for (int j = 0; j < NS; ++j) {
+            const int sh = 2 * j * S;  // constant after unrolling
+            uint32_t lo = sh ? __builtin_amdgcn_alignbit(w1, w0, sh) : w0;
+            uint32_t h;
+            if (WIDE) {
+                uint32_t hi = (sh ? __builtin_amdgcn_alignbit(w2, w1, sh) : w1) & mask_hi;
+                h = bloom_hash_dev(lo, hi);
+            } else {
+                lo &= mask_lo;
+                h = bloom_hash_dev(lo, 0u);
             }
+            const uint32_t w = bloom[bloom_word(h)];
+            const uint32_t tbit = (w >> bloom_bit_a(h)) & (w >> bloom_bit_b(h)) & 1u;
+            cand |= tbit << j;
+        }
 
-            // filter positives -> per-wave LDS ring (ballot/popcount compaction); verified 64
-            // at a time so that the L2 round trip is paid once per 64 candidates, not per chunk
-            uint64_t any = __ballot(cand != 0);
-            while (any) {  // wave-uniform
-                const bool has = cand != 0;
-                if (has) {
-                    const int j = __ffs(cand) - 1;
-                    cand &= cand - 1;
-                    const uint32_t sh = 2u * (uint32_t)j * S;
-                    const uint64_t lo64 = (((uint64_t)w1 << 32) | w0) >> sh;
-                    const uint64_t hi64 = (((uint64_t)w2 << 32) | w1) >> sh;
-                    CandEntry e;
-                    e.key = ((uint64_t)((uint32_t)lo64 & mask_lo)) | ((uint64_t)((uint32_t)hi64 & mask_hi) << 32);
-                    e.t = cpos + lane * 16 + (uint64_t)j * S;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                    ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
-                }
-                q_count += (uint32_t)__popcll(any);
-                n_cand += (uint32_t)__popcll(any);
-                if (q_count >= 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-                    verify_candidate<EMIT>(P, e.key, e.t);
-                    __builtin_amdgcn_wave_barrier();
-                    q_head = (q_head + 64) & (kRingEntries - 1);
-                    q_count -= 64;
-                }
-                any = __ballot(cand != 0);
+        // filter positives -> per-wave LDS ring (ballot/popcount compaction); verified 64
+        // at a time so that the L2 round trip is paid once per 64 candidates, not per chunk
+        uint64_t any = __ballot(cand != 0);
+        while (any) {  // wave-uniform
+            if (cand != 0) {
+                const int j = __ffs(cand) - 1;
+                cand &= cand - 1;
+                const uint32_t sh = 2u * (uint32_t)j * S;
+                const uint64_t lo64 = (((uint64_t)w1 << 32) | w0) >> sh;
+                const uint64_t hi64 = (((uint64_t)w2 << 32) | w1) >> sh;
+                CandEntry e;
+                e.key = ((uint64_t)((uint32_t)lo64 & mask_lo)) | ((uint64_t)((uint32_t)hi64 & mask_hi) << 32);
+                e.t = cpos + lane * 16 + (uint64_t)j * S;
+                const uint32_t below =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
             }
-            pk_cur = pk_nxt;
+            q_count += (uint32_t)__popcll(any);
+            n_cand += (uint32_t)__popcll(any);
+            if (q_count >= 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
+                verify_candidate<EMIT>(P, e.key, e.t);
+                __builtin_amdgcn_wave_barrier();
+                q_head = (q_head + 64) & (kRingEntries - 1);
+                q_count -= 64;
+            }
+            any = __ballot(cand != 0);
+        }
+    };
+
+    // ---- main phase: tiles whose 32 chunk loads (31 scanned + halo) lie inside the text.
+    // No bounds checks here; loads run one group (4 chunks = 4 KiB per wave, 64 KiB per CU)
+    // ahead of their use.
+    const uint64_t n_main_tiles = n_bytes >= kChunkBytes ? (n_bytes - kChunkBytes) / kTileBytes : 0;
+    if (wave_id < n_main_tiles) {
+        uint64_t ld_tile = wave_id;  // loader cursor (wave-uniform)
+        uint32_t ld_c = 0;
+        const uint64_t last_tile = n_main_tiles - 1;
+        auto load_next = [&]() -> uint4 {
+            // unconditional (a branch around the load would force s_waitcnt vmcnt(0) at the
+            // join): past this wave's last tile the address is clamped and the data unused
+            const uint64_t t = ld_tile < last_tile ? ld_tile : last_tile;
+            const uint4 v = *reinterpret_cast<const uint4 *>(seq + t * kTileBytes + (uint64_t)ld_c * kChunkBytes + lane * 16);
+            if (++ld_c == (uint32_t)kTileChunks + 1) {
+                ld_c = 0;
+                ld_tile += n_waves;
+            }
+            return v;
+        };
+        // register pipeline, 4 chunks deep: a group packs the four chunks loaded one group ago
+        // and immediately re-issues the four loads for the next group (straight-line, so the
+        // compiler's s_waitcnt vmcnt(N) stay counted), then ONE copy of the scan code walks
+        // the four packed dwords (rotating packed registers costs v_movs, never a memory wait).
+        uint4 r0 = load_next(), r1 = load_next(), r2 = load_next(), r3 = load_next();
+        uint32_t pk_prev = 0;
+        for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
+            const uint64_t base = tile * kTileBytes;
+#pragma unroll 1
+            for (int g = 0; g < (kTileChunks + 1) / 4; ++g) {
+                uint32_t p0 = pack16(r0);
+                r0 = load_next();
+                uint32_t p1 = pack16(r1);
+                r1 = load_next();
+                uint32_t p2 = pack16(r2);
+                r2 = load_next();
+                uint32_t p3 = pack16(r3);
+                r3 = load_next();
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    const int ci = 4 * g + k - 1;  // chunk scanned now: (pk_prev, p0)
+                    if (ci >= 0) scan_chunk(pk_prev, p0, base + (uint64_t)ci * kChunkBytes);
+                    pk_prev = p0;
+                    p0 = p1;
+                    p1 = p2;
+                    p2 = p3;
+                }
+            }
         }
     }
+
+    // ---- tail phase: the < 17 KiB behind the last main tile, with guarded loads; one wave
+    if (wave_id == n_main_tiles % n_waves) {
+        for (uint64_t cpos = n_main_tiles * kTileBytes; cpos < n_bytes; cpos += kChunkBytes) {
+            const uint32_t pk_cur = pack16(load16(seq, cpos + lane * 16, n_bytes));
+            const uint32_t pk_nxt = pack16(load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
+            scan_chunk(pk_cur, pk_nxt, cpos);
+        }
+    }
+
     // drain what is left in this wave's ring
     if (q_count) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -232,7 +282,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             verify_candidate<EMIT>(P, e.key, e.t);
         }
     }
-    if (P.counters && lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
+    if (P.counters && lane == 0 && n_cand)
+        atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
 }
 
 template <int S>
