@@ -212,7 +212,8 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_start) (void)hipEventDestroy(e);
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
-                    (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits})
+                    (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
+                    (void *)m->d_wq, (void *)m->d_wq_count})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -264,6 +265,10 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.key_mask_lo = (uint32_t)kmask;
     p.key_mask_hi = (uint32_t)(kmask >> 32);
     p.case_insensitive = (m->flags & MK_FLAG_ASCII_CASE_INSENSITIVE) ? 1 : 0;
+    {
+        const char *dbg = getenv("MERKURIO_DEBUG");
+        p.debug = dbg ? (uint32_t)atoi(dbg) : 0;
+    }
     p.rec_flags32 = (uint32_t *)d_rec_flags;
     p.hits = (mk_hit *)d_hits;
     p.hits_cap = (mode == MK_MODE_HITS) ? hits_cap : 0;
@@ -272,6 +277,25 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t waves_per_block = kBlockThreads / 64;
     uint64_t blocks = (p.n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
+    // q-gram-hit queues: one per scan wave, sized for about one hit per 128 text bytes
+    const uint64_t n_queues = blocks * waves_per_block;
+    uint64_t cap = n_bytes / n_queues / 128;
+    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 1024), 32768);
+    {
+        const size_t need = n_queues * cap * sizeof(HitCand);
+        if (need > m->d_wq_bytes) {  // grows on a new maximum only (not in a captured graph)
+            if (m->d_wq) (void)hipFree(m->d_wq);
+            m->d_wq = nullptr;
+            m->d_wq_bytes = 0;
+            MK_HIP(hipMalloc((void **)&m->d_wq, need));
+            m->d_wq_bytes = need;
+        }
+        if (!m->d_wq_count) MK_HIP(hipMalloc((void **)&m->d_wq_count, 65536 * sizeof(uint32_t)));
+    }
+    p.wq = m->d_wq;
+    p.wq_count = m->d_wq_count;
+    p.wq_cap = (uint32_t)cap;
+    p.rec_per_byte = (double)n_rec / (double)n_bytes;
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
     if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
@@ -281,6 +305,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));
         m->timed_launches++;
     }
+    launch_resolve(p, mode == MK_MODE_HITS, (int)n_queues, st);
     m->kernel_name = name;
     m->last_grid = (int)blocks;
     MK_HIP(hipGetLastError());

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "filter.hpp"
+#include "scan_kernel.h"
 #include "host_common.h"
 
 struct mk_matcher {
@@ -34,6 +35,10 @@ struct mk_matcher {
     mk_hit *d_hits = nullptr;
     size_t d_hits_cap = 0;
     unsigned long long *d_nhits = nullptr;
+    // q-gram-hit queues between the scan and resolve kernels
+    mk::HitCand *d_wq = nullptr;
+    size_t d_wq_bytes = 0;
+    uint32_t *d_wq_count = nullptr;
     const char *kernel_name = "";
     int last_grid = 0;
     // optional per-launch kernel timing (hipEvents recorded on the launch stream, tightly

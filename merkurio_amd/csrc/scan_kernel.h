@@ -8,6 +8,14 @@
 
 namespace mk {
 
+// one exact q-gram table hit waiting for full verification: pattern `pat` would start at
+// absolute text position p
+struct alignas(16) HitCand {
+    uint64_t p;
+    uint32_t pat;
+    uint32_t pad;
+};
+
 struct ScanParams {
     // text: concatenated records
     const uint8_t *seq;       // 16-byte aligned
@@ -26,6 +34,13 @@ struct ScanParams {
     uint32_t key_mask_lo;  // low / high 32 bits of the 2q-bit key mask
     uint32_t key_mask_hi;
     uint32_t case_insensitive;
+    double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
+    // per-scan-wave queues of q-gram hits (global memory), filled by the scan kernel and
+    // consumed by the resolve kernel
+    HitCand *wq;         // n_scan_waves * wq_cap entries
+    uint32_t *wq_count;  // n_scan_waves
+    uint32_t wq_cap;
+    uint32_t debug;  // ablation switches for profiling (MERKURIO_DEBUG); 0 in production
     // outputs
     uint32_t *rec_flags32;  // rec_flags viewed as 32-bit words (byte r = record r)
     mk_hit *hits;           // may be null when !EMIT
@@ -37,6 +52,8 @@ struct ScanParams {
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream);
+// n_queues = grid_blocks * (kBlockThreads / 64) of the preceding launch_scan
+void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t stream);
 
 void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
                   const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream);

@@ -53,66 +53,129 @@ struct alignas(16) CandEntry {
 constexpr uint32_t kRingEntries = 128;  // per wave; < 64 pending before an append of <= 64
 constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry);  // 160 KiB
 
-// ---- slow path -------------------------------------------------------------------------
+// ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
+// byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
+// check, then flag / hit tuple / counters.  Used by the resolve kernel (one lane per q-gram
+// hit) and, as overflow fallback, inline by the scan kernel.
 template <bool EMIT>
-__device__ __forceinline__ void verify_candidate(const ScanParams &P, uint64_t key, uint64_t t) {
-    uint32_t slot = table_hash(key) & P.table_mask;
-    for (;;) {
-        const TableEntry e = P.table[slot];
-        if (e.pat == kEmptyPat) break;
-        slot = (slot + 1) & P.table_mask;
-        if (e.key != key) continue;
-        // level 3: exact comparison of the whole pattern at p = t - off
-        if (t < e.off) continue;
-        const uint64_t p = t - e.off;
-        const uint32_t a = P.pat_off[e.pat];
-        const uint32_t len = P.pat_off[e.pat + 1] - a;
-        if (p + len > P.n_bytes) continue;
-        bool eq = true;
-        if (P.case_insensitive) {
-            for (uint32_t i = 0; i < len; ++i)
-                if (fold_ascii(P.seq[p + i]) != fold_ascii(P.pat_bytes[a + i])) {
-                    eq = false;
-                    break;
-                }
-        } else {
-            for (uint32_t i = 0; i < len; ++i)
-                if (P.seq[p + i] != P.pat_bytes[a + i]) {
-                    eq = false;
-                    break;
-                }
-        }
-        if (!eq) continue;
-        // record containing p: largest r with rec_off[r] <= p
-        if (p < P.rec_off[0]) continue;
-        uint64_t lo = 0, hi = P.n_rec;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (P.rec_off[mid] <= p)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const uint64_t rstart = P.rec_off[lo];
-        if (p + len > P.rec_off[lo + 1]) continue;  // occurrence would cross a record boundary
-        // ---- a true occurrence
-        const uint32_t sh = (uint32_t)(lo & 3) * 8;
-        const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << sh);
-        if (P.counters) {
-            if (((old >> sh) & 0xFFu) == 0) atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS_HIT], 1ull);
-            atomicAdd(&P.counters[e.pat], 1ull);
-            atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], 1ull);
-        }
-        if (EMIT) {
-            const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
-            if (idx < P.hits_cap) {
-                mk_hit h;
-                h.rec = lo;
-                h.pat = e.pat;
-                h.pos = (uint32_t)(p - rstart);
-                P.hits[idx] = h;
+__device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p) {
+    const uint32_t a = P.pat_off[pat];
+    const uint32_t len = P.pat_off[pat + 1] - a;
+    if (p + len > P.n_bytes) return;
+    const uint8_t *__restrict__ tx = P.seq + p;
+    const uint8_t *__restrict__ pt = P.pat_bytes + a;
+    if (P.case_insensitive) {
+        for (uint32_t i = 0; i < len; ++i)
+            if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return;
+    } else {
+        // independent 8-byte (unaligned) loads, no early-exit chain: one memory round trip
+        uint64_t diff = 0;
+        if (len >= 8) {
+            for (uint32_t i = 0; i + 8 <= len; i += 8) {
+                uint64_t x, y;
+                __builtin_memcpy(&x, tx + i, 8);
+                __builtin_memcpy(&y, pt + i, 8);
+                diff |= x ^ y;
             }
+            uint64_t x, y;  // last 8 bytes (may overlap the previous block)
+            __builtin_memcpy(&x, tx + len - 8, 8);
+            __builtin_memcpy(&y, pt + len - 8, 8);
+            diff |= x ^ y;
+        } else {
+            for (uint32_t i = 0; i < len; ++i) diff |= (uint64_t)(tx[i] ^ pt[i]);
         }
+        if (diff) return;
+    }
+    // record containing p: largest r with rec_off[r] <= p.  Interpolate (reads are mostly of
+    // similar length), gallop to a bracket, then bisect.
+    if (p < P.rec_off[0]) return;
+    const uint64_t n = P.n_rec;
+    uint64_t r = (uint64_t)((double)p * P.rec_per_byte);
+    if (r >= n) r = n - 1;
+    uint64_t lo, hi;
+    if (P.rec_off[r] <= p) {
+        lo = r;
+        hi = r + 1;
+        uint64_t step = 1;
+        while (hi < n && P.rec_off[hi] <= p) {
+            lo = hi;
+            step <<= 1;
+            hi = (n - hi > step) ? hi + step : n;
+        }
+    } else {
+        hi = r;
+        uint64_t step = 1;
+        lo = r - 1;  // r > 0 here because rec_off[0] <= p
+        while (P.rec_off[lo] > p) {
+            hi = lo;
+            step <<= 1;
+            lo = lo > step ? lo - step : 0;
+        }
+    }
+    while (hi - lo > 1) {  // invariant: rec_off[lo] <= p < rec_off[hi]  (rec_off[n] = n_bytes)
+        const uint64_t mid = (lo + hi) >> 1;
+        if (P.rec_off[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint64_t rstart = P.rec_off[lo];
+    if (p + len > P.rec_off[lo + 1]) return;  // occurrence would cross a record boundary
+    // ---- a true occurrence
+    const uint32_t sh = (uint32_t)(lo & 3) * 8;
+    const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << sh);
+    if (P.counters) {
+        if (((old >> sh) & 0xFFu) == 0) atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS_HIT], 1ull);
+        atomicAdd(&P.counters[pat], 1ull);
+        atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], 1ull);
+    }
+    if (EMIT) {
+        const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
+        if (idx < P.hits_cap) {
+            mk_hit h;
+            h.rec = lo;
+            h.pat = pat;
+            h.pos = (uint32_t)(p - rstart);
+            P.hits[idx] = h;
+        }
+    }
+}
+
+// ---- level 2: up to 64 filter positives (one per lane) against the exact q-gram table -----
+// Wave-uniform loop over the probe sequence; key matches are compacted (ballot/popcount)
+// into this wave's private queue in global memory for the resolve kernel.  wq_n is the
+// wave-uniform fill count of that queue.
+template <bool EMIT>
+__device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t,
+                                                 HitCand *__restrict__ wq, uint32_t &wq_n) {
+    uint32_t slot = table_hash(key) & P.table_mask;
+    uint64_t live = __ballot(active);
+    while (live) {  // wave-uniform
+        TableEntry e;
+        e.pat = kEmptyPat;
+        if (active) e = P.table[slot];
+        const bool empty = e.pat == kEmptyPat;
+        const bool match = active && !empty && e.key == key && t >= e.off;
+        const uint64_t mm = __ballot(match);
+        if (mm) {  // uniform, rare
+            const uint32_t idx =
+                wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            if (match) {
+                if (idx < P.wq_cap) {
+                    HitCand h;
+                    h.p = t - e.off;
+                    h.pat = e.pat;
+                    h.pad = 0;
+                    wq[idx] = h;
+                } else {
+                    resolve_one<EMIT>(P, e.pat, t - e.off);  // queue full: resolve in place
+                }
+            }
+            wq_n += (uint32_t)__popcll(mm);
+        }
+        active = active && !empty;
+        slot = (slot + 1) & P.table_mask;
+        live = __ballot(active);
     }
 }
 
@@ -151,6 +214,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     const uint64_t n_bytes = P.n_bytes;
     CandEntry *ring = reinterpret_cast<CandEntry *>(bloom + kBloomWords) + wave_in_block * kRingEntries;
     uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
+    HitCand *__restrict__ wq = P.wq + wave_id * (uint64_t)P.wq_cap;  // this wave's q-gram-hit queue
+    uint32_t wq_n = 0;                                               // wave-uniform
 
     // ---- scan of one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
     // packed chunk that follows in the text (halo source for lanes 62/63)
@@ -165,6 +230,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         if (lane == 63) w2 = n1;
 
         uint32_t cand = 0;
+        if (P.debug & 4) {  // ablation: no scan at all (loads + pack only)
+            if ((w0 ^ w1 ^ w2) == 0x12345678u) n_cand++;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int sh = 2 * j * S;  // constant after unrolling
@@ -177,13 +246,14 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 lo &= mask_lo;
                 h = bloom_hash_dev(lo, 0u);
             }
-            const uint32_t w = bloom[bloom_word(h)];
+            const uint32_t w = (P.debug & 2) ? (h & 0x10101010u) : bloom[bloom_word(h)];  // ablation: no LDS probe
             const uint32_t tbit = (w >> bloom_bit_a(h)) & (w >> bloom_bit_b(h)) & 1u;
             cand |= tbit << j;
         }
 
         // filter positives -> per-wave LDS ring (ballot/popcount compaction); verified 64
         // at a time so that the L2 round trip is paid once per 64 candidates, not per chunk
+        if (P.debug & 1) cand = 0;  // ablation: drop every candidate
         uint64_t any = __ballot(cand != 0);
         while (any) {  // wave-uniform
             if (cand != 0) {
@@ -205,7 +275,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-                verify_candidate<EMIT>(P, e.key, e.t);
+                probe_candidates<EMIT>(P, true, e.key, e.t, wq, wq_n);
                 __builtin_amdgcn_wave_barrier();
                 q_head = (q_head + 64) & (kRingEntries - 1);
                 q_count -= 64;
@@ -277,13 +347,31 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     if (q_count) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < q_count) {
-            const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-            verify_candidate<EMIT>(P, e.key, e.t);
-        }
+        const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
+        probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, wq, wq_n);
     }
+    // publish this wave's queue fill for the resolve kernel (plain store: wave-private slot)
+    if (lane == 0) P.wq_count[wave_id] = wq_n < P.wq_cap ? wq_n : P.wq_cap;
     if (P.counters && lane == 0 && n_cand)
         atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
+}
+
+// ---- resolve kernel: one block per scan wave's queue, one lane per q-gram hit -----------
+template <bool EMIT>
+__global__ __launch_bounds__(256) void mk_resolve_kernel(const ScanParams P) {
+    const uint32_t n = P.wq_count[blockIdx.x];
+    const HitCand *__restrict__ q = P.wq + (uint64_t)blockIdx.x * P.wq_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const HitCand h = q[i];
+        resolve_one<EMIT>(P, h.pat, h.p);
+    }
+}
+
+void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t st) {
+    if (emit)
+        hipLaunchKernelGGL((mk_resolve_kernel<true>), dim3(n_queues), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((mk_resolve_kernel<false>), dim3(n_queues), dim3(256), 0, st, p);
 }
 
 template <int S>
