@@ -12,8 +12,8 @@
 //     pattern P at text position p covers exactly one sampled position t in [p, p+S-1], and
 //     the text q-gram at t equals P's q-gram at offset t-p, so: no false negatives, and every
 //     occurrence is discovered exactly once (t-p is unique).
-//   * level 1 (LDS): blocked Bloom filter over the packed q-gram keys, 2 bits per key inside
-//     one 32-bit word;   level 2 (L2/HBM): open-addressing table key -> (pattern, offset);
+//   * level 1 (LDS): blocked Bloom filter over the packed q-gram keys, 3 bits per key inside
+//     one 64-bit block;   level 2 (L2/HBM): open-addressing table key -> (pattern, offset);
 //     level 3: byte-exact (or ASCII-case-folded) comparison against the pattern text, then
 //     the record-boundary check.  Only level 3 decides; levels 1-2 may only over-approximate.
 #pragma once
@@ -27,8 +27,9 @@
 
 namespace mk {
 
-constexpr uint32_t kBloomLog2Words = 15;                   // 32768 words
-constexpr uint32_t kBloomWords = 1u << kBloomLog2Words;    // 128 KiB of LDS
+constexpr uint32_t kBloomLog2Blocks = 14;                  // 16384 blocks of 64 bits
+constexpr uint32_t kBloomBlocks = 1u << kBloomLog2Blocks;
+constexpr uint32_t kBloomWords = 2 * kBloomBlocks;         // 32-bit words: 128 KiB of LDS
 constexpr uint32_t kBloomBytes = kBloomWords * 4;
 constexpr uint32_t kEmptyPat = 0xFFFFFFFFu;
 constexpr int kChunkBytes = 1024;                          // one wave-iteration: 64 lanes x 16 B
@@ -54,9 +55,14 @@ MK_HD uint32_t bloom_hash(uint32_t lo, uint32_t hi) {
     h = (t & 0xFFFFFFu) * 0x85EBCBu + h;
     return h;
 }
-MK_HD uint32_t bloom_word(uint32_t h) { return h >> (32 - kBloomLog2Words); }
-MK_HD uint32_t bloom_bit_a(uint32_t h) { return (h >> 12) & 31u; }
-MK_HD uint32_t bloom_bit_b(uint32_t h) { return (h >> 7) & 31u; }
+// Blocked Bloom filter, 3 bits per key inside one 64-bit block (one ds_read_b64 per probe):
+// block = bits [3,17) of h (byte offset h & 0x1FFF8), bit a in the block's low word, bits b
+// and c in its high word.  a, b, c are the top three 5-bit groups of h: a shift instruction
+// uses only the low 5 bits of its count, so h >> 27, h >> 22, h >> 17 need no masking.
+MK_HD uint32_t bloom_block_byte(uint32_t h) { return h & (((kBloomBlocks - 1) << 3)); }
+MK_HD uint32_t bloom_bit_a(uint32_t h) { return h >> 27; }
+MK_HD uint32_t bloom_bit_b(uint32_t h) { return (h >> 22) & 31u; }
+MK_HD uint32_t bloom_bit_c(uint32_t h) { return (h >> 17) & 31u; }
 
 // hash for the exact table
 MK_HD uint32_t table_hash(uint64_t key) {

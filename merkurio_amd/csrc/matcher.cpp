@@ -173,7 +173,9 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         for (uint32_t o = 0; o < S; ++o) {
             const uint64_t key = pack_qgram(p + o, q_f);
             const uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
-            bloom[bloom_word(h)] |= (1u << bloom_bit_a(h)) | (1u << bloom_bit_b(h));
+            const uint32_t blk = bloom_block_byte(h) >> 2;  // index of the block's low word
+            bloom[blk] |= 1u << bloom_bit_a(h);
+            bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
             uint32_t slot = table_hash(key) & tmask;
             while (table[slot].pat != kEmptyPat) slot = (slot + 1) & tmask;
             table[slot].key = key;
@@ -238,7 +240,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     if (mode > MK_MODE_HITS) return fail(MK_E_INVALID_ARG, "unknown mode %u", mode);
     if (((uintptr_t)d_seq & 15) != 0) return fail(MK_E_INVALID_ARG, "d_seq must be 16-byte aligned");
-    if (((uintptr_t)d_rec_flags & 3) != 0) return fail(MK_E_INVALID_ARG, "d_rec_flags must be 4-byte aligned");
+    if (((uintptr_t)d_rec_flags & 15) != 0) return fail(MK_E_INVALID_ARG, "d_rec_flags must be 16-byte aligned");
     if (!d_n_hits || !d_rec_flags || (!d_seq_off && n_rec)) return fail(MK_E_INVALID_ARG, "null device buffer");
     if (mode == MK_MODE_HITS && !d_hits && hits_cap) return fail(MK_E_INVALID_ARG, "d_hits is null");
     hipStream_t st = (hipStream_t)stream;

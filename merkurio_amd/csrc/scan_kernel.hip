@@ -19,16 +19,21 @@
 //     verification against the pattern text -> binary search of the record offsets ->
 //     boundary check -> flag / hit tuple / counters via atomics (wave-aggregated by the
 //     compiler's atomic optimizer).
+#include <algorithm>
+
 #include "scan_kernel.h"
 
 namespace mk {
 
-// 4 ASCII bytes (little endian in d) -> 8 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3
+// 4 ASCII bytes (little endian in d) -> 8 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3.
+// x = d & 0x06060606 holds the four 2-bit codes at bits 1,9,17,25.  One 24-bit multiply by
+// 1 + 2^6 + 2^12 + 2^18 lines codes 0..2 up at bits 19..24 (no partial products collide, so
+// no carries); code 3 already sits at bits 25..26 and is OR-ed in.   v_and, v_mul_u32_u24,
+// v_and_or, v_bfe = 4 VALU ops per dword.
 __device__ __forceinline__ uint32_t pack4(uint32_t d) {
-    uint32_t x = d & 0x06060606u;
-    uint32_t y = x | (x >> 6);
-    uint32_t z = y | (y >> 12);
-    return (z >> 1) & 0xFFu;
+    const uint32_t x = d & 0x06060606u;
+    const uint32_t u = (x & 0x06000000u) | __umul24(x, 0x41041u);
+    return (u >> 19) & 0xFFu;
 }
 __device__ __forceinline__ uint32_t pack16(uint4 v) {
     return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
@@ -58,7 +63,7 @@ constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries
 // check, then flag / hit tuple / counters.  Used by the resolve kernel (one lane per q-gram
 // hit) and, as overflow fallback, inline by the scan kernel.
 template <bool EMIT>
-__device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p) {
+__device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true) {
     const uint32_t a = P.pat_off[pat];
     const uint32_t len = P.pat_off[pat + 1] - a;
     if (p + len > P.n_bytes) return;
@@ -68,19 +73,26 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
         for (uint32_t i = 0; i < len; ++i)
             if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return;
     } else {
-        // independent 8-byte (unaligned) loads, no early-exit chain: one memory round trip
+        // independent 8-byte (unaligned) loads, no early-exit chain: patterns up to 32 bytes
+        // (every k-mer) cost ONE memory round trip; the clamped offsets overlap harmlessly
         uint64_t diff = 0;
         if (len >= 8) {
-            for (uint32_t i = 0; i + 8 <= len; i += 8) {
+            const uint32_t last = len - 8;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t o = 8 * i < last ? 8 * i : last;
                 uint64_t x, y;
-                __builtin_memcpy(&x, tx + i, 8);
-                __builtin_memcpy(&y, pt + i, 8);
+                __builtin_memcpy(&x, tx + o, 8);
+                __builtin_memcpy(&y, pt + o, 8);
                 diff |= x ^ y;
             }
-            uint64_t x, y;  // last 8 bytes (may overlap the previous block)
-            __builtin_memcpy(&x, tx + len - 8, 8);
-            __builtin_memcpy(&y, pt + len - 8, 8);
-            diff |= x ^ y;
+            for (uint32_t o = 32; o < len; o += 8) {  // longer patterns
+                const uint32_t oo = o < last ? o : last;
+                uint64_t x, y;
+                __builtin_memcpy(&x, tx + oo, 8);
+                __builtin_memcpy(&y, pt + oo, 8);
+                diff |= x ^ y;
+            }
         } else {
             for (uint32_t i = 0; i < len; ++i) diff |= (uint64_t)(tx[i] ^ pt[i]);
         }
@@ -121,14 +133,11 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     }
     const uint64_t rstart = P.rec_off[lo];
     if (p + len > P.rec_off[lo + 1]) return;  // occurrence would cross a record boundary
-    // ---- a true occurrence
-    const uint32_t sh = (uint32_t)(lo & 3) * 8;
-    const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << sh);
-    if (P.counters) {
-        if (((old >> sh) & 0xFFu) == 0) atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS_HIT], 1ull);
-        atomicAdd(&P.counters[pat], 1ull);
-        atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], 1ull);
-    }
+    // ---- a true occurrence.  The flag is a plain byte store (idempotent, no atomic); the
+    // number of flagged records is counted afterwards by mk_count_flags_kernel.
+    reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
+    n_true++;
+    if (P.counters) atomicAdd(&P.counters[pat], 1ull);
     if (EMIT) {
         const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
         if (idx < P.hits_cap) {
@@ -147,7 +156,7 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
 // wave-uniform fill count of that queue.
 template <bool EMIT>
 __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t,
-                                                 HitCand *__restrict__ wq, uint32_t &wq_n) {
+                                                 HitCand *__restrict__ wq, uint32_t &wq_n, uint32_t &n_true) {
     uint32_t slot = table_hash(key) & P.table_mask;
     uint64_t live = __ballot(active);
     while (live) {  // wave-uniform
@@ -168,7 +177,7 @@ __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool activ
                     h.pad = 0;
                     wq[idx] = h;
                 } else {
-                    resolve_one<EMIT>(P, e.pat, t - e.off);  // queue full: resolve in place
+                    resolve_one<EMIT>(P, e.pat, t - e.off, n_true);  // queue full: resolve in place
                 }
             }
             wq_n += (uint32_t)__popcll(mm);
@@ -216,24 +225,25 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
     HitCand *__restrict__ wq = P.wq + wave_id * (uint64_t)P.wq_cap;  // this wave's q-gram-hit queue
     uint32_t wq_n = 0;                                               // wave-uniform
+    uint32_t n_true = 0;  // per lane: occurrences resolved in place (queue overflow only)
 
     // ---- scan of one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
     // packed chunk that follows in the text (halo source for lanes 62/63)
     auto scan_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint64_t cpos) {
+        // halo: lane i needs the packed dwords of lanes i+1 and i+2; DPP wave_shl:1 moves a
+        // whole wave by one lane in one VALU op, lane 63 keeps `old` = the next chunk's lane
         const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
         const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
         const uint32_t w0 = pk_cur;
-        uint32_t w1 = __shfl_down(pk_cur, 1);
-        uint32_t w2 = __shfl_down(pk_cur, 2);
-        if (lane == 63) w1 = n0;
-        if (lane == 62) w2 = n0;
-        if (lane == 63) w2 = n1;
+        const uint32_t w1 = __builtin_amdgcn_update_dpp(n0, w0, 0x130, 0xf, 0xf, false);
+        const uint32_t w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
 
         uint32_t cand = 0;
         if (P.debug & 4) {  // ablation: no scan at all (loads + pack only)
             if ((w0 ^ w1 ^ w2) == 0x12345678u) n_cand++;
             return;
         }
+        const char *bloom_bytes = reinterpret_cast<const char *>(bloom);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int sh = 2 * j * S;  // constant after unrolling
@@ -246,8 +256,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 lo &= mask_lo;
                 h = bloom_hash_dev(lo, 0u);
             }
-            const uint32_t w = (P.debug & 2) ? (h & 0x10101010u) : bloom[bloom_word(h)];  // ablation: no LDS probe
-            const uint32_t tbit = (w >> bloom_bit_a(h)) & (w >> bloom_bit_b(h)) & 1u;
+            uint2 blk = *reinterpret_cast<const uint2 *>(bloom_bytes + bloom_block_byte(h));  // ds_read_b64
+            if (P.debug & 2) blk = make_uint2(h & 0x10101010u, h);  // ablation: no LDS probe
+            const uint32_t tbit = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17)) & 1u;
             cand |= tbit << j;
         }
 
@@ -257,14 +268,14 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint64_t any = __ballot(cand != 0);
         while (any) {  // wave-uniform
             if (cand != 0) {
-                const int j = __ffs(cand) - 1;
+                const uint32_t j = (uint32_t)__ffs(cand) - 1u;
                 cand &= cand - 1;
-                const uint32_t sh = 2u * (uint32_t)j * S;
-                const uint64_t lo64 = (((uint64_t)w1 << 32) | w0) >> sh;
-                const uint64_t hi64 = (((uint64_t)w2 << 32) | w1) >> sh;
+                const uint32_t sh = 2u * j * S;
                 CandEntry e;
-                e.key = ((uint64_t)((uint32_t)lo64 & mask_lo)) | ((uint64_t)((uint32_t)hi64 & mask_hi) << 32);
-                e.t = cpos + lane * 16 + (uint64_t)j * S;
+                const uint32_t klo = __builtin_amdgcn_alignbit(w1, w0, sh) & mask_lo;  // sh == 0 -> w0
+                const uint32_t khi = __builtin_amdgcn_alignbit(w2, w1, sh) & mask_hi;
+                e.key = ((uint64_t)khi << 32) | klo;
+                e.t = cpos + (lane * 16 + j * S);
                 const uint32_t below =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
                 ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-                probe_candidates<EMIT>(P, true, e.key, e.t, wq, wq_n);
+                probe_candidates<EMIT>(P, true, e.key, e.t, wq, wq_n, n_true);
                 __builtin_amdgcn_wave_barrier();
                 q_head = (q_head + 64) & (kRingEntries - 1);
                 q_count -= 64;
@@ -289,17 +300,21 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // ahead of their use.
     const uint64_t n_main_tiles = n_bytes >= kChunkBytes ? (n_bytes - kChunkBytes) / kTileBytes : 0;
     if (wave_id < n_main_tiles) {
-        uint64_t ld_tile = wave_id;  // loader cursor (wave-uniform)
+        // loader cursor (wave-uniform): pointer to the next chunk to fetch.  Past this wave's
+        // last tile the pointer parks on the last main tile: the loads stay unconditional (a
+        // branch around a load would force s_waitcnt vmcnt(0) at the join), their data unused.
+        uint64_t ld_tile = wave_id;
         uint32_t ld_c = 0;
         const uint64_t last_tile = n_main_tiles - 1;
+        const uint8_t *ld_ptr = seq + wave_id * kTileBytes + lane * 16;
         auto load_next = [&]() -> uint4 {
-            // unconditional (a branch around the load would force s_waitcnt vmcnt(0) at the
-            // join): past this wave's last tile the address is clamped and the data unused
-            const uint64_t t = ld_tile < last_tile ? ld_tile : last_tile;
-            const uint4 v = *reinterpret_cast<const uint4 *>(seq + t * kTileBytes + (uint64_t)ld_c * kChunkBytes + lane * 16);
-            if (++ld_c == (uint32_t)kTileChunks + 1) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ld_ptr);
+            ld_ptr += kChunkBytes;
+            if (++ld_c == (uint32_t)kTileChunks + 1) {  // next tile of this wave
                 ld_c = 0;
                 ld_tile += n_waves;
+                const uint64_t t = ld_tile < last_tile ? ld_tile : last_tile;
+                ld_ptr = seq + t * kTileBytes + lane * 16;
             }
             return v;
         };
@@ -348,12 +363,13 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-        probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, wq, wq_n);
+        probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, wq, wq_n, n_true);
     }
     // publish this wave's queue fill for the resolve kernel (plain store: wave-private slot)
     if (lane == 0) P.wq_count[wave_id] = wq_n < P.wq_cap ? wq_n : P.wq_cap;
     if (P.counters && lane == 0 && n_cand)
         atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
+    if (P.counters && n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
 }
 
 // ---- resolve kernel: one block per scan wave's queue, one lane per q-gram hit -----------
@@ -361,10 +377,32 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void mk_resolve_kernel(const ScanParams P) {
     const uint32_t n = P.wq_count[blockIdx.x];
     const HitCand *__restrict__ q = P.wq + (uint64_t)blockIdx.x * P.wq_cap;
+    uint32_t n_true = 0;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const HitCand h = q[i];
-        resolve_one<EMIT>(P, h.pat, h.p);
+        resolve_one<EMIT>(P, h.pat, h.p, n_true);
     }
+    if (P.counters) {  // one atomic per wave (uniform address: aggregated by the compiler)
+        if (n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
+    }
+}
+
+// number of records with rec_flags != 0 -> counters[n_pat + MK_SUM_RECORDS_HIT]
+__global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint32_t *__restrict__ flags32, uint64_t n_rec,
+                                                             unsigned long long *__restrict__ out) {
+    const uint64_t n16 = n_rec / 16;
+    unsigned long long c = 0;
+    const uint4 *__restrict__ f4 = reinterpret_cast<const uint4 *>(flags32);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = f4[i];  // flag bytes are 0 or 1
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint8_t *fb = reinterpret_cast<const uint8_t *>(flags32);
+        for (uint64_t r = n16 * 16; r < n_rec; ++r) c += fb[r] != 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
 void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t st) {
@@ -372,6 +410,12 @@ void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t st
         hipLaunchKernelGGL((mk_resolve_kernel<true>), dim3(n_queues), dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((mk_resolve_kernel<false>), dim3(n_queues), dim3(256), 0, st, p);
+    if (p.counters) {
+        const uint64_t n16 = p.n_rec / 16;
+        const int blocks = (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, (n16 + 255) / 256));
+        hipLaunchKernelGGL(mk_count_flags_kernel, dim3(blocks), dim3(256), 0, st, p.rec_flags32, p.n_rec,
+                           p.counters + p.n_pat + MK_SUM_RECORDS_HIT);
+    }
 }
 
 template <int S>
