@@ -36,12 +36,15 @@ constexpr int kChunkBytes = 1024;                          // one wave-iteration
 constexpr int kTileChunks = 31;                            // scanned chunks per wave tile (+1 halo chunk = 32 loads)
 constexpr int kBlockThreads = 1024;                        // 16 waves, one workgroup per CU
 
-// one exact-table slot (16 B, one global_load_dwordx4)
-struct alignas(16) TableEntry {
-    uint64_t key;
-    uint32_t pat;  // kEmptyPat = empty slot
-    uint32_t off;  // offset of the q-gram inside the pattern (0..S-1)
+// one exact-table slot (8 B, one global_load_dwordx2): a 32-bit fingerprint of the q-gram key
+// and (pattern << 4 | offset of the q-gram inside the pattern).  A fingerprint collision only
+// costs a wasted byte comparison in the resolve kernel.
+struct alignas(8) TableEntry {
+    uint32_t fp;
+    uint32_t pat_off;  // kEmptyPat = empty slot
 };
+constexpr uint32_t kMaxPatterns = (1u << 28) - 1;
+MK_HD uint32_t key_fingerprint(uint64_t key) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u); }
 
 MK_HD uint32_t code2(uint8_t c) { return (c >> 1) & 3u; }
 

@@ -38,8 +38,11 @@ int fail(int code, const char *fmt, ...) {
 
 // ---- filter geometry -----------------------------------------------------------------------
 // Pick (q, S): sampling stride S in {16,8,4,2,1}, q-gram length q = min(32, Lmin - S + 1).
-// Larger S = fewer probes per base but S x more table entries; keep the Bloom filter sparse
-// (<= ~48k entries in 2^20 bits at 2 bits/key) and q-grams selective (q >= 14) when S > 1.
+// Larger S = fewer probes per base (the scan is VALU-bound: ~17 vector ops per probe) but S x
+// more filter entries, i.e. more false positives to verify.  Measured on MI355X with 10 k
+// 31-mers (profiles/r01_stride_sweep.txt): S=8 (80 k entries, 0.2 % of bases become
+// candidates) beats S=4 by 14 % and S=16 by 60 %.  Rule: largest S with <= 96 k entries and
+// q >= 14.
 static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t *S) {
     const char *force = getenv("MERKURIO_FORCE_STRIDE");  // tuning / test hook
     int forced = force ? atoi(force) : 0;
@@ -48,7 +51,7 @@ static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t
         uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
         if (forced) {
             if ((int)s != forced) continue;
-        } else if (s > 1 && (qq < 14 || n_pat * s > 49152)) {
+        } else if (s > 1 && (qq < 14 || n_pat * s > 98304)) {
             continue;
         }
         *q = qq;
@@ -100,6 +103,7 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
     *out = nullptr;
     if (n_pat == 0 || !pat_off || !pat_bytes) return fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
     if (algo > MK_ALGO_BNDMQ) return fail(MK_E_INVALID_ARG, "unknown algo %u", algo);
+    if (n_pat > kMaxPatterns) return fail(MK_E_UNSUPPORTED, "too many patterns (%u)", n_pat);
     const bool ci = flags & MK_FLAG_ASCII_CASE_INSENSITIVE;
     uint32_t lmin = 0xFFFFFFFFu, lmax = 0;
     for (uint32_t i = 0; i < n_pat; ++i) {
@@ -163,9 +167,8 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
     std::vector<uint32_t> bloom(kBloomWords, 0);
     std::vector<TableEntry> table(slots);
     for (auto &e : table) {
-        e.key = 0;
-        e.pat = kEmptyPat;
-        e.off = 0;
+        e.fp = 0;
+        e.pat_off = kEmptyPat;
     }
     const uint32_t tmask = m->table_slots - 1;
     for (uint32_t pi = 0; pi < n_pat; ++pi) {
@@ -177,10 +180,9 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
             bloom[blk] |= 1u << bloom_bit_a(h);
             bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
             uint32_t slot = table_hash(key) & tmask;
-            while (table[slot].pat != kEmptyPat) slot = (slot + 1) & tmask;
-            table[slot].key = key;
-            table[slot].pat = pi;
-            table[slot].off = o;
+            while (table[slot].pat_off != kEmptyPat) slot = (slot + 1) & tmask;
+            table[slot].fp = key_fingerprint(key);
+            table[slot].pat_off = (pi << 4) | o;
         }
     }
     auto bail = [&](int code) {

@@ -158,13 +158,16 @@ template <bool EMIT>
 __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t,
                                                  HitCand *__restrict__ wq, uint32_t &wq_n, uint32_t &n_true) {
     uint32_t slot = table_hash(key) & P.table_mask;
+    const uint32_t fp = key_fingerprint(key);
     uint64_t live = __ballot(active);
     while (live) {  // wave-uniform
         TableEntry e;
-        e.pat = kEmptyPat;
+        e.fp = 0;
+        e.pat_off = kEmptyPat;
         if (active) e = P.table[slot];
-        const bool empty = e.pat == kEmptyPat;
-        const bool match = active && !empty && e.key == key && t >= e.off;
+        const bool empty = e.pat_off == kEmptyPat;
+        const uint32_t e_off = e.pat_off & 15u, e_pat = e.pat_off >> 4;
+        const bool match = active && !empty && e.fp == fp && t >= e_off;
         const uint64_t mm = __ballot(match);
         if (mm) {  // uniform, rare
             const uint32_t idx =
@@ -172,12 +175,12 @@ __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool activ
             if (match) {
                 if (idx < P.wq_cap) {
                     HitCand h;
-                    h.p = t - e.off;
-                    h.pat = e.pat;
+                    h.p = t - e_off;
+                    h.pat = e_pat;
                     h.pad = 0;
                     wq[idx] = h;
                 } else {
-                    resolve_one<EMIT>(P, e.pat, t - e.off, n_true);  // queue full: resolve in place
+                    resolve_one<EMIT>(P, e_pat, t - e_off, n_true);  // queue full: resolve in place
                 }
             }
             wq_n += (uint32_t)__popcll(mm);
