@@ -18,6 +18,8 @@ CLI_PATH = os.path.join(LIB_DIR, "merkurio")
 LIB_SOURCES = ["scan_kernel.hip", "matcher.cpp", "host_patterns.cpp", "host_loops.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+# profiling builds: MERKURIO_HIPCC_FLAGS="-DMK_ABLATE=1" python -m merkurio_amd.build --force
+FLAGS += os.environ.get("MERKURIO_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

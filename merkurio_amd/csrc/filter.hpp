@@ -44,19 +44,23 @@ struct alignas(8) TableEntry {
     uint32_t pat_off;  // kEmptyPat = empty slot
 };
 constexpr uint32_t kMaxPatterns = (1u << 28) - 1;
+// The table is an array of 32-byte buckets of 4 entries, filled front to back; a lookup reads
+// one whole bucket (2 x global_load_dwordx4, one memory round trip) and moves on to the next
+// bucket only if this one is full.
+constexpr uint32_t kBucketEntries = 4;
 MK_HD uint32_t key_fingerprint(uint64_t key) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u); }
 
 MK_HD uint32_t code2(uint8_t c) { return (c >> 1) & 3u; }
 
-// hash for the LDS Bloom filter: (word index, bit a, bit b) from a 64-bit key (lo, hi).
-// Two 24x24-bit multiply-adds (v_mad_u32_u24, full rate on CDNA4; v_mul_lo_u32 is quarter
-// rate): t = key >> 24;  h = lo[0:24) * C1 + t;  h = t[0:24) * C2 + h.   Every key bit
-// reaches the high (word-index) bits through a multiply or the additive t.
+// Hash for the LDS Bloom filter, from the 2q-bit packed key (bits at or above 2q are zero):
+//     lo = key[0:32)   t = key[24:56)
+//     h  = lo[0:24) * C1  +  t[0:24) * C2  +  (t & 0xFF000000)          (mod 2^32)
+// i.e. two 24x24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24) over key bits 0..47 plus key
+// bits 48..55 added in place; bits >= 56 (q > 28) do not take part.  The device variants
+// specialised for one q skip whatever masking that q makes redundant (scan_kernel.hip).
 MK_HD uint32_t bloom_hash(uint32_t lo, uint32_t hi) {
     const uint32_t t = (lo >> 24) | (hi << 8);
-    uint32_t h = (lo & 0xFFFFFFu) * 0x9E3779u + t;
-    h = (t & 0xFFFFFFu) * 0x85EBCBu + h;
-    return h;
+    return (lo & 0xFFFFFFu) * 0x9E3779u + (t & 0xFFFFFFu) * 0x85EBCBu + (t & 0xFF000000u);
 }
 // Blocked Bloom filter, 3 bits per key inside one 64-bit block (one ds_read_b64 per probe):
 // block = bits [3,17) of h (byte offset h & 0x1FFF8), bit a in the block's low word, bits b

@@ -170,7 +170,7 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         e.fp = 0;
         e.pat_off = kEmptyPat;
     }
-    const uint32_t tmask = m->table_slots - 1;
+    const uint32_t bmask = m->table_slots / kBucketEntries - 1;  // bucket index mask
     for (uint32_t pi = 0; pi < n_pat; ++pi) {
         const uint8_t *p = pat_bytes + pat_off[pi];
         for (uint32_t o = 0; o < S; ++o) {
@@ -179,10 +179,18 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
             const uint32_t blk = bloom_block_byte(h) >> 2;  // index of the block's low word
             bloom[blk] |= 1u << bloom_bit_a(h);
             bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
-            uint32_t slot = table_hash(key) & tmask;
-            while (table[slot].pat_off != kEmptyPat) slot = (slot + 1) & tmask;
-            table[slot].fp = key_fingerprint(key);
-            table[slot].pat_off = (pi << 4) | o;
+            uint32_t b = table_hash(key) & bmask;
+            for (;;) {  // first bucket from the home bucket on with a free entry
+                TableEntry *e = &table[(size_t)b * kBucketEntries];
+                uint32_t k = 0;
+                while (k < kBucketEntries && e[k].pat_off != kEmptyPat) ++k;
+                if (k < kBucketEntries) {
+                    e[k].fp = key_fingerprint(key);
+                    e[k].pat_off = (pi << 4) | o;
+                    break;
+                }
+                b = (b + 1) & bmask;
+            }
         }
     }
     auto bail = [&](int code) {
@@ -260,7 +268,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
     p.bloom = m->d_bloom;
     p.table = m->d_table;
-    p.table_mask = m->table_slots - 1;
+    p.table_mask = m->table_slots / kBucketEntries - 1;  // bucket mask
     p.pat_bytes = m->d_pat_bytes;
     p.pat_off = m->d_pat_off;
     p.n_pat = m->n_pat;
@@ -269,10 +277,6 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.key_mask_lo = (uint32_t)kmask;
     p.key_mask_hi = (uint32_t)(kmask >> 32);
     p.case_insensitive = (m->flags & MK_FLAG_ASCII_CASE_INSENSITIVE) ? 1 : 0;
-    {
-        const char *dbg = getenv("MERKURIO_DEBUG");
-        p.debug = dbg ? (uint32_t)atoi(dbg) : 0;
-    }
     p.rec_flags32 = (uint32_t *)d_rec_flags;
     p.hits = (mk_hit *)d_hits;
     p.hits_cap = (mode == MK_MODE_HITS) ? hits_cap : 0;

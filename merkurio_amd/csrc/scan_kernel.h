@@ -25,8 +25,8 @@ struct ScanParams {
     uint64_t n_tiles;  // ceil(n_bytes / (kTileChunks * kChunkBytes))
     // compiled pattern set
     const uint32_t *bloom;    // kBloomWords
-    const TableEntry *table;  // table_mask + 1 slots
-    uint32_t table_mask;
+    const TableEntry *table;  // (table_mask + 1) buckets of kBucketEntries entries
+    uint32_t table_mask;      // bucket index mask
     const uint8_t *pat_bytes;
     const uint32_t *pat_off;  // n_pat + 1
     uint32_t n_pat;
@@ -40,7 +40,6 @@ struct ScanParams {
     HitCand *wq;         // n_scan_waves * wq_cap entries
     uint32_t *wq_count;  // n_scan_waves
     uint32_t wq_cap;
-    uint32_t debug;  // ablation switches for profiling (MERKURIO_DEBUG); 0 in production
     // outputs
     uint32_t *rec_flags32;  // rec_flags viewed as 32-bit words (byte r = record r)
     mk_hit *hits;           // may be null when !EMIT

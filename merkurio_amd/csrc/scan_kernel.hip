@@ -25,18 +25,18 @@
 
 namespace mk {
 
-// 4 ASCII bytes (little endian in d) -> 8 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3.
-// x = d & 0x06060606 holds the four 2-bit codes at bits 1,9,17,25.  One 24-bit multiply by
-// 1 + 2^6 + 2^12 + 2^18 lines codes 0..2 up at bits 19..24 (no partial products collide, so
-// no carries); code 3 already sits at bits 25..26 and is OR-ed in.   v_and, v_mul_u32_u24,
-// v_and_or, v_bfe = 4 VALU ops per dword.
-__device__ __forceinline__ uint32_t pack4(uint32_t d) {
-    const uint32_t x = d & 0x06060606u;
-    const uint32_t u = (x & 0x06000000u) | __umul24(x, 0x41041u);
-    return (u >> 19) & 0xFFu;
-}
+// 16 ASCII bytes -> 32 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3.
+// Per dword: x = d & 0x06060606 holds the four codes at bits 1,9,17,25; x * (2^23+2^17+2^11+2^5)
+// lines them up in the TOP BYTE of the product (bits 24..31; the other partial products fall
+// on distinct 2-bit slots below bit 24, so nothing carries).  Three v_perm_b32 then gather the
+// four top bytes: 4 x (v_and + v_mul_lo) + 3 = 11 VALU ops per 16 bases.
+__device__ __forceinline__ uint32_t pack4_top(uint32_t d) { return (d & 0x06060606u) * 0x00820820u; }
 __device__ __forceinline__ uint32_t pack16(uint4 v) {
-    return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+    const uint32_t u0 = pack4_top(v.x), u1 = pack4_top(v.y), u2 = pack4_top(v.z), u3 = pack4_top(v.w);
+    // v_perm_b32(src0, src1, sel): bytes 0-3 of the 8-byte pool come from src1, 4-7 from src0
+    const uint32_t lo16 = __builtin_amdgcn_perm(u1, u0, 0x0c0c0703u);  // [u0.b3, u1.b3, 0, 0]
+    const uint32_t hi16 = __builtin_amdgcn_perm(u3, u2, 0x07030c0cu);  // [0, 0, u2.b3, u3.b3]
+    return lo16 | hi16;
 }
 
 // 16 bytes at text position pos (pos % 16 == 0); bytes at or beyond n read as 0
@@ -57,6 +57,7 @@ struct alignas(16) CandEntry {
 };
 constexpr uint32_t kRingEntries = 128;  // per wave; < 64 pending before an append of <= 64
 constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry);  // 160 KiB
+static_assert(kLdsBytes == 160 * 1024, "one workgroup owns the whole LDS of its CU");
 
 // ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
 // byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
@@ -157,53 +158,110 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
 template <bool EMIT>
 __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t,
                                                  HitCand *__restrict__ wq, uint32_t &wq_n, uint32_t &n_true) {
-    uint32_t slot = table_hash(key) & P.table_mask;
+    uint32_t b = table_hash(key) & P.table_mask;
     const uint32_t fp = key_fingerprint(key);
     uint64_t live = __ballot(active);
-    while (live) {  // wave-uniform
-        TableEntry e;
-        e.fp = 0;
-        e.pat_off = kEmptyPat;
-        if (active) e = P.table[slot];
-        const bool empty = e.pat_off == kEmptyPat;
-        const uint32_t e_off = e.pat_off & 15u, e_pat = e.pat_off >> 4;
-        const bool match = active && !empty && e.fp == fp && t >= e_off;
-        const uint64_t mm = __ballot(match);
-        if (mm) {  // uniform, rare
-            const uint32_t idx =
-                wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-            if (match) {
-                if (idx < P.wq_cap) {
-                    HitCand h;
-                    h.p = t - e_off;
-                    h.pat = e_pat;
-                    h.pad = 0;
-                    wq[idx] = h;
-                } else {
-                    resolve_one<EMIT>(P, e_pat, t - e_off, n_true);  // queue full: resolve in place
-                }
-            }
-            wq_n += (uint32_t)__popcll(mm);
+    while (live) {  // wave-uniform; one iteration unless some lane's home bucket is full
+        uint4 v0 = make_uint4(0, kEmptyPat, 0, kEmptyPat), v1 = v0;
+        if (active) {
+            const uint4 *bp = reinterpret_cast<const uint4 *>(P.table + (size_t)b * kBucketEntries);
+            v0 = bp[0];
+            v1 = bp[1];
         }
-        active = active && !empty;
-        slot = (slot + 1) & P.table_mask;
+        const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
+        const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e_off = epo[k] & 15u, e_pat = epo[k] >> 4;
+            const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
+            const uint64_t mm = __ballot(match);
+            if (mm) {  // uniform, rare
+                const uint32_t idx = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                if (match) {
+                    if (idx < P.wq_cap) {
+                        HitCand h;
+                        h.p = t - e_off;
+                        h.pat = e_pat;
+                        h.pad = 0;
+                        wq[idx] = h;
+                    } else {
+                        resolve_one<EMIT>(P, e_pat, t - e_off, n_true);  // queue full: resolve in place
+                    }
+                }
+                wq_n += (uint32_t)__popcll(mm);
+            }
+        }
+        active = active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
+        b = (b + 1) & P.table_mask;
         live = __ballot(active);
     }
 }
 
-// device form of filter.hpp's bloom_hash (identical value; spelled with the 24-bit multiply
-// intrinsics so that hipcc emits v_alignbit + 2 x v_mad_u32_u24)
-__device__ __forceinline__ uint32_t bloom_hash_dev(uint32_t lo, uint32_t hi) {
-    const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 24);
-    uint32_t h = __umul24(lo, 0x9E3779u) + t;
-    h = __umul24(t, 0x85EBCBu) + h;
-    return h;
+// compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
+//   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only
+#ifndef MK_ABLATE
+#define MK_ABLATE 0
+#endif
+
+// Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
+// sizes that matter get their own kernels: no runtime masks, no unused halo words);
+// QC == 0: runtime q <= 16 (32-bit keys); QC == -1: runtime q in 17..32.
+template <int S, int QC>
+struct Geo {
+    static constexpr bool kFixed = QC > 0;
+    static constexpr int kNS = 16 / S;                                     // samples per lane per chunk
+    static constexpr int kSpan = kFixed ? (kNS - 1) * S + QC : 48;         // bases a lane looks at
+    static constexpr bool kNeedW1 = kSpan > 16, kNeedW2 = kSpan > 32;      // halo words
+};
+
+// bits [bit, bit+32) of the packed stream w0 | w1<<32 | w2<<64 (bit is a compile-time constant)
+__device__ __forceinline__ uint32_t stream32(uint32_t w0, uint32_t w1, uint32_t w2, int bit) {
+    const int k = bit >> 5, r = bit & 31;
+    const uint32_t a = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : 0u;
+    const uint32_t b = k == 0 ? w1 : k == 1 ? w2 : 0u;
+    return r ? __builtin_amdgcn_alignbit(b, a, r) : a;
+}
+
+// Bloom hash of the q-gram that starts `sh` bits into the lane's packed stream; equals
+// filter.hpp's bloom_hash(key) for the masked key.
+template <int S, int QC>
+__device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32_t w2, int sh, uint32_t mask_lo,
+                                                uint32_t mask_hi) {
+    constexpr uint32_t C1 = 0x9E3779u, C2 = 0x85EBCBu;
+    if constexpr (QC > 0) {
+        const uint32_t lo = stream32(w0, w1, w2, sh);
+        if constexpr (QC <= 12) {
+            return __umul24(lo & ((1u << (2 * QC)) - 1u), C1);
+        } else if constexpr (QC < 16) {
+            const uint32_t l = lo & ((1u << (2 * QC)) - 1u);
+            return __umul24(l, C1) + __umul24(l >> 24, C2);
+        } else if constexpr (QC == 16) {
+            return __umul24(lo, C1) + __umul24(lo >> 24, C2);
+        } else if constexpr (QC < 24) {  // key bits 24 .. 2q-1 live in t's low bits
+            const uint32_t t = stream32(w0, w1, w2, sh + 24) & ((1u << (2 * QC - 24)) - 1u);
+            return __umul24(lo, C1) + __umul24(t, C2);
+        } else if constexpr (QC == 24) {  // mul24 ignores t's top byte: no mask at all
+            const uint32_t t = stream32(w0, w1, w2, sh + 24);
+            return __umul24(lo, C1) + __umul24(t, C2);
+        } else {  // 25..32: key bits 48..55 are added in place, bits >= 56 ignored
+            const uint32_t t = stream32(w0, w1, w2, sh + 24);
+            constexpr uint32_t top = QC >= 28 ? 0xFF000000u : (((1u << (2 * QC - 48)) - 1u) << 24);
+            return __umul24(lo, C1) + __umul24(t, C2) + (t & top);
+        }
+    } else {
+        const uint32_t lo = stream32(w0, w1, w2, sh) & mask_lo;
+        const uint32_t hi = QC == 0 ? 0u : (stream32(w0, w1, w2, sh + 32) & mask_hi);
+        const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 24);
+        return __umul24(lo, C1) + __umul24(t, C2) + (t & 0xFF000000u);
+    }
 }
 
 // ---- main kernel -----------------------------------------------------------------------
-template <int S, bool WIDE, bool EMIT>
+template <int S, int QC, bool EMIT>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
-    extern __shared__ uint32_t bloom[];
+    using G = Geo<S, QC>;
+    __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
@@ -219,7 +277,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR
     const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlockThreads / 64) + wave_in_block;
     const uint64_t n_waves = (uint64_t)gridDim.x * (kBlockThreads / 64);
-    constexpr int NS = 16 / S;
+    constexpr int NS = G::kNS;
     constexpr uint64_t kTileBytes = (uint64_t)kTileChunks * kChunkBytes;
     const uint32_t mask_lo = P.key_mask_lo, mask_hi = P.key_mask_hi;
     const uint8_t *__restrict__ seq = P.seq;
@@ -235,39 +293,39 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     auto scan_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint64_t cpos) {
         // halo: lane i needs the packed dwords of lanes i+1 and i+2; DPP wave_shl:1 moves a
         // whole wave by one lane in one VALU op, lane 63 keeps `old` = the next chunk's lane
-        const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
-        const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
         const uint32_t w0 = pk_cur;
-        const uint32_t w1 = __builtin_amdgcn_update_dpp(n0, w0, 0x130, 0xf, 0xf, false);
-        const uint32_t w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
+        uint32_t w1 = 0, w2 = 0;
+        if constexpr (G::kNeedW1) {
+            const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
+            w1 = __builtin_amdgcn_update_dpp(n0, w0, 0x130, 0xf, 0xf, false);
+        }
+        if constexpr (G::kNeedW2) {
+            const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
+            w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
+        }
 
         uint32_t cand = 0;
-        if (P.debug & 4) {  // ablation: no scan at all (loads + pack only)
+        if constexpr ((MK_ABLATE & 4) != 0) {  // loads + pack only
             if ((w0 ^ w1 ^ w2) == 0x12345678u) n_cand++;
             return;
         }
         const char *bloom_bytes = reinterpret_cast<const char *>(bloom);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const int sh = 2 * j * S;  // constant after unrolling
-            uint32_t lo = sh ? __builtin_amdgcn_alignbit(w1, w0, sh) : w0;
-            uint32_t h;
-            if (WIDE) {
-                uint32_t hi = (sh ? __builtin_amdgcn_alignbit(w2, w1, sh) : w1) & mask_hi;
-                h = bloom_hash_dev(lo, hi);
-            } else {
-                lo &= mask_lo;
-                h = bloom_hash_dev(lo, 0u);
-            }
-            uint2 blk = *reinterpret_cast<const uint2 *>(bloom_bytes + bloom_block_byte(h));  // ds_read_b64
-            if (P.debug & 2) blk = make_uint2(h & 0x10101010u, h);  // ablation: no LDS probe
-            const uint32_t tbit = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17)) & 1u;
-            cand |= tbit << j;
+            const uint32_t h = sample_hash<S, QC>(w0, w1, w2, 2 * j * S, mask_lo, mask_hi);
+            uint2 blk;
+            if constexpr ((MK_ABLATE & 2) != 0)
+                blk = make_uint2(h & 0x10101010u, h);
+            else
+                blk = *reinterpret_cast<const uint2 *>(bloom_bytes + bloom_block_byte(h));  // ds_read_b64
+            // all three filter bits set?  (shift counts use the low 5 bits of their register)
+            const uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
+            cand |= (m & 1u) << j;
         }
+        if constexpr ((MK_ABLATE & 1) != 0) cand = 0;
 
         // filter positives -> per-wave LDS ring (ballot/popcount compaction); verified 64
         // at a time so that the L2 round trip is paid once per 64 candidates, not per chunk
-        if (P.debug & 1) cand = 0;  // ablation: drop every candidate
         uint64_t any = __ballot(cand != 0);
         while (any) {  // wave-uniform
             if (cand != 0) {
@@ -421,57 +479,42 @@ void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t st
     }
 }
 
-template <int S>
-static const char *launch_s(const ScanParams &p, bool wide, bool emit, int grid, hipStream_t st) {
-    dim3 g(grid), b(kBlockThreads);
-#define MK_LAUNCH(W, E)                                                                                        \
-    do {                                                                                                       \
-        static bool attr_done = false;                                                                         \
-        if (!attr_done) {                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mk_scan_kernel<S, W, E>),                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);           \
-            attr_done = true;                                                                                  \
-        }                                                                                                      \
-        hipLaunchKernelGGL((mk_scan_kernel<S, W, E>), g, b, kLdsBytes, st, p);                               \
-    } while (0)
-    if (wide) {
-        if (emit)
-            MK_LAUNCH(true, true);
-        else
-            MK_LAUNCH(true, false);
-    } else {
-        if (emit)
-            MK_LAUNCH(false, true);
-        else
-            MK_LAUNCH(false, false);
-    }
-#undef MK_LAUNCH
-    static const char *names[5][2][2] = {
-        {{"mk_scan_kernel<1,false,false>", "mk_scan_kernel<1,false,true>"},
-         {"mk_scan_kernel<1,true,false>", "mk_scan_kernel<1,true,true>"}},
-        {{"mk_scan_kernel<2,false,false>", "mk_scan_kernel<2,false,true>"},
-         {"mk_scan_kernel<2,true,false>", "mk_scan_kernel<2,true,true>"}},
-        {{"mk_scan_kernel<4,false,false>", "mk_scan_kernel<4,false,true>"},
-         {"mk_scan_kernel<4,true,false>", "mk_scan_kernel<4,true,true>"}},
-        {{"mk_scan_kernel<8,false,false>", "mk_scan_kernel<8,false,true>"},
-         {"mk_scan_kernel<8,true,false>", "mk_scan_kernel<8,true,true>"}},
-        {{"mk_scan_kernel<16,false,false>", "mk_scan_kernel<16,false,true>"},
-         {"mk_scan_kernel<16,true,false>", "mk_scan_kernel<16,true,true>"}},
-    };
-    const int si = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
-    return names[si][wide ? 1 : 0][emit ? 1 : 0];
+template <int S, int QC, bool EMIT>
+static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
+    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT>), dim3(grid), dim3(kBlockThreads), 0, st, p);
+    return name;
 }
 
+#define MK_VARIANT(S_, QC_)                                                                            \
+    return emit ? launch_one<S_, QC_, true>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true>") \
+                : launch_one<S_, QC_, false>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false>")
+
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream) {
+    // k-mer sizes with their own kernels (q fixed at compile time): the 31-mer family
+    // (q = 32 - S) and the 21-mer family (q = 22 - S, S <= 4)
+    if (S == 16 && p.q == 16) MK_VARIANT(16, 16);
+    if (S == 8 && p.q == 24) MK_VARIANT(8, 24);
+    if (S == 4 && p.q == 28) MK_VARIANT(4, 28);
+    if (S == 4 && p.q == 18) MK_VARIANT(4, 18);
+    // everything else: runtime q, narrow (q <= 16) or wide keys
+    if (wide) switch (S) {
+            case 1: MK_VARIANT(1, -1);
+            case 2: MK_VARIANT(2, -1);
+            case 4: MK_VARIANT(4, -1);
+            case 8: MK_VARIANT(8, -1);
+            case 16: MK_VARIANT(16, -1);
+            default: return nullptr;
+        }
     switch (S) {
-        case 1: return launch_s<1>(p, wide, emit, grid_blocks, stream);
-        case 2: return launch_s<2>(p, wide, emit, grid_blocks, stream);
-        case 4: return launch_s<4>(p, wide, emit, grid_blocks, stream);
-        case 8: return launch_s<8>(p, wide, emit, grid_blocks, stream);
-        case 16: return launch_s<16>(p, wide, emit, grid_blocks, stream);
+        case 1: MK_VARIANT(1, 0);
+        case 2: MK_VARIANT(2, 0);
+        case 4: MK_VARIANT(4, 0);
+        case 8: MK_VARIANT(8, 0);
+        case 16: MK_VARIANT(16, 0);
         default: return nullptr;
     }
 }
+#undef MK_VARIANT
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
 __global__ void mk_synth_fill_kernel(uint64_t seed, uint64_t n_bytes, uint8_t *__restrict__ seq) {
