@@ -225,7 +225,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_wq, (void *)m->d_wq_count})
+                    (void *)m->d_wq})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -250,7 +250,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     if (mode > MK_MODE_HITS) return fail(MK_E_INVALID_ARG, "unknown mode %u", mode);
     if (((uintptr_t)d_seq & 15) != 0) return fail(MK_E_INVALID_ARG, "d_seq must be 16-byte aligned");
-    if (((uintptr_t)d_rec_flags & 15) != 0) return fail(MK_E_INVALID_ARG, "d_rec_flags must be 16-byte aligned");
+    if (((uintptr_t)d_rec_flags & 3) != 0) return fail(MK_E_INVALID_ARG, "d_rec_flags must be 4-byte aligned");
     if (!d_n_hits || !d_rec_flags || (!d_seq_off && n_rec)) return fail(MK_E_INVALID_ARG, "null device buffer");
     if (mode == MK_MODE_HITS && !d_hits && hits_cap) return fail(MK_E_INVALID_ARG, "d_hits is null");
     hipStream_t st = (hipStream_t)stream;
@@ -285,24 +285,13 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t waves_per_block = kBlockThreads / 64;
     uint64_t blocks = (p.n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
-    // q-gram-hit queues: one per scan wave, sized for about one hit per 128 text bytes
-    const uint64_t n_queues = blocks * waves_per_block;
-    uint64_t cap = n_bytes / n_queues / 128;
-    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 1024), 32768);
-    {
-        const size_t need = n_queues * cap * sizeof(HitCand);
-        if (need > m->d_wq_bytes) {  // grows on a new maximum only (not in a captured graph)
-            if (m->d_wq) (void)hipFree(m->d_wq);
-            m->d_wq = nullptr;
-            m->d_wq_bytes = 0;
-            MK_HIP(hipMalloc((void **)&m->d_wq, need));
-            m->d_wq_bytes = need;
-        }
-        if (!m->d_wq_count) MK_HIP(hipMalloc((void **)&m->d_wq_count, 65536 * sizeof(uint32_t)));
+    // q-gram-hit rings: 128 entries per scan wave (allocated once for the largest grid)
+    if (!m->d_wq) {
+        const size_t need = (size_t)m->num_cus * waves_per_block * 128 * sizeof(HitCand);
+        MK_HIP(hipMalloc((void **)&m->d_wq, need));
+        m->d_wq_bytes = need;
     }
     p.wq = m->d_wq;
-    p.wq_count = m->d_wq_count;
-    p.wq_cap = (uint32_t)cap;
     p.rec_per_byte = (double)n_rec / (double)n_bytes;
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
@@ -313,7 +302,6 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));
         m->timed_launches++;
     }
-    launch_resolve(p, mode == MK_MODE_HITS, (int)n_queues, st);
     m->kernel_name = name;
     m->last_grid = (int)blocks;
     MK_HIP(hipGetLastError());

@@ -38,7 +38,6 @@ struct mk_matcher {
     // q-gram-hit queues between the scan and resolve kernels
     mk::HitCand *d_wq = nullptr;
     size_t d_wq_bytes = 0;
-    uint32_t *d_wq_count = nullptr;
     const char *kernel_name = "";
     int last_grid = 0;
     // optional per-launch kernel timing (hipEvents recorded on the launch stream, tightly

@@ -35,11 +35,8 @@ struct ScanParams {
     uint32_t key_mask_hi;
     uint32_t case_insensitive;
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
-    // per-scan-wave queues of q-gram hits (global memory), filled by the scan kernel and
-    // consumed by the resolve kernel
-    HitCand *wq;         // n_scan_waves * wq_cap entries
-    uint32_t *wq_count;  // n_scan_waves
-    uint32_t wq_cap;
+    // per-scan-wave rings of q-gram hits awaiting resolve_one (global memory, 128 entries each)
+    HitCand *wq;
     // outputs
     uint32_t *rec_flags32;  // rec_flags viewed as 32-bit words (byte r = record r)
     mk_hit *hits;           // may be null when !EMIT
@@ -51,8 +48,6 @@ struct ScanParams {
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream);
-// n_queues = grid_blocks * (kBlockThreads / 64) of the preceding launch_scan
-void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t stream);
 
 void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
                   const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream);

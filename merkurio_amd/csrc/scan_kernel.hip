@@ -64,7 +64,8 @@ static_assert(kLdsBytes == 160 * 1024, "one workgroup owns the whole LDS of its 
 // check, then flag / hit tuple / counters.  Used by the resolve kernel (one lane per q-gram
 // hit) and, as overflow fallback, inline by the scan kernel.
 template <bool EMIT>
-__device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true) {
+__device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
+                                            uint32_t &n_first) {
     const uint32_t a = P.pat_off[pat];
     const uint32_t len = P.pat_off[pat + 1] - a;
     if (p + len > P.n_bytes) return;
@@ -134,10 +135,11 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     }
     const uint64_t rstart = P.rec_off[lo];
     if (p + len > P.rec_off[lo + 1]) return;  // occurrence would cross a record boundary
-    // ---- a true occurrence.  The flag is a plain byte store (idempotent, no atomic); the
-    // number of flagged records is counted afterwards by mk_count_flags_kernel.
-    reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
+    // ---- a true occurrence
+    const uint32_t fsh = (uint32_t)(lo & 3) * 8;
+    const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << fsh);
     n_true++;
+    if (((old >> fsh) & 0xFFu) == 0) n_first++;
     if (P.counters) atomicAdd(&P.counters[pat], 1ull);
     if (EMIT) {
         const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
@@ -151,13 +153,37 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     }
 }
 
-// ---- level 2: up to 64 filter positives (one per lane) against the exact q-gram table -----
-// Wave-uniform loop over the probe sequence; key matches are compacted (ballot/popcount)
-// into this wave's private queue in global memory for the resolve kernel.  wq_n is the
-// wave-uniform fill count of that queue.
+// ---- per-wave ring of q-gram hits (global memory, L2-resident: 128 x 16 B per wave) --------
+// True q-gram hits are rare; resolving them the moment they are found would run the ~5
+// dependent memory round trips of resolve_one with one or two active lanes.  They are
+// queued instead and resolved 64 at a time (one per lane).
+constexpr uint32_t kHitRing = 128;
+struct HitRing {
+    HitCand *q;      // this wave's ring
+    uint32_t head;   // wave-uniform
+    uint32_t count;  // wave-uniform
+};
+
 template <bool EMIT>
-__device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t,
-                                                 HitCand *__restrict__ wq, uint32_t &wq_n, uint32_t &n_true) {
+__device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint32_t n, uint32_t lane, uint32_t &n_true,
+                                           uint32_t &n_first) {
+    // entries were stored by other lanes of this wave: same CU, same L1; order the accesses
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < n) {
+        const HitCand h = hr.q[(hr.head + lane) & (kHitRing - 1)];
+        resolve_one<EMIT>(P, h.pat, h.p, n_true, n_first);
+    }
+    hr.head = (hr.head + n) & (kHitRing - 1);
+    hr.count -= n;
+}
+
+// ---- level 2: up to 64 filter positives (one per lane) against the exact q-gram table -----
+// Wave-uniform loop over the bucket chain; fingerprint matches are compacted (ballot /
+// popcount) into the wave's hit ring.
+template <bool EMIT>
+__device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t, uint32_t lane,
+                                                 HitRing &hr, uint32_t &n_true, uint32_t &n_first) {
     uint32_t b = table_hash(key) & P.table_mask;
     const uint32_t fp = key_fingerprint(key);
     uint64_t live = __ballot(active);
@@ -176,20 +202,17 @@ __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool activ
             const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
             const uint64_t mm = __ballot(match);
             if (mm) {  // uniform, rare
-                const uint32_t idx = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
                 if (match) {
-                    if (idx < P.wq_cap) {
-                        HitCand h;
-                        h.p = t - e_off;
-                        h.pat = e_pat;
-                        h.pad = 0;
-                        wq[idx] = h;
-                    } else {
-                        resolve_one<EMIT>(P, e_pat, t - e_off, n_true);  // queue full: resolve in place
-                    }
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                    HitCand h;
+                    h.p = t - e_off;
+                    h.pat = e_pat;
+                    h.pad = 0;
+                    hr.q[(hr.head + hr.count + below) & (kHitRing - 1)] = h;
                 }
-                wq_n += (uint32_t)__popcll(mm);
+                hr.count += (uint32_t)__popcll(mm);  // < 64 before, <= 127 now
+                if (hr.count >= 64) drain_hits<EMIT>(P, hr, 64, lane, n_true, n_first);
             }
         }
         active = active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
@@ -284,9 +307,11 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     const uint64_t n_bytes = P.n_bytes;
     CandEntry *ring = reinterpret_cast<CandEntry *>(bloom + kBloomWords) + wave_in_block * kRingEntries;
     uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
-    HitCand *__restrict__ wq = P.wq + wave_id * (uint64_t)P.wq_cap;  // this wave's q-gram-hit queue
-    uint32_t wq_n = 0;                                               // wave-uniform
-    uint32_t n_true = 0;  // per lane: occurrences resolved in place (queue overflow only)
+    HitRing hr;  // this wave's q-gram-hit ring
+    hr.q = P.wq + wave_id * (uint64_t)kHitRing;
+    hr.head = 0;
+    hr.count = 0;
+    uint32_t n_true = 0, n_first = 0;  // per lane: occurrences found / records newly flagged
 
     // ---- scan of one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
     // packed chunk that follows in the text (halo source for lanes 62/63)
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-                probe_candidates<EMIT>(P, true, e.key, e.t, wq, wq_n, n_true);
+                probe_candidates<EMIT>(P, true, e.key, e.t, lane, hr, n_true, n_first);
                 __builtin_amdgcn_wave_barrier();
                 q_head = (q_head + 64) & (kRingEntries - 1);
                 q_count -= 64;
@@ -419,63 +444,19 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         }
     }
 
-    // drain what is left in this wave's ring
+    // drain what is left in this wave's rings
     if (q_count) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-        probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, wq, wq_n, n_true);
+        probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, lane, hr, n_true, n_first);
     }
-    // publish this wave's queue fill for the resolve kernel (plain store: wave-private slot)
-    if (lane == 0) P.wq_count[wave_id] = wq_n < P.wq_cap ? wq_n : P.wq_cap;
-    if (P.counters && lane == 0 && n_cand)
-        atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
-    if (P.counters && n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
-}
-
-// ---- resolve kernel: one block per scan wave's queue, one lane per q-gram hit -----------
-template <bool EMIT>
-__global__ __launch_bounds__(256) void mk_resolve_kernel(const ScanParams P) {
-    const uint32_t n = P.wq_count[blockIdx.x];
-    const HitCand *__restrict__ q = P.wq + (uint64_t)blockIdx.x * P.wq_cap;
-    uint32_t n_true = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const HitCand h = q[i];
-        resolve_one<EMIT>(P, h.pat, h.p, n_true);
-    }
-    if (P.counters) {  // one atomic per wave (uniform address: aggregated by the compiler)
+    if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, n_first);
+    if (P.counters) {
+        if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
+        // uniform addresses: the compiler folds each of these into one atomic per wave
         if (n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
-    }
-}
-
-// number of records with rec_flags != 0 -> counters[n_pat + MK_SUM_RECORDS_HIT]
-__global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint32_t *__restrict__ flags32, uint64_t n_rec,
-                                                             unsigned long long *__restrict__ out) {
-    const uint64_t n16 = n_rec / 16;
-    unsigned long long c = 0;
-    const uint4 *__restrict__ f4 = reinterpret_cast<const uint4 *>(flags32);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 v = f4[i];  // flag bytes are 0 or 1
-        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint8_t *fb = reinterpret_cast<const uint8_t *>(flags32);
-        for (uint64_t r = n16 * 16; r < n_rec; ++r) c += fb[r] != 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
-}
-
-void launch_resolve(const ScanParams &p, bool emit, int n_queues, hipStream_t st) {
-    if (emit)
-        hipLaunchKernelGGL((mk_resolve_kernel<true>), dim3(n_queues), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((mk_resolve_kernel<false>), dim3(n_queues), dim3(256), 0, st, p);
-    if (p.counters) {
-        const uint64_t n16 = p.n_rec / 16;
-        const int blocks = (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, (n16 + 255) / 256));
-        hipLaunchKernelGGL(mk_count_flags_kernel, dim3(blocks), dim3(256), 0, st, p.rec_flags32, p.n_rec,
-                           p.counters + p.n_pat + MK_SUM_RECORDS_HIT);
+        if (n_first) atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS_HIT], (unsigned long long)n_first);
     }
 }
 
