@@ -29,6 +29,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
+def measured_traffic(kernel, n_rec, read_len, n_pat):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this
+    exact workload (profiles/traffic_rNN.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes, gfx950
+    correction applied); None if no such profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+        try:
+            j = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if (j.get("kernel"), j.get("records_per_gpu"), j.get("read_len"), j.get("patterns")) == \
+                (kernel, n_rec, read_len, n_pat):
+            best = (j["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
+    return best
+
+
 def make_patterns(n, k, seed=0x4D65724B):
     rng = np.random.default_rng(seed)
     codes = rng.integers(0, 4, size=(int(n * 1.01) + 8, k), dtype=np.uint8)
@@ -53,6 +70,7 @@ def main():
     import torch
     import torch.distributed as dist
     from merkurio_amd import native as mk
+    from merkurio_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,8 +126,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:  # the job's only collective: hit-count / summary vector (RCCL over xGMI)
-        dist.all_reduce(d_cnt)
+    sharding.all_reduce_counters(d_cnt)  # the job's only collective: hit-count / summary vector (RCCL over xGMI)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -153,6 +170,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
+                "traffic_source": None,
                 "kernel_ms_avg": round(k_avg_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -161,6 +179,9 @@ def main():
                         "records": int(summ[mk.MK_SUM_RECORDS]), "bases": int(summ[mk.MK_SUM_BASES]),
                         "filter_candidates": int(summ[mk.MK_SUM_CANDIDATES])},
         }
+        tr = measured_traffic(m.kernel_name, n_rec, L, len(patterns))
+        if tr:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, d_flags,
                                                args.cpu_seconds)

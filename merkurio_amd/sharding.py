@@ -1,0 +1,64 @@
+"""Record sharding across the GPUs of one node and the merge / reduction of per-shard results.
+
+The path shards embarrassingly: records — or mate pairs, which are never split
+(src/cmd_extract.rs:463-468,600-606) — are independent and the pattern set is replicated.  One
+process per GPU; rank r owns the contiguous unit range shard_bounds(n, world)[r], so that
+concatenating per-rank outputs in rank order reproduces the single-device output order.  The
+only collective on the path is the sum of the counter vector at the end of a job
+(`all_reduce_counters`: RCCL over xGMI with backend "nccl", gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def shard_bounds(n_units, world_size):
+    """contiguous [lo, hi) ranges, sizes differing by at most one, in rank order"""
+    base, rem = divmod(int(n_units), int(world_size))
+    bounds, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < rem else 0)
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
+
+
+def counters_layout(n_pat):
+    """index map of the u64 counter vector of mk_scan_device (include/merkurio_hip.h)"""
+    from . import native as mk
+    return {"pattern_hit_counts": slice(0, n_pat), "hits": n_pat + mk.MK_SUM_HITS,
+            "records_hit": n_pat + mk.MK_SUM_RECORDS_HIT, "records": n_pat + mk.MK_SUM_RECORDS,
+            "bases": n_pat + mk.MK_SUM_BASES, "candidates": n_pat + mk.MK_SUM_CANDIDATES}
+
+
+def all_reduce_counters(t):
+    """in-place sum of the int64 counter tensor over all ranks (no-op without a process group)"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def merge_shards(shard_results, bounds):
+    """shard_results[r] = (flags: bool/uint8 array over the shard's records, hits: structured
+    array with shard-local `rec`) in rank order -> (flags, hits) of the whole batch, hits with
+    global record indices, still in emission order (records ascend across shards)."""
+    flags = np.concatenate([np.asarray(f, dtype=np.uint8) for f, _ in shard_results]) if shard_results else np.zeros(0, np.uint8)
+    parts = []
+    for (f, h), (lo, hi) in zip(shard_results, bounds):
+        assert len(f) == hi - lo
+        h = h.copy()
+        h["rec"] += lo
+        parts.append(h)
+    hits = np.concatenate(parts) if parts else None
+    return flags, hits
+
+
+def gather_to_rank0(flags, hits, bounds):
+    """collects every rank's (flags, hits) on rank 0 in rank order (object gather: results are
+    sparse and small next to the scan); returns merge_shards(...) on rank 0, None elsewhere"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return merge_shards([(flags, hits)], bounds)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out = [None] * world if rank == 0 else None
+    dist.gather_object((np.asarray(flags), np.asarray(hits)), out, dst=0)
+    return merge_shards(out, bounds) if rank == 0 else None
