@@ -25,6 +25,8 @@
 
 namespace mk {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // 16 ASCII bytes -> 32 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3.
 // Per dword: x = d & 0x06060606 holds the four codes at bits 1,9,17,25; x * (2^23+2^17+2^11+2^5)
 // lines them up in the TOP BYTE of the product (bits 24..31; the other partial products fall
@@ -394,7 +396,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         const uint64_t last_tile = n_main_tiles - 1;
         const uint8_t *ld_ptr = seq + wave_id * kTileBytes + lane * 16;
         auto load_next = [&]() -> uint4 {
-            const uint4 v = *reinterpret_cast<const uint4 *>(ld_ptr);
+            // non-temporal: the text is read once; keep L2 for the exact table and the filter image
+            const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ld_ptr));
+            const uint4 v = make_uint4(nv.x, nv.y, nv.z, nv.w);
             ld_ptr += kChunkBytes;
             if (++ld_c == (uint32_t)kTileChunks + 1) {  // next tile of this wave
                 ld_c = 0;
