@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--patterns", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--plant-every", type=int, default=100, help="1 in N reads carries a planted k-mer")
+    ap.add_argument("--rc", action="store_true", help="add reverse complements to the pattern list (-r)")
+    ap.add_argument("--mode", choices=["any", "hits"], default="any",
+                    help="any = per-record flags (extract without logging, the headline); hits = also emit every "
+                         "(record, pattern, position) tuple (extract/tag with logging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -87,6 +91,8 @@ def main():
     raw = make_patterns(args.patterns, args.k)
     patterns = mk.parse_pattern_list(kmer_seq=raw)[:args.patterns]
     assert len(patterns) == args.patterns
+    if args.rc:
+        patterns = mk.parse_pattern_list(kmer_seq=patterns, reverse_complement=True)
     m = mk.Matcher(patterns, device=local_rank)
     assert m.use_ac == mk.recommend_aho_corasick(patterns)
     lib = mk.load()
@@ -106,9 +112,14 @@ def main():
     assert rc == 0, lib.mk_last_error()
     torch.cuda.synchronize()
 
+    emit = args.mode == "hits"
+    hits_cap = max(1 << 20, 4 * n_rec // max(1, args.plant_every)) if emit else 0
+    d_hits = torch.empty(2 * hits_cap, dtype=torch.int64, device=dev) if emit else None
+
     def step():
-        rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec, mk.MK_MODE_ANY,
-                                d_flags.data_ptr(), None, 0, d_nh.data_ptr(), d_cnt.data_ptr(), st)
+        rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec,
+                                mk.MK_MODE_HITS if emit else mk.MK_MODE_ANY, d_flags.data_ptr(),
+                                d_hits.data_ptr() if emit else None, hits_cap, d_nh.data_ptr(), d_cnt.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(lib.mk_last_error().decode())
 
@@ -158,7 +169,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"extract (any-hit flags): {n_rec} x {L} bp synthetic reads per GPU, "
+                "workload": f"extract ({'all hit tuples' if emit else 'any-hit flags'}): {n_rec} x {L} bp synthetic reads per GPU, "
                             f"{len(patterns)} {args.k}-mers, Aho-Corasick semantics, 1/{args.plant_every} reads planted",
                 "records_per_gpu": n_rec, "read_len": L, "patterns": len(patterns), "k": args.k,
                 "sharding": f"records x{world}", "kernel": m.kernel_name, "filter": info,

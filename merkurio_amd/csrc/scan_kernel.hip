@@ -142,7 +142,23 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << fsh);
     n_true++;
     if (((old >> fsh) & 0xFFu) == 0) n_first++;
-    if (P.counters) atomicAdd(&P.counters[pat], 1ull);
+    if (P.counters) {
+        if (P.n_pat <= 32) {
+            // few patterns: a million hits on a handful of addresses would serialise in the
+            // atomic unit.  Aggregate per wave: one atomic per distinct pattern among the
+            // lanes that are here (ballot of the active lanes, loop over distinct values).
+            uint64_t todo = __ballot(1);
+            while (todo) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                const uint32_t p0 = (uint32_t)__shfl((int)pat, (int)leader);
+                const uint64_t same = __ballot(pat == p0) & todo;
+                if ((threadIdx.x & 63u) == leader) atomicAdd(&P.counters[p0], (unsigned long long)__popcll(same));
+                todo &= ~same;
+            }
+        } else {
+            atomicAdd(&P.counters[pat], 1ull);
+        }
+    }
     if (EMIT) {
         const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
         if (idx < P.hits_cap) {
