@@ -154,7 +154,7 @@ def main():
         k_avg_ms = float(np.mean(kernel_ms))
         algo_bytes = n_bytes * 1 + n_rec * 9  # 1 B/base + u64 offset + 1 B flag per record
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
-        info = m.filter_info()
+        info = dict(m.filter_info(), **m.filter_mode())
         out = {
             "metric": "Gbases/s scanned (150bp FASTQ, 10k 31-mers); % HBM roofline at 1/2/4/8 GPUs",
             "value": round(value, 3),

@@ -141,6 +141,9 @@ uint32_t mk_matcher_num_patterns(const mk_matcher *m);
 /* filter geometry chosen at create time: q-gram length, sampling stride, table entries */
 int mk_matcher_filter_info(const mk_matcher *m, uint32_t *q_gram, uint32_t *stride, uint64_t *entries,
                            uint64_t *table_bytes);
+/* where the level-1 filter lives: *in_lds = 1 (128 KiB image staged in LDS by every workgroup)
+ * or 0 (large pattern sets: blocks in global memory, L2 / Infinity-Cache resident), and its size */
+int mk_matcher_filter_mode(const mk_matcher *m, uint32_t *in_lds, uint64_t *filter_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Batched scan, host buffers

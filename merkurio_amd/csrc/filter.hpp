@@ -71,6 +71,14 @@ MK_HD uint32_t bloom_bit_a(uint32_t h) { return h >> 27; }
 MK_HD uint32_t bloom_bit_b(uint32_t h) { return (h >> 22) & 31u; }
 MK_HD uint32_t bloom_bit_c(uint32_t h) { return (h >> 17) & 31u; }
 
+// Global-memory variant of the filter for pattern sets too large for a useful 128 KiB LDS
+// image (more than ~96 k filter entries even at stride 1): the same 3-bit / 64-bit blocks,
+// but 2^g_log2 of them in HBM (resident in L2 / Infinity Cache), sized ~32 bits per entry.
+// Block index = high bits of h, bit positions from a second multiply so that they do not
+// correlate with the block index.
+MK_HD uint32_t gbloom_block(uint32_t h, uint32_t block_mask) { return (h >> 5) & block_mask; }
+MK_HD uint32_t gbloom_bits(uint32_t h) { return h * 0x9E3779B1u; }  // a,b,c = top three 5-bit groups
+
 // hash for the exact table
 MK_HD uint32_t table_hash(uint64_t key) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;

@@ -43,23 +43,50 @@ int fail(int code, const char *fmt, ...) {
 // 31-mers (profiles/r01_stride_sweep.txt): S=8 (80 k entries, 0.2 % of bases become
 // candidates) beats S=4 by 14 % and S=16 by 60 %.  Rule: largest S with <= 96 k entries and
 // q >= 14.
-static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t *S) {
+static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t *S, uint32_t *gblocks) {
     const char *force = getenv("MERKURIO_FORCE_STRIDE");  // tuning / test hook
-    int forced = force ? atoi(force) : 0;
-    for (uint32_t s : {16u, 8u, 4u, 2u, 1u}) {
-        if (s > lmin) continue;
-        uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
-        if (forced) {
-            if ((int)s != forced) continue;
-        } else if (s > 1 && (qq < 14 || n_pat * s > 98304)) {
-            continue;
+    const int forced = force ? atoi(force) : 0;
+    const char *fg = getenv("MERKURIO_FORCE_GLOBAL_FILTER");  // test hook
+    const bool force_global = fg && atoi(fg) != 0;
+    *gblocks = 0;
+    constexpr uint64_t kMaxLdsEntries = 98304;
+    if (n_pat <= kMaxLdsEntries && !force_global) {  // LDS filter
+        for (uint32_t s : {16u, 8u, 4u, 2u, 1u}) {
+            if (s > lmin) continue;
+            uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
+            if (forced) {
+                if ((int)s != forced) continue;
+            } else if (s > 1 && (qq < 14 || n_pat * s > kMaxLdsEntries)) {
+                continue;
+            }
+            *q = qq;
+            *S = s;
+            return;
         }
-        *q = qq;
-        *S = s;
+        *q = std::min<uint32_t>(32, lmin);
+        *S = 1;
         return;
     }
+    // Large set: the filter moves to global memory (L2 / Infinity Cache resident), where
+    // every sample costs a random 8-byte read -> take the largest stride that keeps the
+    // q-grams selective (q >= 16) and the filter at most 256 MiB.
     *q = std::min<uint32_t>(32, lmin);
     *S = 1;
+    for (uint32_t s : {16u, 8u, 4u, 2u}) {
+        if (s > lmin) continue;
+        const uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
+        if (forced ? (int)s != forced : (qq < 16 || n_pat * s * 4 > (1ull << 25))) continue;
+        *q = qq;
+        *S = s;
+        break;
+    }
+    // Filter size: measured with 500 k 21-mers (2 M entries, profiles/r01_gbloom_sweep.txt) a
+    // 2 MiB image (8 entries per 64-bit block, 1.2 % of samples pass) is fastest because it
+    // stays resident in the 4 MiB XCD L2; 8 MiB (0.09 % pass) is 1.8x slower.  ~8 entries/block.
+    uint64_t blocks = 1ull << 17;  // >= 1 MiB
+    while (blocks < n_pat * *S / 8 && blocks < (1ull << 25)) blocks <<= 1;
+    if (const char *e = getenv("MERKURIO_GBLOOM_LOG2_BLOCKS")) blocks = 1ull << atoi(e);  // tuning hook
+    *gblocks = (uint32_t)blocks;
 }
 
 uint64_t pack_qgram(const uint8_t *p, uint32_t q) {
@@ -153,7 +180,7 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         m->num_cus = prop.multiProcessorCount;
 
     // ---- compile the pattern set: Bloom filter + exact table
-    choose_geometry(lmin, n_pat, &m->q, &m->S);
+    choose_geometry(lmin, n_pat, &m->q, &m->S, &m->gbloom_blocks);
     const uint32_t q_f = m->q, S = m->S;
     m->entries = (uint64_t)n_pat * S;
     uint64_t slots = 64;
@@ -164,7 +191,8 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", ne);
     }
     m->table_slots = (uint32_t)slots;
-    std::vector<uint32_t> bloom(kBloomWords, 0);
+    const uint32_t gmask = m->gbloom_blocks ? m->gbloom_blocks - 1 : 0;
+    std::vector<uint32_t> bloom(m->gbloom_blocks ? (size_t)m->gbloom_blocks * 2 : (size_t)kBloomWords, 0);
     std::vector<TableEntry> table(slots);
     for (auto &e : table) {
         e.fp = 0;
@@ -176,9 +204,16 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         for (uint32_t o = 0; o < S; ++o) {
             const uint64_t key = pack_qgram(p + o, q_f);
             const uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
-            const uint32_t blk = bloom_block_byte(h) >> 2;  // index of the block's low word
-            bloom[blk] |= 1u << bloom_bit_a(h);
-            bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
+            if (m->gbloom_blocks) {
+                const size_t blk = (size_t)gbloom_block(h, gmask) * 2;
+                const uint32_t hb = gbloom_bits(h);
+                bloom[blk] |= 1u << bloom_bit_a(hb);
+                bloom[blk + 1] |= (1u << bloom_bit_b(hb)) | (1u << bloom_bit_c(hb));
+            } else {
+                const uint32_t blk = bloom_block_byte(h) >> 2;  // index of the block's low word
+                bloom[blk] |= 1u << bloom_bit_a(h);
+                bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
+            }
             uint32_t b = table_hash(key) & bmask;
             for (;;) {  // first bucket from the home bucket on with a free entry
                 TableEntry *e = &table[(size_t)b * kBucketEntries];
@@ -203,12 +238,12 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         if (e_ != hipSuccess) return bail(fail(MK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); \
     } while (0)
     MK_HIP_M(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    MK_HIP_M(hipMalloc((void **)&m->d_bloom, kBloomBytes));
+    MK_HIP_M(hipMalloc((void **)&m->d_bloom, bloom.size() * sizeof(uint32_t)));
     MK_HIP_M(hipMalloc((void **)&m->d_table, slots * sizeof(TableEntry)));
     MK_HIP_M(hipMalloc((void **)&m->d_pat_bytes, m->pat_bytes.size() + 16));
     MK_HIP_M(hipMalloc((void **)&m->d_pat_off, (n_pat + 1) * sizeof(uint32_t)));
     MK_HIP_M(hipMalloc((void **)&m->d_nhits, sizeof(unsigned long long)));
-    MK_HIP_M(hipMemcpy(m->d_bloom, bloom.data(), kBloomBytes, hipMemcpyHostToDevice));
+    MK_HIP_M(hipMemcpy(m->d_bloom, bloom.data(), bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     MK_HIP_M(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
     MK_HIP_M(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
     MK_HIP_M(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -244,6 +279,13 @@ int mk_matcher_filter_info(const mk_matcher *m, uint32_t *q_gram, uint32_t *stri
     return MK_OK;
 }
 
+int mk_matcher_filter_mode(const mk_matcher *m, uint32_t *in_lds, uint64_t *filter_bytes) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (in_lds) *in_lds = m->gbloom_blocks ? 0 : 1;
+    if (filter_bytes) *filter_bytes = m->gbloom_blocks ? (uint64_t)m->gbloom_blocks * 8 : (uint64_t)kBloomBytes;
+    return MK_OK;
+}
+
 int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const void *d_seq_off, uint64_t n_rec,
                    uint32_t mode, void *d_rec_flags, void *d_hits, uint64_t hits_cap, void *d_n_hits,
                    void *d_counters, void *stream) {
@@ -267,6 +309,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t tile_bytes = (uint64_t)kTileChunks * kChunkBytes;
     p.n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
     p.bloom = m->d_bloom;
+    p.gbloom_mask = m->gbloom_blocks ? m->gbloom_blocks - 1 : 0;
     p.table = m->d_table;
     p.table_mask = m->table_slots / kBucketEntries - 1;  // bucket mask
     p.pat_bytes = m->d_pat_bytes;
@@ -296,7 +339,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
     if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
-    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, (int)blocks, st);
+    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, (int)blocks, st);
     if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);
     if (slots) {
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));

@@ -21,6 +21,7 @@ struct mk_matcher {
     uint64_t entries = 0;
     uint32_t table_slots = 0;
     uint32_t *d_bloom = nullptr;
+    uint32_t gbloom_blocks = 0;  // > 0: filter lives in global memory (large pattern sets)
     mk::TableEntry *d_table = nullptr;
     uint8_t *d_pat_bytes = nullptr;
     uint32_t *d_pat_off = nullptr;

@@ -24,7 +24,8 @@ struct ScanParams {
     uint64_t n_rec;
     uint64_t n_tiles;  // ceil(n_bytes / (kTileChunks * kChunkBytes))
     // compiled pattern set
-    const uint32_t *bloom;    // kBloomWords
+    const uint32_t *bloom;    // LDS mode: kBloomWords words; global mode: 2 * (gbloom_mask + 1) words
+    uint32_t gbloom_mask;     // global mode: 64-bit-block index mask (0 = LDS mode)
     const TableEntry *table;  // (table_mask + 1) buckets of kBucketEntries entries
     uint32_t table_mask;      // bucket index mask
     const uint8_t *pat_bytes;
@@ -47,7 +48,8 @@ struct ScanParams {
 
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
-const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream);
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
+                        hipStream_t stream);
 
 void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
                   const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream);

@@ -299,16 +299,18 @@ __device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32
 }
 
 // ---- main kernel -----------------------------------------------------------------------
-template <int S, int QC, bool EMIT>
+template <int S, int QC, bool EMIT, bool GF>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
     using G = Geo<S, QC>;
     __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
-    {
+    if constexpr (!GF) {  // stage the filter image of the pattern set in LDS
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
         for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
+    const uint2 *__restrict__ gbloom = reinterpret_cast<const uint2 *>(P.bloom);  // GF: filter blocks in global memory
+    const uint32_t gmask = P.gbloom_mask;
 
     if (P.counters && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS], (unsigned long long)P.n_rec);
@@ -355,12 +357,16 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         const char *bloom_bytes = reinterpret_cast<const char *>(bloom);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const uint32_t h = sample_hash<S, QC>(w0, w1, w2, 2 * j * S, mask_lo, mask_hi);
+            uint32_t h = sample_hash<S, QC>(w0, w1, w2, 2 * j * S, mask_lo, mask_hi);
             uint2 blk;
-            if constexpr ((MK_ABLATE & 2) != 0)
+            if constexpr ((MK_ABLATE & 2) != 0) {
                 blk = make_uint2(h & 0x10101010u, h);
-            else
+            } else if constexpr (GF) {
+                blk = gbloom[gbloom_block(h, gmask)];  // random 8-byte read, L2 / Infinity Cache
+                h = gbloom_bits(h);
+            } else {
                 blk = *reinterpret_cast<const uint2 *>(bloom_bytes + bloom_block_byte(h));  // ds_read_b64
+            }
             // all three filter bits set?  (shift counts use the low 5 bits of their register)
             const uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
             cand |= (m & 1u) << j;
@@ -480,38 +486,59 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     }
 }
 
-template <int S, int QC, bool EMIT>
+template <int S, int QC, bool EMIT, bool GF>
 static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
-    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT>), dim3(grid), dim3(kBlockThreads), 0, st, p);
+    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT, GF>), dim3(grid), dim3(kBlockThreads), 0, st, p);
     return name;
 }
 
-#define MK_VARIANT(S_, QC_)                                                                            \
-    return emit ? launch_one<S_, QC_, true>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true>") \
-                : launch_one<S_, QC_, false>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false>")
+#define MK_VARIANT(S_, QC_, GF_)                                                                                   \
+    return emit ? launch_one<S_, QC_, true, GF_>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true," #GF_ ">") \
+                : launch_one<S_, QC_, false, GF_>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false," #GF_ ">")
 
-const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, int grid_blocks, hipStream_t stream) {
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
+                        hipStream_t stream) {
+    if (global_filter) {  // large pattern sets: filter blocks in global memory
+        if (S == 4 && p.q == 18) MK_VARIANT(4, 18, true);  // 21-mers
+        if (S == 8 && p.q == 24) MK_VARIANT(8, 24, true);  // 31-mers
+        if (wide) switch (S) {
+                case 1: MK_VARIANT(1, -1, true);
+                case 2: MK_VARIANT(2, -1, true);
+                case 4: MK_VARIANT(4, -1, true);
+                case 8: MK_VARIANT(8, -1, true);
+                case 16: MK_VARIANT(16, -1, true);
+                default: return nullptr;
+            }
+        switch (S) {
+            case 1: MK_VARIANT(1, 0, true);
+            case 2: MK_VARIANT(2, 0, true);
+            case 4: MK_VARIANT(4, 0, true);
+            case 8: MK_VARIANT(8, 0, true);
+            case 16: MK_VARIANT(16, 0, true);
+            default: return nullptr;
+        }
+    }
     // k-mer sizes with their own kernels (q fixed at compile time): the 31-mer family
     // (q = 32 - S) and the 21-mer family (q = 22 - S, S <= 4)
-    if (S == 16 && p.q == 16) MK_VARIANT(16, 16);
-    if (S == 8 && p.q == 24) MK_VARIANT(8, 24);
-    if (S == 4 && p.q == 28) MK_VARIANT(4, 28);
-    if (S == 4 && p.q == 18) MK_VARIANT(4, 18);
+    if (S == 16 && p.q == 16) MK_VARIANT(16, 16, false);
+    if (S == 8 && p.q == 24) MK_VARIANT(8, 24, false);
+    if (S == 4 && p.q == 28) MK_VARIANT(4, 28, false);
+    if (S == 4 && p.q == 18) MK_VARIANT(4, 18, false);
     // everything else: runtime q, narrow (q <= 16) or wide keys
     if (wide) switch (S) {
-            case 1: MK_VARIANT(1, -1);
-            case 2: MK_VARIANT(2, -1);
-            case 4: MK_VARIANT(4, -1);
-            case 8: MK_VARIANT(8, -1);
-            case 16: MK_VARIANT(16, -1);
+            case 1: MK_VARIANT(1, -1, false);
+            case 2: MK_VARIANT(2, -1, false);
+            case 4: MK_VARIANT(4, -1, false);
+            case 8: MK_VARIANT(8, -1, false);
+            case 16: MK_VARIANT(16, -1, false);
             default: return nullptr;
         }
     switch (S) {
-        case 1: MK_VARIANT(1, 0);
-        case 2: MK_VARIANT(2, 0);
-        case 4: MK_VARIANT(4, 0);
-        case 8: MK_VARIANT(8, 0);
-        case 16: MK_VARIANT(16, 0);
+        case 1: MK_VARIANT(1, 0, false);
+        case 2: MK_VARIANT(2, 0, false);
+        case 4: MK_VARIANT(4, 0, false);
+        case 8: MK_VARIANT(8, 0, false);
+        case 16: MK_VARIANT(16, 0, false);
         default: return nullptr;
     }
 }

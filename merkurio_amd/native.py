@@ -44,7 +44,7 @@ EXPORTS = [
     "mk_abi_version", "mk_last_error", "mk_device_count", "mk_read_kmers_from_text", "mk_parse_pattern_list",
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
     "mk_free", "mk_matcher_create", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
-    "mk_matcher_filter_info", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
+    "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
     "mk_synth_reads_host",
@@ -141,6 +141,7 @@ def load(build_if_missing=True):
     L.mk_matcher_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mk_matcher_filter_mode.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.mk_extract_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -330,6 +331,11 @@ class Matcher:
         q, s, e, tb = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
         _check(load().mk_matcher_filter_info(self._h, C.byref(q), C.byref(s), C.byref(e), C.byref(tb)))
         return {"q_gram": q.value, "stride": s.value, "entries": e.value, "table_bytes": tb.value}
+
+    def filter_mode(self):
+        lds, fb = C.c_uint32(), C.c_uint64()
+        _check(load().mk_matcher_filter_mode(self._h, C.byref(lds), C.byref(fb)))
+        return {"in_lds": bool(lds.value), "filter_bytes": fb.value}
 
     # ---- batched scan, host buffers
     def scan(self, seqs, mode=MK_MODE_HITS, hits_cap=None):

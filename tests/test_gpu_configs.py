@@ -87,9 +87,25 @@ def test_config5_large_pattern_set(mk):
     patterns = mk.parse_pattern_list(kmer_seq=_kmers(500_000, 21, 5))
     recs = _reads(20_000, 250, 51, plant=patterns, every=10)
     m = mk.Matcher(patterns)
-    assert m.use_ac
+    assert m.use_ac and m.filter_mode()["in_lds"] is False and m.filter_info()["stride"] == 4
     om = ob.Matcher(patterns, True, 0, False)
     assert m.extract_single(recs, logging=True) == ob.extract_single(om, recs, logging=True)
+
+
+@pytest.mark.parametrize("stride", [1, 2, 4, 8, 16])
+def test_global_filter_variants(mk, stride, monkeypatch):
+    """every kernel variant of the global-memory filter mode (forced on a small set)"""
+    monkeypatch.setenv("MERKURIO_FORCE_GLOBAL_FILTER", "1")
+    monkeypatch.setenv("MERKURIO_FORCE_STRIDE", str(stride))
+    for k, n in ((31, 3000), (21, 2000), (16 + stride - 1, 500)):
+        if stride > k:
+            continue
+        patterns = mk.parse_pattern_list(kmer_seq=_kmers(n, k, 60 + stride))
+        recs = _reads(4000, 150, 70 + stride, plant=patterns, every=7)
+        m = mk.Matcher(patterns)
+        assert m.filter_mode()["in_lds"] is False and m.filter_info()["stride"] == stride
+        om = ob.Matcher(patterns, True, 0, False)
+        assert m.extract_single(recs, logging=True) == ob.extract_single(om, recs, logging=True)
 
 
 def test_headline_full_size_properties(mk):
