@@ -1,0 +1,48 @@
+// commands.hpp -- argument structs of the two subcommands (clap structs of
+// src/cmd_extract.rs:32-141 and src/cmd_tag.rs:29-150) and their drivers.
+#pragma once
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "util.hpp"
+
+namespace cli {
+
+struct CommonArgs {
+    std::vector<std::string> kmer_seq;     // -s
+    std::optional<std::string> kmer_file;  // -f
+    bool reverse_complement = false;       // -r
+    bool canonical = false;                // -c
+    std::optional<std::string> out_log;    // -l [path]   ("STDOUT" when given without a value)
+    std::optional<std::string> json_log;   // -j [path]
+    bool suppress_output = false;          // -S
+    bool invert_match = false;             // -v
+    bool case_insensitive = false;         // -I
+    bool lowercase = false;                // -L
+    bool uppercase = false;                // -U
+    std::optional<size_t> q_size;          // -q
+    bool aho_corasick = false;             // -a
+    // opt-in extras of this build (defaults reproduce the reference behaviour)
+    int device = 0;       // --device
+    int batch_mb = 1024;  // --batch-mb: sequence bytes per GPU batch
+};
+
+struct ExtractArgs : CommonArgs {
+    std::string in_fastx;                   // -i / -1
+    std::optional<std::string> in_fastq_2;  // -2
+    std::optional<std::string> out_fastx;   // -o
+};
+
+struct TagArgs : CommonArgs {
+    std::string in_file;                  // -i
+    std::optional<std::string> out_file;  // -o
+    std::string tag = "km";               // -t
+    int threads = 1;                      // -p
+    bool filter_matching = false;         // -m
+};
+
+int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv);
+int run_tag(const TagArgs &a, const std::vector<std::string> &argv);
+
+}  // namespace cli

@@ -1,0 +1,336 @@
+#include "io.hpp"
+
+#include <zlib.h>
+
+#include <cstring>
+
+namespace cli {
+
+std::vector<char> read_file_maybe_gz(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) bail("No such file or directory: " + path);
+    unsigned char magic[6] = {0};
+    size_t got = fread(magic, 1, sizeof(magic), f);
+    fclose(f);
+    if (got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')
+        bail("bzip2 input is not supported by this build (gzip and plain text are): " + path);
+    if (got >= 6 && magic[0] == 0xFD && !memcmp(magic + 1, "7zXZ", 4))
+        bail("xz input is not supported by this build (gzip and plain text are): " + path);
+    if (got >= 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD)
+        bail("zstd input is not supported by this build (gzip and plain text are): " + path);
+    // gzopen reads plain files transparently and walks concatenated gzip members (BGZF)
+    gzFile g = gzopen(path.c_str(), "rb");
+    if (!g) bail("Cannot open " + path);
+    gzbuffer(g, 1 << 20);
+    std::vector<char> out;
+    size_t cap = 1 << 22;
+    out.resize(cap);
+    size_t n = 0;
+    for (;;) {
+        if (n == cap) {
+            cap *= 2;
+            out.resize(cap);
+        }
+        int r = gzread(g, out.data() + n, (unsigned)std::min<size_t>(cap - n, 1u << 30));
+        if (r < 0) {
+            gzclose(g);
+            bail("Error while decompressing " + path);
+        }
+        if (r == 0) break;
+        n += (size_t)r;
+    }
+    gzclose(g);
+    out.resize(n);
+    return out;
+}
+
+// ---- FASTA / FASTQ ------------------------------------------------------------------------------
+static uint64_t line_end(const std::vector<char> &d, uint64_t b) {  // index of '\n' or size
+    const void *p = memchr(d.data() + b, '\n', d.size() - b);
+    return p ? (uint64_t)((const char *)p - d.data()) : d.size();
+}
+static uint64_t strip_cr(const std::vector<char> &d, uint64_t b, uint64_t e) { return (e > b && d[e - 1] == '\r') ? e - 1 : e; }
+
+void FastxFile::parse(const std::string &path) {
+    data = read_file_maybe_gz(path);
+    recs.clear();
+    uint64_t p = 0;
+    const uint64_t n = data.size();
+    while (p < n && (data[p] == '\n' || data[p] == '\r')) ++p;
+    if (p >= n) return;
+    if (data[p] != '>' && data[p] != '@') bail("Error during FASTQ/A record parsing.");
+    fastq = data[p] == '@';
+    while (p < n) {
+        if (data[p] == '\n' || data[p] == '\r') {  // blank line between records
+            ++p;
+            continue;
+        }
+        Rec r{};
+        if (!fastq) {
+            if (data[p] != '>') bail("Error during FASTQ/A record parsing.");
+            uint64_t e = line_end(data, p);
+            r.id_b = p + 1;
+            r.id_e = strip_cr(data, p + 1, e);
+            uint64_t s = std::min(e + 1, n);
+            r.raw_b = s;
+            uint64_t q = s;  // the sequence runs to the '\n' before the next line that starts with '>'
+            for (;;) {
+                if (q >= n || data[q] == '>') break;
+                q = std::min(line_end(data, q) + 1, n);
+            }
+            uint64_t re = q;
+            while (re > s && (data[re - 1] == '\n' || data[re - 1] == '\r')) --re;  // drop the final line end
+            r.raw_e = re;
+            r.qual_b = r.qual_e = 0;
+            p = q;
+        } else {
+            if (data[p] != '@') bail("Error during FASTQ/A record parsing.");
+            uint64_t e1 = line_end(data, p);
+            if (e1 >= n) bail("Error during FASTQ/A record parsing.");
+            r.id_b = p + 1;
+            r.id_e = strip_cr(data, p + 1, e1);
+            uint64_t e2 = line_end(data, e1 + 1);
+            r.raw_b = e1 + 1;
+            r.raw_e = strip_cr(data, e1 + 1, e2);
+            if (e2 >= n || data[e2 + 1] != '+') bail("Error during FASTQ/A record parsing.");
+            uint64_t e3 = line_end(data, e2 + 1);
+            if (e3 >= n) bail("Error during FASTQ/A record parsing.");
+            uint64_t e4 = line_end(data, e3 + 1);
+            r.qual_b = e3 + 1;
+            r.qual_e = strip_cr(data, e3 + 1, e4);
+            if (r.qual_e - r.qual_b != r.raw_e - r.raw_b) bail("Error during FASTQ/A record parsing.");
+            p = std::min(e4 + 1, n);
+        }
+        recs.push_back(r);
+    }
+}
+
+uint64_t FastxFile::append_seq(size_t i, std::vector<uint8_t> &out) const {
+    const Rec &r = recs[i];
+    const size_t before = out.size();
+    if (fastq) {
+        out.insert(out.end(), data.begin() + r.raw_b, data.begin() + r.raw_e);
+    } else {
+        for (uint64_t k = r.raw_b; k < r.raw_e; ++k)
+            if (data[k] != '\n' && data[k] != '\r') out.push_back((uint8_t)data[k]);
+    }
+    return out.size() - before;
+}
+
+void FastxFile::write(size_t i, Sink &w) const {
+    const Rec &r = recs[i];
+    w.write(fastq ? "@" : ">", 1);
+    w.write(data.data() + r.id_b, r.id_e - r.id_b);
+    w.write("\n", 1);
+    w.write(data.data() + r.raw_b, r.raw_e - r.raw_b);
+    w.write("\n", 1);
+    if (fastq) {
+        w.write("+\n", 2);
+        w.write(data.data() + r.qual_b, r.qual_e - r.qual_b);
+        w.write("\n", 1);
+    }
+}
+
+// ---- SAM / BAM ------------------------------------------------------------------------------------
+static std::string upper_seq(const std::string &s) {
+    if (s == "*") return "";
+    std::string o = s;
+    for (auto &c : o)
+        if (c >= 'a' && c <= 'z') c = (char)(c & ~0x20);
+    return o;
+}
+
+static void parse_sam_text(const std::vector<char> &d, SamFile &out) {
+    uint64_t p = 0;
+    const uint64_t n = d.size();
+    while (p < n) {
+        uint64_t e = line_end(d, p);
+        uint64_t le = strip_cr(d, p, e);
+        if (le > p) {
+            if (d[p] == '@') {
+                out.header.append(d.data() + p, le - p);
+                out.header += '\n';
+            } else {
+                SamFile::Rec r;
+                r.line.assign(d.data() + p, le - p);
+                size_t t1 = r.line.find('\t');
+                if (t1 == std::string::npos) bail("Error during SAM record parsing: too few fields");
+                r.name = r.line.substr(0, t1);
+                size_t b = 0;
+                for (int f = 0; f < 9; ++f) {
+                    b = r.line.find('\t', b);
+                    if (b == std::string::npos) bail("Error during SAM record parsing: too few fields");
+                    ++b;
+                }
+                size_t e10 = r.line.find('\t', b);
+                r.seq = upper_seq(r.line.substr(b, e10 == std::string::npos ? std::string::npos : e10 - b));
+                out.recs.push_back(std::move(r));
+            }
+        }
+        p = e + 1;
+    }
+}
+
+namespace {
+struct Cur {
+    const uint8_t *p, *e;
+    template <class T>
+    T get() {
+        if ((size_t)(e - p) < sizeof(T)) bail("Error during BAM record parsing: truncated file");
+        T v;
+        memcpy(&v, p, sizeof(T));
+        p += sizeof(T);
+        return v;
+    }
+    const uint8_t *take(size_t n) {
+        if ((size_t)(e - p) < n) bail("Error during BAM record parsing: truncated file");
+        const uint8_t *r = p;
+        p += n;
+        return r;
+    }
+};
+}  // namespace
+
+static void aux_to_text(Cur &c, std::string &out) {
+    while (c.p < c.e) {
+        const uint8_t *tag = c.take(2);
+        char type = (char)c.get<uint8_t>();
+        out += '\t';
+        out.append((const char *)tag, 2);
+        char buf[64];
+        switch (type) {
+        case 'A': out += ":A:"; out += (char)c.get<uint8_t>(); break;
+        case 'c': out += ":i:" + std::to_string((int)c.get<int8_t>()); break;
+        case 'C': out += ":i:" + std::to_string((unsigned)c.get<uint8_t>()); break;
+        case 's': out += ":i:" + std::to_string((int)c.get<int16_t>()); break;
+        case 'S': out += ":i:" + std::to_string((unsigned)c.get<uint16_t>()); break;
+        case 'i': out += ":i:" + std::to_string(c.get<int32_t>()); break;
+        case 'I': out += ":i:" + std::to_string(c.get<uint32_t>()); break;
+        case 'f': snprintf(buf, sizeof(buf), "%g", (double)c.get<float>()); out += ":f:"; out += buf; break;
+        case 'Z':
+        case 'H': {
+            out += type == 'Z' ? ":Z:" : ":H:";
+            const uint8_t *s = c.p;
+            while (c.p < c.e && *c.p) ++c.p;
+            out.append((const char *)s, c.p - s);
+            if (c.p < c.e) ++c.p;
+            break;
+        }
+        case 'B': {
+            char sub = (char)c.get<uint8_t>();
+            int32_t cnt = c.get<int32_t>();
+            out += ":B:";
+            out += sub;
+            for (int32_t k = 0; k < cnt; ++k) {
+                out += ',';
+                switch (sub) {
+                case 'c': out += std::to_string((int)c.get<int8_t>()); break;
+                case 'C': out += std::to_string((unsigned)c.get<uint8_t>()); break;
+                case 's': out += std::to_string((int)c.get<int16_t>()); break;
+                case 'S': out += std::to_string((unsigned)c.get<uint16_t>()); break;
+                case 'i': out += std::to_string(c.get<int32_t>()); break;
+                case 'I': out += std::to_string(c.get<uint32_t>()); break;
+                case 'f': snprintf(buf, sizeof(buf), "%g", (double)c.get<float>()); out += buf; break;
+                default: bail("Error during BAM record parsing: bad B array subtype");
+                }
+            }
+            break;
+        }
+        default: bail("Error during BAM record parsing: unknown tag type");
+        }
+    }
+}
+
+static void parse_bam(const std::vector<char> &d, SamFile &out) {
+    Cur c{(const uint8_t *)d.data(), (const uint8_t *)d.data() + d.size()};
+    if (memcmp(c.take(4), "BAM\1", 4) != 0) bail("Error reading BAM file: bad magic");
+    int32_t l_text = c.get<int32_t>();
+    const uint8_t *text = c.take((size_t)l_text);
+    size_t tl = (size_t)l_text;
+    while (tl && text[tl - 1] == 0) --tl;
+    out.header.assign((const char *)text, tl);
+    if (!out.header.empty() && out.header.back() != '\n') out.header += '\n';
+    int32_t n_ref = c.get<int32_t>();
+    std::vector<std::string> refs;
+    for (int32_t i = 0; i < n_ref; ++i) {
+        int32_t l_name = c.get<int32_t>();
+        const uint8_t *nm = c.take((size_t)l_name);
+        refs.emplace_back((const char *)nm, l_name > 0 ? (size_t)l_name - 1 : 0);
+        (void)c.get<int32_t>();
+    }
+    static const char kSeq[] = "=ACMGRSVTWYHKDBN", kCig[] = "MIDNSHP=X";
+    while (c.p < c.e) {
+        int32_t block = c.get<int32_t>();
+        Cur r{c.take((size_t)block), nullptr};
+        r.e = r.p + block;
+        int32_t ref_id = r.get<int32_t>(), pos = r.get<int32_t>();
+        uint8_t l_name = r.get<uint8_t>(), mapq = r.get<uint8_t>();
+        (void)r.get<uint16_t>();
+        uint16_t n_cig = r.get<uint16_t>(), flag = r.get<uint16_t>();
+        int32_t l_seq = r.get<int32_t>(), next_ref = r.get<int32_t>(), next_pos = r.get<int32_t>(), tlen = r.get<int32_t>();
+        const uint8_t *nm = r.take(l_name);
+        SamFile::Rec rec;
+        rec.name.assign((const char *)nm, l_name ? l_name - 1u : 0u);
+        std::string &s = rec.line;
+        s = rec.name;
+        s += '\t' + std::to_string(flag) + '\t';
+        s += ref_id >= 0 && ref_id < n_ref ? refs[ref_id] : "*";
+        s += '\t' + std::to_string(pos + 1) + '\t' + std::to_string(mapq) + '\t';
+        if (n_cig == 0) s += '*';
+        for (uint16_t k = 0; k < n_cig; ++k) {
+            uint32_t v = r.get<uint32_t>();
+            s += std::to_string(v >> 4);
+            s += (v & 15) < 9 ? kCig[v & 15] : '?';
+        }
+        s += '\t';
+        s += next_ref < 0 ? "*" : (next_ref == ref_id ? "=" : (next_ref < n_ref ? refs[next_ref] : "*"));
+        s += '\t' + std::to_string(next_pos + 1) + '\t' + std::to_string(tlen) + '\t';
+        const uint8_t *sq = r.take(((size_t)l_seq + 1) / 2);
+        rec.seq.resize((size_t)l_seq);
+        for (int32_t k = 0; k < l_seq; ++k) rec.seq[k] = kSeq[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
+        s += l_seq ? rec.seq : "*";
+        s += '\t';
+        const uint8_t *ql = r.take((size_t)l_seq);
+        if (l_seq == 0 || ql[0] == 0xFF)
+            s += '*';
+        else
+            for (int32_t k = 0; k < l_seq; ++k) s += (char)(ql[k] + 33);
+        aux_to_text(r, s);
+        out.recs.push_back(std::move(rec));
+    }
+}
+
+void SamFile::parse(const std::string &path) {
+    const std::string ext = extension(path);
+    if (ext.empty()) bail("Could not detect the file extension: \"" + path + "\"");
+    if (ext != "sam" && ext != "bam") bail("Input file must be a BAM or SAM file.");
+    header.clear();
+    recs.clear();
+    std::vector<char> d = read_file_maybe_gz(path);
+    if (ext == "bam")
+        parse_bam(d, *this);
+    else
+        parse_sam_text(d, *this);
+}
+
+int sam_find_tag(const std::string &line, const std::string &tag, std::string *val) {
+    size_t b = 0;
+    for (int f = 0; f < 11; ++f) {
+        b = line.find('\t', b);
+        if (b == std::string::npos) return 0;
+        ++b;
+    }
+    while (b < line.size()) {
+        size_t e = line.find('\t', b);
+        if (e == std::string::npos) e = line.size();
+        if (e - b >= 5 && line.compare(b, 2, tag) == 0 && line[b + 2] == ':') {
+            if (line[b + 3] != 'Z' || line[b + 4] != ':') return 2;
+            *val = line.substr(b + 5, e - b - 5);
+            return 1;
+        }
+        b = e + 1;
+    }
+    return 0;
+}
+
+}  // namespace cli

@@ -1,0 +1,176 @@
+"""End-to-end tests of the C++ `merkurio extract|tag` host program (GPU: it calls the HIP
+library) against the reference's golden files -- the same comparisons the reference's own
+fixture tests make (src/cmd_extract.rs:724-1057, src/cmd_tag.rs:696-1135), plus byte-exact
+checks of the parts of the text / JSON logs that do not depend on time, version or paths."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "merkurio_amd", "lib", "merkurio")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from merkurio_amd import build, native
+    build.build_all()
+    if native.device_count() < 1:
+        pytest.fail("no HIP device visible")
+
+
+def run(args, cwd=None, check=True):
+    p = subprocess.run([BIN] + args, cwd=cwd, capture_output=True)
+    if check and p.returncode != 0:
+        raise AssertionError(f"merkurio {' '.join(args)} -> {p.returncode}\n{p.stderr.decode()}")
+    return p
+
+
+def log_body(path):
+    """text log without its 4 volatile header lines (src/cmd_extract.rs:746-748)"""
+    return open(path, "rb").read().split(b"\n", 4)[4]
+
+
+def json_stable(path):
+    """(text of the matching_records array, text from the first statistics object to the end, parsed doc)"""
+    t = open(path, "rb").read()
+    head, rest = t.split(b'  "meta_information": ', 1)
+    key = b'  "paired_end_reads_statistics": ' if b'"paired_end_reads_statistics"' in rest else b'  "pattern_hit_counts": '
+    tail = key + rest.split(key, 1)[1]
+    return head, tail, json.loads(t)
+
+
+def check_json(got, gold):
+    gh, gt, gj = json_stable(got)
+    eh, et, ej = json_stable(gold)
+    assert gh == eh and gt == et
+    for k in ("search_algorithm", "inverted_matching", "case_insensitive", "subcommand", "program", "input_files"):
+        if k == "input_files":
+            assert gj["meta_information"][k]["record_file_1"] == ej["meta_information"][k]["record_file_1"]
+        else:
+            assert gj["meta_information"][k] == ej["meta_information"][k]
+    assert list(gj["meta_information"].keys()) == list(ej["meta_information"].keys())  # same (sorted) key set
+
+
+def sam_without_own_pg(path):
+    return [ln for ln in open(path, "rb").read().split(b"\n") if not ln.startswith(b"@PG\tID:merkurio")]
+
+
+@pytest.mark.parametrize("name,extra", [("simple", []), ("simple-inv", ["-v"])])
+def test_extract_fasta_fixtures(golden, tmp_path, name, extra):
+    fx = os.path.join(golden, "fixtures")
+    out = tmp_path / f"{name}.extracted.fasta"
+    run(["extract", "-i", os.path.join(fx, "input/simple.fasta"), "-r", "-s", "ACG", *extra, "-o", str(out),
+         "-l", str(tmp_path / "x.log"), "-j", str(tmp_path / "x.json")])
+    assert out.read_bytes() == open(os.path.join(fx, f"extract/{name}.extracted.fasta"), "rb").read()
+    assert log_body(tmp_path / "x.log") == log_body(os.path.join(fx, f"extract/{name}.log"))
+    check_json(tmp_path / "x.json", os.path.join(fx, f"extract/{name}.json"))
+    head = open(tmp_path / "x.log").read().split("\n")[:4]
+    assert head[0] == "#SeqKatcher extract log" and head[2].startswith("#Running merkurio version ")
+    assert head[3].startswith("#Command line: ")
+
+
+def test_extract_fixed_width(golden, tmp_path):
+    fx = os.path.join(golden, "fixtures")
+    out = tmp_path / "fw.faa"
+    run(["extract", "-i", os.path.join(fx, "input/fixed-width.faa"), "-s", "DKAT", "-o", str(out), "-l", str(tmp_path / "x.log"),
+         "-j", str(tmp_path / "x.json")])
+    assert out.read_bytes() == open(os.path.join(fx, "extract/fixed-width.extracted.faa"), "rb").read()
+    assert log_body(tmp_path / "x.log") == log_body(os.path.join(fx, "extract/fixed-width.log"))
+    check_json(tmp_path / "x.json", os.path.join(fx, "extract/fixed-width.json"))
+
+
+def test_extract_paired(golden, tmp_path):
+    fx = os.path.join(golden, "fixtures")
+    run(["extract", "-i", os.path.join(fx, "input/paired-1.fastq"), "-2", os.path.join(fx, "input/paired-2.fastq"), "-s", "CTT",
+         "-o", str(tmp_path / "paired.extracted.fastq"), "-l", str(tmp_path / "x.log"), "-j", str(tmp_path / "x.json")])
+    for k in (1, 2):
+        assert (tmp_path / f"paired_{k}.extracted.fastq").read_bytes() == \
+            open(os.path.join(fx, f"extract/paired_{k}.extracted.fastq"), "rb").read()
+    assert log_body(tmp_path / "x.log") == log_body(os.path.join(fx, "extract/paired.log"))
+    check_json(tmp_path / "x.json", os.path.join(fx, "extract/paired.json"))
+
+
+@pytest.mark.parametrize("name,inp,extra,out", [
+    ("simple", "simple.sam", ["-m"], "simple.extracted.sam"),
+    ("simple-inv", "simple.sam", ["-v"], "simple-inv.extracted.sam"),
+    ("simple-bam", "simple.bam", [], "simple.tagged.extracted.sam"),
+])
+def test_tag_fixtures(golden, tmp_path, name, inp, extra, out):
+    fx = os.path.join(golden, "fixtures")
+    o = tmp_path / "out.sam"
+    run(["tag", "-i", os.path.join(fx, "input", inp), "-o", str(o), "-s", "CTC", "-r", "-l", str(tmp_path / "x.log"), "-j",
+         str(tmp_path / "x.json"), "-p", "2", *extra])
+    assert sam_without_own_pg(o) == sam_without_own_pg(os.path.join(fx, "tag", out))
+    own = [ln for ln in o.read_bytes().split(b"\n") if ln.startswith(b"@PG\tID:merkurio")]
+    assert len(own) == 1 and own[0].startswith(b"@PG\tID:merkurio\tPN:merkurio\tCL:") and b"\tVN:" in own[0]
+    # the 5-line header of the tag log carries the tag line: body starts after 5 lines there too
+    g = open(tmp_path / "x.log", "rb").read().split(b"\n", 4)
+    e = open(os.path.join(fx, "tag", f"{name}.log"), "rb").read().split(b"\n", 4)
+    assert g[4] == e[4] and g[0] == b"#SeqKatcher tag log"
+    check_json(tmp_path / "x.json", os.path.join(fx, "tag", f"{name}.json"))
+
+
+def test_tag_aho_corasick_vector(golden, tmp_path):
+    """tests/fixtures/extract/log.json: tag -i simple.bam -S -s CTC AC CT AA T A C G GA AG -r -j log.json"""
+    fx = os.path.join(golden, "fixtures")
+    run(["tag", "-i", os.path.join(fx, "input/simple.bam"), "-S", "-s", "CTC", "AC", "CT", "AA", "T", "A", "C", "G", "GA", "AG", "-r",
+         "-j", str(tmp_path / "log.json")])
+    check_json(tmp_path / "log.json", os.path.join(fx, "extract/log.json"))
+
+
+def test_example_minimal_stdout(golden):
+    d = os.path.join(golden, "example-minimal")
+    p = run(["extract", "-f", os.path.join(d, "kmers.txt"), "-i", os.path.join(d, "sample.fasta")])
+    src = open(os.path.join(d, "sample.fasta"), "rb").read()
+    assert p.stdout == (src if src.endswith(b"\n") else src + b"\n")
+    p = run(["tag", "-f", os.path.join(d, "kmers.txt"), "-i", os.path.join(d, "sample.sam")])
+    lines = p.stdout.split(b"\n")
+    assert sum(1 for ln in lines if ln and not ln.startswith(b"@")) == 3 and all(b"\tkm:Z:" in ln for ln in lines if ln and ln[:1] != b"@")
+
+
+def test_example_workflow(golden, tmp_path):
+    wf = os.path.join(golden, "example-workflow")
+    run(["extract", "-i", os.path.join(wf, "data/mutant_R1.subset.fastq.gz"), "-2", os.path.join(wf, "data/mutant_R2.subset.fastq.gz"),
+         "-f", os.path.join(wf, "significant_kmers.txt"), "-r", "-o", str(tmp_path / "mutant_extracted.fastq.gz"), "-l",
+         str(tmp_path / "x.log"), "-j", str(tmp_path / "x.json")])
+    for k in (1, 2):
+        assert (tmp_path / f"mutant_extracted_{k}.fastq").read_bytes() == \
+            open(os.path.join(wf, f"output/mutant_extracted_{k}.fastq"), "rb").read()
+    got = json.load(open(tmp_path / "x.json"))
+    gold = json.load(open(os.path.join(wf, "logs/mutant_extracted.stats.json")))
+    strip = lambda rows: [(r["record_id"], r["pattern"], r["position"], r["file"].split(".")[0]) for r in rows]
+    assert strip(got["matching_records"]) == strip(gold["matching_records"])
+    assert got["pattern_hit_counts"] == gold["pattern_hit_counts"]
+    assert got["paired_end_reads_statistics"] == gold["paired_end_reads_statistics"]
+    # tag golden (README.md:259): no logging
+    o = tmp_path / "tagged.sam"
+    run(["tag", "-i", os.path.join(wf, "output/mutant_extracted.sorted.sam"), "-f", os.path.join(wf, "significant_kmers.txt"), "-r",
+         "-o", str(o)])
+    assert sam_without_own_pg(o) == sam_without_own_pg(os.path.join(wf, "output/mutant_extracted.sorted.tagged.sam"))
+
+
+def test_cli_errors(golden, tmp_path):
+    fx = os.path.join(golden, "fixtures/input")
+    assert run(["extract", "-i", os.path.join(fx, "simple.fasta")], check=False).returncode == 2  # kmers group required
+    assert run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "A", "-f", "x"], check=False).returncode == 2
+    assert run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "A", "-S"], check=False).returncode == 2  # -S requires logging
+    assert run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "A", "-q", "1", "-a"], check=False).returncode == 2
+    p = run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "A", "-l", "-j"], check=False)  # both logs to stdout
+    assert p.returncode == 1 and b"Cannot use both" in p.stderr
+    p = run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "ACG", "-l"], check=False)  # log to stdout + records to stdout
+    assert p.returncode == 1 and b"Cannot write log to stdout" in p.stderr
+    p = run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "ACG", "-q", "9", "-o", str(tmp_path / "o")], check=False)
+    assert p.returncode == 1 and b"Invalid q-gram length: 9" in p.stderr
+    p = run(["extract", "-i", os.path.join(fx, "paired-1.fastq"), "-2", os.path.join(fx, "simple.fasta"), "-s", "CTT"], check=False)
+    assert p.returncode == 1 and b"different number of records" in p.stderr
+    p = run(["tag", "-i", os.path.join(fx, "simple.sam"), "-s", "CTC", "-t", "kmx"], check=False)
+    assert p.returncode == 1 and b"Tag must be exactly two characters long." in p.stderr
+    p = run(["tag", "-i", os.path.join(fx, "simple.fasta"), "-s", "CTC"], check=False)
+    assert p.returncode == 1 and b"Input file must be a BAM or SAM file." in p.stderr
+    # -S with a log on stdout is fine, and -v is reported in the header line
+    p = run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "ACG", "-S", "-l", "-v"])
+    assert b"#Searching for 1 pattern (inverted matching)\n" in p.stdout and b"simple.fasta\tseq1\tACG\t0\n" in p.stdout
