@@ -135,7 +135,7 @@ def test_example_minimal_stdout(golden):
 def test_example_workflow(golden, tmp_path):
     wf = os.path.join(golden, "example-workflow")
     run(["extract", "-i", os.path.join(wf, "data/mutant_R1.subset.fastq.gz"), "-2", os.path.join(wf, "data/mutant_R2.subset.fastq.gz"),
-         "-f", os.path.join(wf, "significant_kmers.txt"), "-r", "-o", str(tmp_path / "mutant_extracted.fastq.gz"), "-l",
+         "-f", os.path.join(wf, "significant_kmers.txt"), "-r", "-o", str(tmp_path / "mutant_extracted"), "-l",
          str(tmp_path / "x.log"), "-j", str(tmp_path / "x.json")])
     for k in (1, 2):
         assert (tmp_path / f"mutant_extracted_{k}.fastq").read_bytes() == \
