@@ -83,7 +83,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -124,8 +125,8 @@ def main():
             raise RuntimeError(lib.mk_last_error().decode())
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -140,7 +141,7 @@ def main():
     sharding.all_reduce_counters(d_cnt)  # the job's only collective: hit-count / summary vector (RCCL over xGMI)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -197,7 +198,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, d_flags,
                                                args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -36,13 +36,21 @@ def _deps():
 
 
 def build_lib(force=False, verbose=False):
+    """(Re)builds the library if it is missing or older than its sources.  Serialised with a
+    file lock and written through a temporary name: several ranks of one job may call this."""
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
     if not force and not _stale(LIB_PATH, _deps()):
         return LIB_PATH
-    cmd = [HIPCC, *FLAGS, "-shared", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or _stale(LIB_PATH, _deps()):  # still stale once we hold the lock
+            tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+            cmd = [HIPCC, *FLAGS, "-shared", "-o", tmp] + [os.path.join(CSRC, s) for s in LIB_SOURCES]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -112,8 +112,8 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     _bind_to_torch_hip_runtime()
-    if build_if_missing:
-        _build.build_lib()
+    if build_if_missing and (not os.path.exists(_build.LIB_PATH) or os.environ.get("MERKURIO_REBUILD") == "1"):
+        _build.build_lib()  # a present library is used as is (the driver's build() step keeps it fresh)
     if not os.path.exists(_build.LIB_PATH):
         raise MerkurioError(MK_E_HIP, f"{_build.LIB_PATH} is missing: run `python -m merkurio_amd.build`")
     L = C.CDLL(_build.LIB_PATH)

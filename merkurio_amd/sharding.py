@@ -32,7 +32,7 @@ def counters_layout(n_pat):
 def all_reduce_counters(t):
     """in-place sum of the int64 counter tensor over all ranks (no-op without a process group)"""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
