@@ -244,6 +244,9 @@ __device__ __forceinline__ void probe_candidates(const ScanParams &P, bool activ
 #ifndef MK_ABLATE
 #define MK_ABLATE 0
 #endif
+#ifndef MK_LOOPV
+#define MK_LOOPV 0
+#endif
 
 // Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
 // sizes that matter get their own kernels: no runtime masks, no unused halo words);
@@ -332,28 +335,31 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     hr.head = 0;
     hr.count = 0;
     uint32_t n_true = 0, n_first = 0;  // per lane: occurrences found / records newly flagged
+    uint32_t abl_acc = 0;              // ablation builds only
 
-    // ---- scan of one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
-    // packed chunk that follows in the text (halo source for lanes 62/63)
-    auto scan_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint64_t cpos) {
-        // halo: lane i needs the packed dwords of lanes i+1 and i+2; DPP wave_shl:1 moves a
-        // whole wave by one lane in one VALU op, lane 63 keeps `old` = the next chunk's lane
-        const uint32_t w0 = pk_cur;
-        uint32_t w1 = 0, w2 = 0;
+    // ---- level 1 for one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
+    // packed chunk that follows in the text (halo source for the last lanes).  Returns the
+    // lane's candidate mask (bit j = sample j passed the filter).  Straight-line code.
+    auto halo = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &w1, uint32_t &w2) {
+        // lane i needs the packed dwords of lanes i+1 and i+2; DPP wave_shl:1 moves a whole
+        // wave by one lane in one VALU op, lane 63 keeps `old` = the next chunk's lane
+        w1 = 0;
+        w2 = 0;
         if constexpr (G::kNeedW1) {
             const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
-            w1 = __builtin_amdgcn_update_dpp(n0, w0, 0x130, 0xf, 0xf, false);
+            w1 = __builtin_amdgcn_update_dpp(n0, pk_cur, 0x130, 0xf, 0xf, false);
         }
         if constexpr (G::kNeedW2) {
             const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
             w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
         }
-
+    };
+    auto filter_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt) -> uint32_t {
+        const uint32_t w0 = pk_cur;
+        uint32_t w1, w2;
+        halo(pk_cur, pk_nxt, w1, w2);
+        if constexpr ((MK_ABLATE & 4) != 0) return ((w0 ^ w1 ^ w2) == 0x12345678u) ? 1u : 0u;  // loads + pack only
         uint32_t cand = 0;
-        if constexpr ((MK_ABLATE & 4) != 0) {  // loads + pack only
-            if ((w0 ^ w1 ^ w2) == 0x12345678u) n_cand++;
-            return;
-        }
         const char *bloom_bytes = reinterpret_cast<const char *>(bloom);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -371,10 +377,20 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             const uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
             cand |= (m & 1u) << j;
         }
-        if constexpr ((MK_ABLATE & 1) != 0) cand = 0;
+        if constexpr ((MK_ABLATE & 1) != 0) {  // keep the filter work alive, drop its result
+            abl_acc += cand;
+            cand = 0;
+        }
+        return cand;
+    };
 
-        // filter positives -> per-wave LDS ring (ballot/popcount compaction); verified 64
-        // at a time so that the L2 round trip is paid once per 64 candidates, not per chunk
+    // ---- level 1 -> 2 hand-off (rare): filter positives of one chunk -> per-wave LDS ring
+    // (ballot/popcount compaction); 64 at a time they are probed against the exact table, so
+    // the L2 round trip is paid once per 64 candidates, not per chunk
+    auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t cand, uint64_t cpos) {
+        const uint32_t w0 = pk_cur;
+        uint32_t w1, w2;
+        halo(pk_cur, pk_nxt, w1, w2);
         uint64_t any = __ballot(cand != 0);
         while (any) {  // wave-uniform
             if (cand != 0) {
@@ -430,43 +446,73 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             }
             return v;
         };
-        // register pipeline, 4 chunks deep: a group packs the four chunks loaded one group ago
-        // and immediately re-issues the four loads for the next group (straight-line, so the
-        // compiler's s_waitcnt vmcnt(N) stay counted), then ONE copy of the scan code walks
-        // the four packed dwords (rotating packed registers costs v_movs, never a memory wait).
+        // Register pipeline, one group = 4 chunks deep.  A group (straight-line code, so the
+        // compiler's s_waitcnt vmcnt(N) stay counted): pack the four chunks loaded one group
+        // ago, re-issue the four loads, run level 1 on the four chunk pairs (pk_prev,p0) ..
+        // (p2,p3).  Only if some lane has a filter positive does the wave enter the (looped,
+        // single-copy) hand-off code.
         uint4 r0 = load_next(), r1 = load_next(), r2 = load_next(), r3 = load_next();
         uint32_t pk_prev = 0;
         for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
             const uint64_t base = tile * kTileBytes;
 #pragma unroll 1
             for (int g = 0; g < (kTileChunks + 1) / 4; ++g) {
-                uint32_t p0 = pack16(r0);
+                const uint32_t p0 = pack16(r0), p1 = pack16(r1), p2 = pack16(r2), p3 = pack16(r3);
+                __builtin_amdgcn_sched_barrier(0);  // pack first: the loads reuse the same registers
                 r0 = load_next();
-                uint32_t p1 = pack16(r1);
                 r1 = load_next();
-                uint32_t p2 = pack16(r2);
                 r2 = load_next();
-                uint32_t p3 = pack16(r3);
                 r3 = load_next();
+#if MK_LOOPV == 1
+                // variant: one looped copy of filter + hand-off per chunk (rotating packed registers)
+                {
+                    uint32_t q0 = p0, q1 = p1, q2 = p2;
 #pragma unroll 1
-                for (int k = 0; k < 4; ++k) {
-                    const int ci = 4 * g + k - 1;  // chunk scanned now: (pk_prev, p0)
-                    if (ci >= 0) scan_chunk(pk_prev, p0, base + (uint64_t)ci * kChunkBytes);
-                    pk_prev = p0;
-                    p0 = p1;
-                    p1 = p2;
-                    p2 = p3;
+                    for (int k = 0; k < 4; ++k) {
+                        const int ci = 4 * g + k - 1;
+                        if (ci >= 0) {
+                            const uint32_t ck = filter_chunk(pk_prev, q0);
+                            if constexpr ((MK_ABLATE & 4) != 0) n_cand += ck;
+                            if (__ballot(ck != 0)) queue_candidates(pk_prev, q0, ck, base + (uint64_t)ci * kChunkBytes);
+                        }
+                        pk_prev = q0;
+                        q0 = q1;
+                        q1 = q2;
+                        q2 = p3;
+                    }
                 }
+#else
+                // chunk scanned by pair k is 4g + k - 1; the first pair of a tile straddles tiles
+                uint32_t c0 = filter_chunk(pk_prev, p0);
+                if (g == 0) c0 = 0;
+                const uint32_t c1 = filter_chunk(p0, p1);
+                const uint32_t c2 = filter_chunk(p1, p2);
+                const uint32_t c3 = filter_chunk(p2, p3);
+                if constexpr ((MK_ABLATE & 4) != 0) n_cand += c0 + c1 + c2 + c3;
+                if (__ballot((c0 | c1 | c2 | c3) != 0)) {  // rare at useful filter densities
+#pragma unroll 1
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t cur = k == 0 ? pk_prev : k == 1 ? p0 : k == 2 ? p1 : p2;
+                        const uint32_t nxt = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+                        const uint32_t ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                        if (__ballot(ck != 0))
+                            queue_candidates(cur, nxt, ck, base + (uint64_t)(4 * g + k - 1) * kChunkBytes);
+                    }
+                }
+#endif
+                pk_prev = p3;
             }
         }
     }
 
-    // ---- tail phase: the < 17 KiB behind the last main tile, with guarded loads; one wave
+    // ---- tail phase: the < 32 KiB behind the last main tile, with guarded loads; one wave
     if (wave_id == n_main_tiles % n_waves) {
         for (uint64_t cpos = n_main_tiles * kTileBytes; cpos < n_bytes; cpos += kChunkBytes) {
             const uint32_t pk_cur = pack16(load16(seq, cpos + lane * 16, n_bytes));
             const uint32_t pk_nxt = pack16(load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
-            scan_chunk(pk_cur, pk_nxt, cpos);
+            const uint32_t ck = filter_chunk(pk_cur, pk_nxt);
+            if constexpr ((MK_ABLATE & 4) != 0) n_cand += ck;
+            if (__ballot(ck != 0)) queue_candidates(pk_cur, pk_nxt, ck, cpos);
         }
     }
 
@@ -478,6 +524,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, lane, hr, n_true, n_first);
     }
     if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, n_first);
+    if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
         if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
         // uniform addresses: the compiler folds each of these into one atomic per wave
