@@ -430,39 +430,47 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         // last tile the pointer parks on the last main tile: the loads stay unconditional (a
         // branch around a load would force s_waitcnt vmcnt(0) at the join), their data unused.
         uint64_t ld_tile = wave_id;
-        uint32_t ld_c = 0;
+        uint32_t ld_g = 0;  // group index inside the tile (a tile is 8 groups of 4 chunk loads)
         const uint64_t last_tile = n_main_tiles - 1;
         const uint8_t *ld_ptr = seq + wave_id * kTileBytes + lane * 16;
-        auto load_next = [&]() -> uint4 {
+        auto nt_load = [](const uint8_t *p) -> uint4 {
             // non-temporal: the text is read once; keep L2 for the exact table and the filter image
-            const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ld_ptr));
-            const uint4 v = make_uint4(nv.x, nv.y, nv.z, nv.w);
-            ld_ptr += kChunkBytes;
-            if (++ld_c == (uint32_t)kTileChunks + 1) {  // next tile of this wave
-                ld_c = 0;
+            const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+            return make_uint4(nv.x, nv.y, nv.z, nv.w);
+        };
+        // four loads off one address register (immediate offsets); the tile wrap is checked
+        // once per group so that the group stays one basic block
+        auto load_group = [&](uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+            a = nt_load(ld_ptr);
+            b = nt_load(ld_ptr + kChunkBytes);
+            c = nt_load(ld_ptr + 2 * kChunkBytes);
+            d = nt_load(ld_ptr + 3 * kChunkBytes);
+            ld_ptr += 4 * kChunkBytes;
+            if (++ld_g == (uint32_t)(kTileChunks + 1) / 4) {  // next tile of this wave
+                ld_g = 0;
                 ld_tile += n_waves;
                 const uint64_t t = ld_tile < last_tile ? ld_tile : last_tile;
                 ld_ptr = seq + t * kTileBytes + lane * 16;
             }
-            return v;
         };
         // Register pipeline, one group = 4 chunks deep.  A group (straight-line code, so the
         // compiler's s_waitcnt vmcnt(N) stay counted): pack the four chunks loaded one group
         // ago, re-issue the four loads, run level 1 on the four chunk pairs (pk_prev,p0) ..
         // (p2,p3).  Only if some lane has a filter positive does the wave enter the (looped,
         // single-copy) hand-off code.
-        uint4 r0 = load_next(), r1 = load_next(), r2 = load_next(), r3 = load_next();
+        uint4 r0, r1, r2, r3;
+        load_group(r0, r1, r2, r3);
         uint32_t pk_prev = 0;
         for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
             const uint64_t base = tile * kTileBytes;
 #pragma unroll 1
             for (int g = 0; g < (kTileChunks + 1) / 4; ++g) {
                 const uint32_t p0 = pack16(r0), p1 = pack16(r1), p2 = pack16(r2), p3 = pack16(r3);
-                __builtin_amdgcn_sched_barrier(0);  // pack first: the loads reuse the same registers
-                r0 = load_next();
-                r1 = load_next();
-                r2 = load_next();
-                r3 = load_next();
+                // pack BEFORE re-issuing the loads into the same registers: without this pin the
+                // compiler sinks the packs below the loads and keeps the raw data alive with 16
+                // v_mov per group
+                asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+                load_group(r0, r1, r2, r3);
 #if MK_LOOPV == 1
                 // variant: one looped copy of filter + hand-off per chunk (rotating packed registers)
                 {
