@@ -197,45 +197,56 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
 }
 
 // ---- level 2: up to 64 filter positives (one per lane) against the exact q-gram table -----
-// Wave-uniform loop over the bucket chain; fingerprint matches are compacted (ballot /
-// popcount) into the wave's hit ring.
+// One bucket (32 B, 4 entries) per lane and round.  probe_round() consumes a bucket that is
+// already in registers: fingerprint matches are compacted (ballot/popcount) into the wave's
+// hit ring; returns whether this lane must look at the next bucket (its bucket was full).
 template <bool EMIT>
-__device__ __forceinline__ void probe_candidates(const ScanParams &P, bool active, uint64_t key, uint64_t t, uint32_t lane,
-                                                 HitRing &hr, uint32_t &n_true, uint32_t &n_first) {
-    uint32_t b = table_hash(key) & P.table_mask;
-    const uint32_t fp = key_fingerprint(key);
-    uint64_t live = __ballot(active);
-    while (live) {  // wave-uniform; one iteration unless some lane's home bucket is full
-        uint4 v0 = make_uint4(0, kEmptyPat, 0, kEmptyPat), v1 = v0;
-        if (active) {
-            const uint4 *bp = reinterpret_cast<const uint4 *>(P.table + (size_t)b * kBucketEntries);
-            v0 = bp[0];
-            v1 = bp[1];
-        }
-        const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
-        const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
+__device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint64_t t, uint4 v0, uint4 v1,
+                                            uint32_t lane, HitRing &hr, uint32_t &n_true, uint32_t &n_first) {
+    const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
+    const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e_off = epo[k] & 15u, e_pat = epo[k] >> 4;
-            const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
-            const uint64_t mm = __ballot(match);
-            if (mm) {  // uniform, rare
-                if (match) {
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                    HitCand h;
-                    h.p = t - e_off;
-                    h.pat = e_pat;
-                    h.pad = 0;
-                    hr.q[(hr.head + hr.count + below) & (kHitRing - 1)] = h;
-                }
-                hr.count += (uint32_t)__popcll(mm);  // < 64 before, <= 127 now
-                if (hr.count >= 64) drain_hits<EMIT>(P, hr, 64, lane, n_true, n_first);
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t e_off = epo[k] & 15u, e_pat = epo[k] >> 4;
+        const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
+        const uint64_t mm = __ballot(match);
+        if (mm) {  // uniform, rare
+            if (match) {
+                const uint32_t below =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                HitCand h;
+                h.p = t - e_off;
+                h.pat = e_pat;
+                h.pad = 0;
+                hr.q[(hr.head + hr.count + below) & (kHitRing - 1)] = h;
             }
+            hr.count += (uint32_t)__popcll(mm);  // < 64 before, <= 127 now
+            if (hr.count >= 64) drain_hits<EMIT>(P, hr, 64, lane, n_true, n_first);
         }
-        active = active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
+    }
+    return active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
+}
+
+__device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, uint32_t b, uint4 &v0, uint4 &v1) {
+    v0 = make_uint4(0, kEmptyPat, 0, kEmptyPat);
+    v1 = v0;
+    if (active) {
+        const uint4 *bp = reinterpret_cast<const uint4 *>(P.table + (size_t)b * kBucketEntries);
+        v0 = bp[0];
+        v1 = bp[1];
+    }
+}
+
+// synchronous probe: wave-uniform loop over the bucket chain (one iteration unless a home
+// bucket is full), each iteration one memory round trip
+template <bool EMIT>
+__device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint64_t t,
+                                            uint32_t lane, HitRing &hr, uint32_t &n_true, uint32_t &n_first) {
+    while (__ballot(active)) {
+        uint4 v0, v1;
+        load_bucket(P, active, b, v0, v1);
+        active = probe_round<EMIT>(P, active, fp, t, v0, v1, lane, hr, n_true, n_first);
         b = (b + 1) & P.table_mask;
-        live = __ballot(active);
     }
 }
 
@@ -384,6 +395,47 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         return cand;
     };
 
+    // ---- level 2 drains.  Synchronous: take n (<= 64) candidates off the ring and walk their
+    // bucket chains.  Asynchronous (the normal case): issue the bucket loads now, keep them in
+    // registers, and consume them at the top of the next group -- by then the loads are older
+    // than the stream loads the wave has waited for anyway, so the probe's memory round trip
+    // overlaps a whole group of scanning instead of stalling the wave (and its prefetches).
+    bool pend_on = false;  // wave-uniform
+    bool pend_active = false;
+    uint32_t pend_fp = 0, pend_b = 0;
+    uint64_t pend_t = 0;
+    uint4 pend_v0 = make_uint4(0, 0, 0, 0), pend_v1 = pend_v0;
+    auto take_from_ring = [&](uint32_t n, bool &active, uint32_t &b, uint32_t &fp, uint64_t &t) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
+        __builtin_amdgcn_wave_barrier();
+        active = lane < n;
+        b = table_hash(e.key) & P.table_mask;
+        fp = key_fingerprint(e.key);
+        t = e.t;
+        q_head = (q_head + n) & (kRingEntries - 1);
+        q_count -= n;
+    };
+    auto drain_ring = [&](uint32_t n) {  // synchronous
+        bool active;
+        uint32_t b, fp;
+        uint64_t t;
+        take_from_ring(n, active, b, fp, t);
+        probe_chain<EMIT>(P, active, b, fp, t, lane, hr, n_true, n_first);
+    };
+    auto issue_probe = [&](uint32_t n) {  // asynchronous: loads only
+        take_from_ring(n, pend_active, pend_b, pend_fp, pend_t);
+        load_bucket(P, pend_active, pend_b, pend_v0, pend_v1);
+        pend_on = true;
+    };
+    auto consume_probe = [&]() {
+        const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, n_true, n_first);
+        if (__ballot(more))  // some home bucket was full: finish those chains synchronously
+            probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, n_true, n_first);
+        pend_on = false;
+    };
+
     // ---- level 1 -> 2 hand-off (rare): filter positives of one chunk -> per-wave LDS ring
     // (ballot/popcount compaction); 64 at a time they are probed against the exact table, so
     // the L2 round trip is paid once per 64 candidates, not per chunk
@@ -393,6 +445,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         halo(pk_cur, pk_nxt, w1, w2);
         uint64_t any = __ballot(cand != 0);
         while (any) {  // wave-uniform
+            if (q_count > 64) drain_ring(64);  // an append round adds <= 64 entries to the 128-entry ring
             if (cand != 0) {
                 const uint32_t j = (uint32_t)__ffs(cand) - 1u;
                 cand &= cand - 1;
@@ -408,15 +461,6 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             }
             q_count += (uint32_t)__popcll(any);
             n_cand += (uint32_t)__popcll(any);
-            if (q_count >= 64) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-                probe_candidates<EMIT>(P, true, e.key, e.t, lane, hr, n_true, n_first);
-                __builtin_amdgcn_wave_barrier();
-                q_head = (q_head + 64) & (kRingEntries - 1);
-                q_count -= 64;
-            }
             any = __ballot(cand != 0);
         }
     };
@@ -470,6 +514,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 // compiler sinks the packs below the loads and keeps the raw data alive with 16
                 // v_mov per group
                 asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+                if (pend_on) consume_probe();  // its loads are older than the stream loads just waited for
                 load_group(r0, r1, r2, r3);
 #if MK_LOOPV == 1
                 // variant: one looped copy of filter + hand-off per chunk (rotating packed registers)
@@ -508,10 +553,12 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     }
                 }
 #endif
+                if (!pend_on && q_count >= 32) issue_probe(q_count < 64 ? q_count : 64);
                 pk_prev = p3;
             }
         }
     }
+    if (pend_on) consume_probe();
 
     // ---- tail phase: the < 32 KiB behind the last main tile, with guarded loads; one wave
     if (wave_id == n_main_tiles % n_waves) {
@@ -525,12 +572,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     }
 
     // drain what is left in this wave's rings
-    if (q_count) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-        probe_candidates<EMIT>(P, lane < q_count, e.key, e.t, lane, hr, n_true, n_first);
-    }
+    while (q_count) drain_ring(q_count < 64 ? q_count : 64);
     if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, n_first);
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
