@@ -166,7 +166,8 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
 /* ------------------------------------------------------------------------------------
  * Batched scan, device-resident buffers (the kernel boundary; asynchronous)
  *
- * All pointers are device pointers on the matcher's device.  d_seq must be 16-byte aligned;
+ * All pointers are device pointers on the matcher's device.  d_seq must be 16-byte aligned and
+ * d_seq_off[0] must be 0 (offsets relative to d_seq);
  * d_rec_flags 4-byte aligned with its allocation padded to a multiple of 4 bytes.
  * The call enqueues on `stream` (a hipStream_t, NULL = default stream): clear of
  * d_rec_flags[0..n_rec) and of *d_n_hits, then the scan kernel.  d_hits may be NULL in

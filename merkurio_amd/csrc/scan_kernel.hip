@@ -73,12 +73,20 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     if (p + len > P.n_bytes) return;
     const uint8_t *__restrict__ tx = P.seq + p;
     const uint8_t *__restrict__ pt = P.pat_bytes + a;
+    // Everything below that touches memory is independent of everything else, so it is issued
+    // together and costs ONE round trip: the record-offset pair at the interpolated record
+    // index (reads are mostly of similar length, so the guess is usually right) and the four
+    // 8-byte text / pattern loads of the comparison.
+    const uint64_t n = P.n_rec;
+    uint64_t lo = (uint64_t)((double)p * P.rec_per_byte);
+    if (lo >= n) lo = n - 1;
+    uint64_t rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];  // seq_off[0] == 0 is part of the ABI
     if (P.case_insensitive) {
         for (uint32_t i = 0; i < len; ++i)
             if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return;
     } else {
-        // independent 8-byte (unaligned) loads, no early-exit chain: patterns up to 32 bytes
-        // (every k-mer) cost ONE memory round trip; the clamped offsets overlap harmlessly
+        // independent 8-byte (unaligned) loads, no early-exit chain; the clamped offsets of
+        // patterns up to 32 bytes (every k-mer) overlap harmlessly
         uint64_t diff = 0;
         if (len >= 8) {
             const uint32_t last = len - 8;
@@ -102,41 +110,39 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
         }
         if (diff) return;
     }
-    // record containing p: largest r with rec_off[r] <= p.  Interpolate (reads are mostly of
-    // similar length), gallop to a bracket, then bisect.
-    if (p < P.rec_off[0]) return;
-    const uint64_t n = P.n_rec;
-    uint64_t r = (uint64_t)((double)p * P.rec_per_byte);
-    if (r >= n) r = n - 1;
-    uint64_t lo, hi;
-    if (P.rec_off[r] <= p) {
-        lo = r;
-        hi = r + 1;
-        uint64_t step = 1;
-        while (hi < n && P.rec_off[hi] <= p) {
-            lo = hi;
-            step <<= 1;
-            hi = (n - hi > step) ? hi + step : n;
-        }
-    } else {
-        hi = r;
-        uint64_t step = 1;
-        lo = r - 1;  // r > 0 here because rec_off[0] <= p
-        while (P.rec_off[lo] > p) {
+    // record containing p: largest r with rec_off[r] <= p.  Wrong guess (ragged records):
+    // gallop from it to a bracket, then bisect.
+    if (!(rstart <= p && p < rend)) {
+        uint64_t hi;
+        if (rstart <= p) {
+            hi = lo + 1;
+            uint64_t step = 1;
+            while (hi < n && P.rec_off[hi] <= p) {
+                lo = hi;
+                step <<= 1;
+                hi = (n - hi > step) ? hi + step : n;
+            }
+        } else {
             hi = lo;
-            step <<= 1;
-            lo = lo > step ? lo - step : 0;
+            uint64_t step = 1;
+            lo = lo - 1;  // lo > 0 here because rec_off[0] = 0 <= p
+            while (P.rec_off[lo] > p) {
+                hi = lo;
+                step <<= 1;
+                lo = lo > step ? lo - step : 0;
+            }
         }
+        while (hi - lo > 1) {  // invariant: rec_off[lo] <= p < rec_off[hi]  (rec_off[n] = n_bytes)
+            const uint64_t mid = (lo + hi) >> 1;
+            if (P.rec_off[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        rstart = P.rec_off[lo];
+        rend = P.rec_off[lo + 1];
     }
-    while (hi - lo > 1) {  // invariant: rec_off[lo] <= p < rec_off[hi]  (rec_off[n] = n_bytes)
-        const uint64_t mid = (lo + hi) >> 1;
-        if (P.rec_off[mid] <= p)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const uint64_t rstart = P.rec_off[lo];
-    if (p + len > P.rec_off[lo + 1]) return;  // occurrence would cross a record boundary
+    if (p + len > rend) return;  // occurrence would cross a record boundary
     // ---- a true occurrence
     const uint32_t fsh = (uint32_t)(lo & 3) * 8;
     const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << fsh);
