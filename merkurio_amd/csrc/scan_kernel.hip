@@ -264,6 +264,9 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 #ifndef MK_LOOPV
 #define MK_LOOPV 0
 #endif
+#ifndef MK_ISSUE_AT
+#define MK_ISSUE_AT 56  // ring fill at which a group ends with an asynchronous level-2 probe
+#endif
 
 // Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
 // sizes that matter get their own kernels: no runtime masks, no unused halo words);
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     }
                 }
 #endif
-                if (!pend_on && q_count >= 32) issue_probe(q_count < 64 ? q_count : 64);
+                if (!pend_on && q_count >= MK_ISSUE_AT) issue_probe(q_count < 64 ? q_count : 64);
                 pk_prev = p3;
             }
         }
