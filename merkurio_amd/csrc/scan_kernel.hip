@@ -262,7 +262,7 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 #define MK_ABLATE 0
 #endif
 #ifndef MK_LOOPV
-#define MK_LOOPV 0
+#define MK_LOOPV 1  // 1: one looped copy of filter + hand-off per chunk (2 % faster at S=8, tools/loopv_ab.sh); 0: four straight-line filter passes per group
 #endif
 #ifndef MK_ISSUE_AT
 #define MK_ISSUE_AT 56  // ring fill at which a group ends with an asynchronous level-2 probe
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 if (pend_on) consume_probe();  // its loads are older than the stream loads just waited for
                 load_group(r0, r1, r2, r3);
 #if MK_LOOPV == 1
-                // variant: one looped copy of filter + hand-off per chunk (rotating packed registers)
+                // one looped copy of filter + hand-off per chunk (rotating the packed registers)
                 {
                     uint32_t q0 = p0, q1 = p1, q2 = p2;
 #pragma unroll 1
