@@ -64,7 +64,7 @@ def build_cli(force=False, verbose=False):
     if not force and not _stale(CLI_PATH, deps):
         return CLI_PATH
     cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-o", CLI_PATH, *srcs, "-L" + LIB_DIR,
-           "-lmerkurio_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
+           "-lmerkurio_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 
 #include "../../../include/merkurio_hip.h"
 #include "io.hpp"
@@ -14,6 +15,23 @@ namespace cli {
 
 static const char *kProgram = "merkurio";
 static const char *kVersion = "1.0.0";  // crate version of the reference tree (Cargo.toml:3)
+
+// MERKURIO_TIMING=1: phase wall times on stderr (where does an end-to-end run spend its time)
+struct PhaseTimer {
+    bool on = getenv("MERKURIO_TIMING") != nullptr;
+    double t0 = now();
+    static double now() {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + ts.tv_nsec * 1e-9;
+    }
+    void mark(const char *what) {
+        if (!on) return;
+        const double t = now();
+        fprintf(stderr, "[timing] %-28s %8.3f s\n", what, t - t0);
+        t0 = t;
+    }
+};
 
 static void mk_check(int rc, const char *what) {
     if (rc != MK_OK) bail(std::string(what) + ": " + mk_last_error());
@@ -172,11 +190,14 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     Loggers lg;
     open_loggers(a, lg);
     if (lg.active) write_log_header(lg.text, "extract", argv, nullptr, pats.list.size(), a.invert_match);
+    PhaseTimer tm;
     bool use_ac = false;
     mk_matcher *m = make_matcher(a, pats, &use_ac);
+    tm.mark("matcher create (HIP init)");
 
     FastxFile f1, f2;
     f1.parse(a.in_fastx);
+    tm.mark("read + parse input");
     const bool paired = (bool)a.in_fastq_2;
     if (paired) {
         f2.parse(*a.in_fastq_2);
@@ -212,22 +233,18 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     std::vector<mk_row> rows(4096);
     size_t i = 0;
     while (i < n) {
-        s1.clear(); s2.clear();
-        o1.assign(1, 0); o2.assign(1, 0);
         const size_t b0 = i;
-        while (i < n && (s1.size() + s2.size() < batch_bytes || i == b0)) {
-            f1.append_seq(i, s1);
-            o1.push_back(s1.size());
-            if (paired) {
-                f2.append_seq(i, s2);
-                o2.push_back(s2.size());
-            }
+        uint64_t bytes = 0;
+        while (i < n && (bytes < batch_bytes || i == b0)) {
+            bytes += f1.raw_len(i) + (paired ? f2.raw_len(i) : 0);
             ++i;
         }
+        f1.gather(b0, i, s1, o1);
+        if (paired) f2.gather(b0, i, s2, o2);
         const uint64_t nb = i - b0;
         keep.assign(nb, 0);
-        s1.push_back(0); s2.push_back(0);
         uint64_t n_rows = 0;
+        tm.mark("batch: gather sequences");
         for (;;) {
             mk_counters cb;
             memset(&cb, 0, sizeof(cb));
@@ -248,6 +265,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             for (size_t k = 0; k < counts.size(); ++k) counts[k] += cnt_b[k];
             break;
         }
+        tm.mark("batch: H2D + scan + D2H");
         if (lg.active)
             for (uint64_t k = 0; k < n_rows; ++k) {
                 const mk_row &r = rows[k];
@@ -265,6 +283,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     }
     w1.flush();
     w2.flush();
+    tm.mark("log rows + write records");
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, paired);

@@ -1,8 +1,14 @@
 #include "io.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace cli {
 
@@ -44,60 +50,89 @@ std::vector<char> read_file_maybe_gz(const std::string &path) {
     return out;
 }
 
-// ---- FASTA / FASTQ ------------------------------------------------------------------------------
-static uint64_t line_end(const std::vector<char> &d, uint64_t b) {  // index of '\n' or size
-    const void *p = memchr(d.data() + b, '\n', d.size() - b);
-    return p ? (uint64_t)((const char *)p - d.data()) : d.size();
+FileBytes::~FileBytes() {
+    if (map) munmap(map, map_len);
 }
-static uint64_t strip_cr(const std::vector<char> &d, uint64_t b, uint64_t e) { return (e > b && d[e - 1] == '\r') ? e - 1 : e; }
 
-void FastxFile::parse(const std::string &path) {
-    data = read_file_maybe_gz(path);
-    recs.clear();
-    uint64_t p = 0;
-    const uint64_t n = data.size();
-    while (p < n && (data[p] == '\n' || data[p] == '\r')) ++p;
-    if (p >= n) return;
-    if (data[p] != '>' && data[p] != '@') bail("Error during FASTQ/A record parsing.");
-    fastq = data[p] == '@';
-    while (p < n) {
-        if (data[p] == '\n' || data[p] == '\r') {  // blank line between records
+void FileBytes::load(const std::string &path) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) bail("No such file or directory: " + path);
+    unsigned char magic[2] = {0, 0};
+    ssize_t got = pread(fd, magic, 2, 0);
+    struct stat st;
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m != MAP_FAILED) {
+            close(fd);
+            map = m;
+            map_len = (uint64_t)st.st_size;
+            p = (const char *)m;
+            n = map_len;
+            // reject the compressed formats this build cannot read
+            if (n >= 3 && !memcmp(p, "BZh", 3)) bail("bzip2 input is not supported by this build (gzip and plain text are): " + path);
+            if (n >= 6 && (unsigned char)p[0] == 0xFD && !memcmp(p + 1, "7zXZ", 4))
+                bail("xz input is not supported by this build (gzip and plain text are): " + path);
+            if (n >= 4 && !memcmp(p, "\x28\xB5\x2F\xFD", 4))
+                bail("zstd input is not supported by this build (gzip and plain text are): " + path);
+            return;
+        }
+    }
+    close(fd);
+    owned = read_file_maybe_gz(path);
+    p = owned.data();
+    n = owned.size();
+}
+
+// ---- FASTA / FASTQ ------------------------------------------------------------------------------
+static uint64_t line_end(const char *d, uint64_t n, uint64_t b) {  // index of '\n' or n
+    const void *p = memchr(d + b, '\n', n - b);
+    return p ? (uint64_t)((const char *)p - d) : n;
+}
+static uint64_t strip_cr(const char *d, uint64_t b, uint64_t e) { return (e > b && d[e - 1] == '\r') ? e - 1 : e; }
+
+// records of d[p, stop): p is at a record start (or blank lines before one); a record that starts
+// before `stop` is parsed completely even if it runs past it
+static void parse_fastx_range(const char *d, uint64_t n, uint64_t p, uint64_t stop, bool fastq,
+                              std::vector<FastxFile::Rec> &recs) {
+    while (p < stop) {
+        if (d[p] == '\n' || d[p] == '\r') {  // blank line between records
             ++p;
             continue;
         }
-        Rec r{};
+        FastxFile::Rec r{};
         if (!fastq) {
-            if (data[p] != '>') bail("Error during FASTQ/A record parsing.");
-            uint64_t e = line_end(data, p);
+            if (d[p] != '>') bail("Error during FASTQ/A record parsing.");
+            uint64_t e = line_end(d, n, p);
             r.id_b = p + 1;
-            r.id_e = strip_cr(data, p + 1, e);
+            r.id_e = strip_cr(d, p + 1, e);
             uint64_t s = std::min(e + 1, n);
             r.raw_b = s;
-            uint64_t q = s;  // the sequence runs to the '\n' before the next line that starts with '>'
+            uint64_t q = s;  // the sequence runs to the line end before the next line that starts with '>'
             for (;;) {
-                if (q >= n || data[q] == '>') break;
-                q = std::min(line_end(data, q) + 1, n);
+                if (q >= n || d[q] == '>') break;
+                q = std::min(line_end(d, n, q) + 1, n);
             }
             uint64_t re = q;
-            while (re > s && (data[re - 1] == '\n' || data[re - 1] == '\r')) --re;  // drop the final line end
+            while (re > s && (d[re - 1] == '\n' || d[re - 1] == '\r')) --re;  // drop the final line end
             r.raw_e = re;
             r.qual_b = r.qual_e = 0;
             p = q;
         } else {
-            if (data[p] != '@') bail("Error during FASTQ/A record parsing.");
-            uint64_t e1 = line_end(data, p);
+            if (d[p] != '@') bail("Error during FASTQ/A record parsing.");
+            uint64_t e1 = line_end(d, n, p);
             if (e1 >= n) bail("Error during FASTQ/A record parsing.");
             r.id_b = p + 1;
-            r.id_e = strip_cr(data, p + 1, e1);
-            uint64_t e2 = line_end(data, e1 + 1);
+            r.id_e = strip_cr(d, p + 1, e1);
+            uint64_t e2 = line_end(d, n, e1 + 1);
             r.raw_b = e1 + 1;
-            r.raw_e = strip_cr(data, e1 + 1, e2);
-            if (e2 >= n || data[e2 + 1] != '+') bail("Error during FASTQ/A record parsing.");
-            uint64_t e3 = line_end(data, e2 + 1);
+            r.raw_e = strip_cr(d, e1 + 1, e2);
+            if (e2 + 1 >= n || d[e2 + 1] != '+') bail("Error during FASTQ/A record parsing.");
+            uint64_t e3 = line_end(d, n, e2 + 1);
             if (e3 >= n) bail("Error during FASTQ/A record parsing.");
-            uint64_t e4 = line_end(data, e3 + 1);
+            uint64_t e4 = line_end(d, n, e3 + 1);
             r.qual_b = e3 + 1;
-            r.qual_e = strip_cr(data, e3 + 1, e4);
+            r.qual_e = strip_cr(d, e3 + 1, e4);
             if (r.qual_e - r.qual_b != r.raw_e - r.raw_b) bail("Error during FASTQ/A record parsing.");
             p = std::min(e4 + 1, n);
         }
@@ -105,11 +140,68 @@ void FastxFile::parse(const std::string &path) {
     }
 }
 
+// first record start at or after `from` (line-aligned).  FASTQ: a line starting with '@' whose
+// second-next line starts with '+' (a quality line may start with '@', but then the line two
+// below it is a sequence line, which never starts with '+').
+static uint64_t next_record_start(const char *d, uint64_t n, uint64_t from, bool fastq) {
+    uint64_t p = from == 0 ? 0 : std::min(line_end(d, n, from - 1) + 1, n);
+    while (p < n) {
+        if (!fastq) {
+            if (d[p] == '>') return p;
+        } else if (d[p] == '@') {
+            uint64_t e1 = line_end(d, n, p);
+            uint64_t e2 = e1 < n ? line_end(d, n, e1 + 1) : n;
+            if (e2 + 1 < n && d[e2 + 1] == '+') return p;
+        }
+        p = std::min(line_end(d, n, p) + 1, n);
+    }
+    return n;
+}
+
+void FastxFile::parse(const std::string &path) {
+    file.load(path);
+    data = file.p;
+    const uint64_t n = file.n;
+    recs.clear();
+    uint64_t p = 0;
+    while (p < n && (data[p] == '\n' || data[p] == '\r')) ++p;
+    if (p >= n) return;
+    if (data[p] != '>' && data[p] != '@') bail("Error during FASTQ/A record parsing.");
+    fastq = data[p] == '@';
+    // split at record starts and parse the pieces on host threads (the ingest side of the hot path)
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("MERKURIO_IO_THREADS")) hw = (unsigned)atoi(e);
+    uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(hw ? hw : 1), 32, n / (16u << 20) + 1}));
+    std::vector<uint64_t> cut(T + 1);
+    cut[0] = p;
+    cut[T] = n;
+    for (uint64_t t = 1; t < T; ++t) cut[t] = std::max(cut[t - 1], next_record_start(data, n, p + (n - p) * t / T, fastq));
+    std::vector<std::vector<Rec>> parts(T);
+    std::vector<std::string> errs(T);
+    std::vector<std::thread> th;
+    for (uint64_t t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            try {
+                parts[t].reserve((cut[t + 1] - cut[t]) / 200 + 16);
+                parse_fastx_range(data, n, cut[t], cut[t + 1], fastq, parts[t]);
+            } catch (const Error &e) {
+                errs[t] = e.what();
+            }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : errs)
+        if (!e.empty()) bail(e);
+    size_t total = 0;
+    for (auto &v : parts) total += v.size();
+    recs.reserve(total);
+    for (auto &v : parts) recs.insert(recs.end(), v.begin(), v.end());
+}
+
 uint64_t FastxFile::append_seq(size_t i, std::vector<uint8_t> &out) const {
     const Rec &r = recs[i];
     const size_t before = out.size();
     if (fastq) {
-        out.insert(out.end(), data.begin() + r.raw_b, data.begin() + r.raw_e);
+        out.insert(out.end(), data + r.raw_b, data + r.raw_e);
     } else {
         for (uint64_t k = r.raw_b; k < r.raw_e; ++k)
             if (data[k] != '\n' && data[k] != '\r') out.push_back((uint8_t)data[k]);
@@ -117,16 +209,44 @@ uint64_t FastxFile::append_seq(size_t i, std::vector<uint8_t> &out) const {
     return out.size() - before;
 }
 
+void FastxFile::gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const {
+    const size_t nb = b1 - b0;
+    off.resize(nb + 1);
+    off[0] = 0;
+    if (!fastq) {  // FASTA: line breaks have to be squeezed out; few, long records
+        seq.clear();
+        for (size_t i = b0; i < b1; ++i) {
+            append_seq(i, seq);
+            off[i - b0 + 1] = seq.size();
+        }
+        seq.push_back(0);
+        return;
+    }
+    for (size_t i = 0; i < nb; ++i) off[i + 1] = off[i] + raw_len(b0 + i);
+    seq.resize(off[nb] + 1);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("MERKURIO_IO_THREADS")) hw = (unsigned)atoi(e);
+    const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), 32, nb / 65536 + 1}));
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            for (size_t i = nb * t / T; i < nb * (t + 1) / T; ++i)
+                memcpy(seq.data() + off[i], data + recs[b0 + i].raw_b, off[i + 1] - off[i]);
+        });
+    for (auto &x : th) x.join();
+    seq[off[nb]] = 0;
+}
+
 void FastxFile::write(size_t i, Sink &w) const {
     const Rec &r = recs[i];
     w.write(fastq ? "@" : ">", 1);
-    w.write(data.data() + r.id_b, r.id_e - r.id_b);
+    w.write(data + r.id_b, r.id_e - r.id_b);
     w.write("\n", 1);
-    w.write(data.data() + r.raw_b, r.raw_e - r.raw_b);
+    w.write(data + r.raw_b, r.raw_e - r.raw_b);
     w.write("\n", 1);
     if (fastq) {
         w.write("+\n", 2);
-        w.write(data.data() + r.qual_b, r.qual_e - r.qual_b);
+        w.write(data + r.qual_b, r.qual_e - r.qual_b);
         w.write("\n", 1);
     }
 }
@@ -140,19 +260,20 @@ static std::string upper_seq(const std::string &s) {
     return o;
 }
 
-static void parse_sam_text(const std::vector<char> &d, SamFile &out) {
+static void parse_sam_text(const std::vector<char> &dv, SamFile &out) {
     uint64_t p = 0;
-    const uint64_t n = d.size();
+    const uint64_t n = dv.size();
+    const char *d = dv.data();
     while (p < n) {
-        uint64_t e = line_end(d, p);
+        uint64_t e = line_end(d, n, p);
         uint64_t le = strip_cr(d, p, e);
         if (le > p) {
             if (d[p] == '@') {
-                out.header.append(d.data() + p, le - p);
+                out.header.append(d + p, le - p);
                 out.header += '\n';
             } else {
                 SamFile::Rec r;
-                r.line.assign(d.data() + p, le - p);
+                r.line.assign(d + p, le - p);
                 size_t t1 = r.line.find('\t');
                 if (t1 == std::string::npos) bail("Error during SAM record parsing: too few fields");
                 r.name = r.line.substr(0, t1);

@@ -16,8 +16,23 @@ namespace cli {
 std::vector<char> read_file_maybe_gz(const std::string &path);
 
 // ---- FASTA / FASTQ ------------------------------------------------------------------------------
+// a whole input file in memory: mmap for plain files, an inflated copy for gzip
+struct FileBytes {
+    const char *p = nullptr;
+    uint64_t n = 0;
+    std::vector<char> owned;  // gzip path
+    void *map = nullptr;      // mmap path
+    uint64_t map_len = 0;
+    ~FileBytes();
+    void load(const std::string &path);
+    FileBytes() = default;
+    FileBytes(const FileBytes &) = delete;
+    FileBytes &operator=(const FileBytes &) = delete;
+};
+
 struct FastxFile {
-    std::vector<char> data;  // the (decompressed) file
+    FileBytes file;
+    const char *data = nullptr;  // = file.p
     bool fastq = false;
     struct Rec {
         uint64_t id_b, id_e;    // header line without the marker ('>' / '@') and line end
@@ -26,9 +41,14 @@ struct FastxFile {
     };
     std::vector<Rec> recs;
     void parse(const std::string &path);
-    std::string id(size_t i) const { return std::string(data.data() + recs[i].id_b, recs[i].id_e - recs[i].id_b); }
+    std::string id(size_t i) const { return std::string(data + recs[i].id_b, recs[i].id_e - recs[i].id_b); }
     // record.seq(): newline-free sequence appended to `out`; returns num_bases()
     uint64_t append_seq(size_t i, std::vector<uint8_t> &out) const;
+    // sequences of records [b0, b1) concatenated into seq (+1 pad byte) with offsets off[0..b1-b0];
+    // FASTQ records are copied by several host threads
+    void gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const;
+    // number of sequence bytes of record i as stored (upper bound of num_bases)
+    uint64_t raw_len(size_t i) const { return recs[i].raw_e - recs[i].raw_b; }
     // record.write(writer, None): FASTA keeps the original wrapping, FASTQ is 4 lines
     void write(size_t i, Sink &w) const;
 };

@@ -29,7 +29,8 @@ print(f"generated {n} reads ({os.path.getsize(fq) / 1e6:.0f} MB FASTQ) in {time.
 binp = os.path.join(ROOT, "merkurio_amd", "lib", "merkurio")
 for label, extra in (("extract (no log)", []), ("extract -l -j", ["-l", os.path.join(tmp, "e2e.log"), "-j", os.path.join(tmp, "e2e.json")])):
     t0 = time.time()
-    subprocess.run([binp, "extract", "-i", fq, "-f", km, "-o", os.path.join(tmp, "e2e_out"), *extra], check=True)
+    subprocess.run([binp, "extract", "-i", fq, "-f", km, "-o", os.path.join(tmp, "e2e_out"), *extra], check=True,
+                   env=dict(os.environ, MERKURIO_TIMING="1"))
     dt = time.time() - t0
     kept = os.path.getsize(os.path.join(tmp, "e2e_out.fastq")) // (13 + 2 * L + 4)
     print(f"{label}: {dt:.2f} s wall -> {n * L / dt / 1e9:.3f} Gbases/s end to end, {kept} reads extracted", flush=True)
