@@ -1,0 +1,85 @@
+"""Randomised differential test: many small random pattern sets / record batches through the
+GPU path vs the oracle, covering the generic (runtime-q) kernel variants, every stride the
+geometry rule can pick, odd pattern lengths, mixed alphabets, -I, -r/-c pattern lists, forced
+BNDMq / Aho-Corasick emission orders and the global-filter mode."""
+import random
+
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mk():
+    from merkurio_amd import native
+    native.load()
+    if native.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    return native
+
+
+ALPHABETS = [b"ACGT", b"ACGTN", b"ACGTacgt", b"AC", b"ACDEFGHIKLMNPQRSTVWY", b"ACGTRYKMBVDHSWN"]
+
+
+def _case(rnd):
+    alpha = rnd.choice(ALPHABETS)
+    n_pat = rnd.choice([1, 2, 5, 13, 14, 40, 300])
+    base_len = rnd.choice([1, 2, 3, 4, 7, 8, 12, 15, 16, 17, 20, 21, 23, 24, 25, 28, 31, 32, 33, 40, 47, 48, 49, 64, 65, 90])
+    mixed = rnd.random() < 0.3
+    raw = []
+    for _ in range(n_pat):
+        L = max(1, base_len + (rnd.randrange(0, 9) if mixed else 0))
+        raw.append(bytes(rnd.choice(alpha) for _ in range(L)))
+    recs = []
+    for _ in range(rnd.choice([1, 20, 200])):
+        n = rnd.choice([0, 1, base_len - 1 if base_len > 1 else 1, base_len, base_len + 1, 100, 151, 700])
+        s = bytearray(rnd.choice(alpha) for _ in range(n))
+        for _ in range(rnd.choice([0, 0, 1, 2])):
+            p = rnd.choice(raw)
+            if len(p) <= n:
+                k = rnd.randrange(0, n - len(p) + 1)
+                s[k:k + len(p)] = p
+        recs.append(bytes(s))
+    return raw, recs
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_vs_oracle(mk, seed, monkeypatch):
+    rnd = random.Random(1000 + seed)
+    for it in range(60):
+        raw, recs = _case(rnd)
+        kw = dict(reverse_complement=rnd.random() < 0.3, canonical=False, lowercase=False, uppercase=rnd.random() < 0.1)
+        if not kw["reverse_complement"] and rnd.random() < 0.2:
+            kw["canonical"] = True
+        ci = rnd.random() < 0.2
+        rc, patterns = ob.parse_pattern_list(raw, **kw)
+        assert rc == 0 and patterns == mk.parse_pattern_list(kmer_seq=raw, **kw)
+        max_len = max(len(p) for p in patterns)
+        choice = rnd.random()
+        algo, q = mk.MK_ALGO_AUTO, 0
+        if choice < 0.2:
+            algo = mk.MK_ALGO_AC
+        elif choice < 0.4 and max_len <= 64 and not ci:
+            algo, q = mk.MK_ALGO_BNDMQ, rnd.choice([0, 1])
+        if rnd.random() < 0.15:
+            monkeypatch.setenv("MERKURIO_FORCE_GLOBAL_FILTER", "1")
+        else:
+            monkeypatch.delenv("MERKURIO_FORCE_GLOBAL_FILTER", raising=False)
+        m = mk.Matcher(patterns, algo=algo, q=q, case_insensitive=ci)
+        use_ac = m.use_ac
+        assert use_ac == (True if (ci or algo == mk.MK_ALGO_AC) else False if algo == mk.MK_ALGO_BNDMQ
+                          else ob.select_aho_corasick(ci, False, False, patterns))
+        om = ob.Matcher(patterns, use_ac, 0, ci)
+        assert om.rc == 0
+        logging, invert = rnd.random() < 0.8, rnd.random() < 0.3
+        got = m.extract_single(recs, logging=logging, invert=invert)
+        exp = ob.extract_single(om, recs, logging=logging, invert=invert)
+        assert got == exp, (seed, it, patterns[:3], len(recs))
+        if len(recs) >= 2:
+            h = len(recs) // 2
+            assert m.extract_paired(recs[:h], recs[h:2 * h], logging=True) == ob.extract_paired(om, recs[:h], recs[h:2 * h], logging=True)
+        keep, rows, c, found = m.tag_records(recs, logging=logging, filter_matching=rnd.random() < 0.5)
+        keep_o, rows_o, c_o, found_o = ob.tag_records(om, recs, logging=logging, filter_matching=False)
+        assert rows == rows_o and found == [sorted(set(f)) for f in found_o]
