@@ -353,16 +353,18 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     SamFile sam;
     sam.parse(a.in_file);  // "Input file must be a BAM or SAM file." for other extensions
     if (out_ext != "sam" && out_ext != "bam" && out_ext != "STDOUT") bail("Output file must be a BAM or SAM file.");
-    if (out_ext == "bam" && !a.suppress_output)
-        bail("BAM output is not available in this build: give -o a .sam path (the reference leaves BAM output untested, "
-             "src/cmd_tag.rs:1134)");
     Sink w;
-    if (!a.suppress_output) {
+    BamWriter bw;
+    const bool to_bam = out_ext == "bam" && !a.suppress_output;
+    // header + @PG line (src/cmd_tag.rs:509-514)
+    const std::string out_header =
+        sam.header + "@PG\tID:" + kProgram + "\tPN:" + kProgram + "\tCL:" + join(argv) + "\tVN:" + kVersion + "\n";
+    if (to_bam) {
+        bw.open(with_extension(*a.out_file, out_ext), out_header);
+    } else if (!a.suppress_output) {
         w.open(out_ext == "STDOUT" ? "STDOUT" : with_extension(*a.out_file, out_ext));
         if (!w.f) bail("Error writing SAM file: " + with_extension(*a.out_file, out_ext));
-        // header + @PG line (src/cmd_tag.rs:509-514)
-        w.write(sam.header);
-        w.write(std::string("@PG\tID:") + kProgram + "\tPN:" + kProgram + "\tCL:" + join(argv) + "\tVN:" + kVersion + "\n");
+        w.write(out_header);
     }
 
     const size_t n = sam.recs.size();
@@ -418,7 +420,9 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
             mk_check(rc, "Error building tag value");
             break;
         }
-        if (!a.suppress_output) {
+        if (to_bam) {
+            bw.write_record(sam.recs[k].line + "\t" + a.tag + ":Z:" + std::string(val.data(), need));
+        } else if (!a.suppress_output) {
             w.write(sam.recs[k].line);
             w.write("\t" + a.tag + ":Z:");
             w.write(val.data(), need);
@@ -426,6 +430,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         }
     }
     w.flush();
+    bw.close();
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, false);

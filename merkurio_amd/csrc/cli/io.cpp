@@ -434,6 +434,228 @@ void SamFile::parse(const std::string &path) {
         parse_sam_text(d, *this);
 }
 
+// ---- BAM output ---------------------------------------------------------------------------------
+BamWriter::~BamWriter() { close(); }
+
+void BamWriter::put(const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    while (n) {
+        size_t room = 0xff00 - block.size();
+        size_t k = std::min(room, n);
+        block.insert(block.end(), b, b + k);
+        b += k;
+        n -= k;
+        if (block.size() >= 0xff00) flush_block();
+    }
+}
+
+void BamWriter::flush_block() {  // one BGZF member: gzip header with the BC extra field, raw deflate, crc32, isize
+    std::vector<uint8_t> out(block.size() + block.size() / 8 + 1024);
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) bail("Error writing BAM file: zlib init failed");
+    z.next_in = block.data();
+    z.avail_in = (uInt)block.size();
+    z.next_out = out.data() + 18;
+    z.avail_out = (uInt)(out.size() - 26);
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) bail("Error writing BAM file: deflate failed");
+    const size_t clen = z.total_out;
+    deflateEnd(&z);
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(out.data(), hdr, 16);
+    const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
+    memcpy(out.data() + 16, &bsize, 2);
+    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), block.data(), (uInt)block.size());
+    const uint32_t isize = (uint32_t)block.size();
+    memcpy(out.data() + 18 + clen, &crc, 4);
+    memcpy(out.data() + 22 + clen, &isize, 4);
+    if (fwrite(out.data(), 1, clen + 26, f) != clen + 26) bail("Error writing BAM file");
+    block.clear();
+}
+
+void BamWriter::open(const std::string &path, const std::string &header_text) {
+    f = fopen(path.c_str(), "wb");
+    if (!f) bail("Error writing BAM file: " + path);
+    std::vector<uint32_t> ref_len;
+    size_t b = 0;
+    while (b < header_text.size()) {  // @SQ SN:name LN:len
+        size_t e = header_text.find('\n', b);
+        if (e == std::string::npos) e = header_text.size();
+        const std::string ln = header_text.substr(b, e - b);
+        if (ln.rfind("@SQ", 0) == 0) {
+            std::string sn;
+            uint32_t lnv = 0;
+            size_t q = 0;
+            while (q < ln.size()) {
+                size_t t = ln.find('\t', q);
+                if (t == std::string::npos) t = ln.size();
+                if (ln.compare(q, 3, "SN:") == 0) sn = ln.substr(q + 3, t - q - 3);
+                if (ln.compare(q, 3, "LN:") == 0) lnv = (uint32_t)strtoul(ln.c_str() + q + 3, nullptr, 10);
+                q = t + 1;
+            }
+            ref_names.push_back(sn);
+            ref_len.push_back(lnv);
+        }
+        b = e + 1;
+    }
+    put("BAM\1", 4);
+    const int32_t l_text = (int32_t)header_text.size();
+    put(&l_text, 4);
+    put(header_text.data(), header_text.size());
+    const int32_t n_ref = (int32_t)ref_names.size();
+    put(&n_ref, 4);
+    for (int32_t i = 0; i < n_ref; ++i) {
+        const int32_t l_name = (int32_t)ref_names[i].size() + 1;
+        put(&l_name, 4);
+        put(ref_names[i].c_str(), (size_t)l_name);
+        put(&ref_len[i], 4);
+    }
+}
+
+static int reg2bin(int64_t beg, int64_t end) {  // SAM spec 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+void BamWriter::write_record(const std::string &line) {
+    std::vector<std::string> fld;
+    size_t b = 0;
+    for (;;) {
+        size_t e = line.find('\t', b);
+        fld.push_back(line.substr(b, e == std::string::npos ? std::string::npos : e - b));
+        if (e == std::string::npos) break;
+        b = e + 1;
+    }
+    if (fld.size() < 11) bail("Error writing record to output file: too few SAM fields");
+    auto ref_id = [&](const std::string &n) -> int32_t {
+        if (n == "*") return -1;
+        for (size_t i = 0; i < ref_names.size(); ++i)
+            if (ref_names[i] == n) return (int32_t)i;
+        return -1;
+    };
+    std::vector<uint8_t> r;
+    auto add = [&](const void *p, size_t n) { r.insert(r.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    const int32_t rid = ref_id(fld[2]), pos = (int32_t)strtol(fld[3].c_str(), nullptr, 10) - 1;
+    const uint8_t mapq = (uint8_t)strtoul(fld[4].c_str(), nullptr, 10);
+    const uint16_t flag = (uint16_t)strtoul(fld[1].c_str(), nullptr, 10);
+    std::vector<uint32_t> cig;
+    int64_t ref_span = 0;
+    if (fld[5] != "*") {
+        const char *c = fld[5].c_str();
+        while (*c) {
+            char *e;
+            uint32_t len = (uint32_t)strtoul(c, &e, 10);
+            const char *ops = "MIDNSHP=X";
+            const char *o = strchr(ops, *e);
+            if (!o || !*e) bail("Error writing record to output file: bad CIGAR");
+            const uint32_t op = (uint32_t)(o - ops);
+            cig.push_back(len << 4 | op);
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_span += len;
+            c = e + 1;
+        }
+    }
+    const std::string &seq = fld[9];
+    const int32_t l_seq = seq == "*" ? 0 : (int32_t)seq.size();
+    const int32_t next_rid = fld[6] == "=" ? rid : ref_id(fld[6]);
+    const int32_t next_pos = (int32_t)strtol(fld[7].c_str(), nullptr, 10) - 1, tlen = (int32_t)strtol(fld[8].c_str(), nullptr, 10);
+    const uint8_t l_name = (uint8_t)(fld[0].size() + 1);
+    const uint16_t bin = (uint16_t)reg2bin(pos, pos + (ref_span ? ref_span : 1)), n_cig = (uint16_t)cig.size();
+    add(&rid, 4); add(&pos, 4); add(&l_name, 1); add(&mapq, 1); add(&bin, 2); add(&n_cig, 2); add(&flag, 2);
+    add(&l_seq, 4); add(&next_rid, 4); add(&next_pos, 4); add(&tlen, 4);
+    add(fld[0].c_str(), l_name);
+    if (!cig.empty()) add(cig.data(), cig.size() * 4);
+    static const char kSeq[] = "=ACMGRSVTWYHKDBN";
+    for (int32_t k = 0; k < l_seq; k += 2) {
+        auto code = [&](char ch) -> uint8_t {
+            const char *q = strchr(kSeq, ch >= 'a' && ch <= 'z' ? ch - 32 : ch);
+            return q && ch ? (uint8_t)(q - kSeq) : 15;
+        };
+        uint8_t v = (uint8_t)(code(seq[k]) << 4);
+        if (k + 1 < l_seq) v |= code(seq[k + 1]);
+        r.push_back(v);
+    }
+    if (fld[10] == "*") {
+        r.insert(r.end(), (size_t)l_seq, 0xFF);
+    } else {
+        if ((int32_t)fld[10].size() != l_seq) bail("Error writing record to output file: SEQ and QUAL lengths differ");
+        for (char ch : fld[10]) r.push_back((uint8_t)(ch - 33));
+    }
+    for (size_t k = 11; k < fld.size(); ++k) {  // TAG:TYPE:VALUE
+        const std::string &t = fld[k];
+        if (t.size() < 5 || t[2] != ':' || t[4] != ':') bail("Error writing record to output file: bad optional field");
+        add(t.data(), 2);
+        const char type = t[3];
+        const std::string v = t.substr(5);
+        if (type == 'A') {
+            r.push_back('A');
+            r.push_back(v.empty() ? 0 : (uint8_t)v[0]);
+        } else if (type == 'i') {  // smallest integer type that holds the value, like samtools
+            const long long x = strtoll(v.c_str(), nullptr, 10);
+            if (x >= 0) {
+                if (x <= 0xff) { r.push_back('C'); uint8_t y = (uint8_t)x; add(&y, 1); }
+                else if (x <= 0xffff) { r.push_back('S'); uint16_t y = (uint16_t)x; add(&y, 2); }
+                else { r.push_back('I'); uint32_t y = (uint32_t)x; add(&y, 4); }
+            } else {
+                if (x >= -128) { r.push_back('c'); int8_t y = (int8_t)x; add(&y, 1); }
+                else if (x >= -32768) { r.push_back('s'); int16_t y = (int16_t)x; add(&y, 2); }
+                else { r.push_back('i'); int32_t y = (int32_t)x; add(&y, 4); }
+            }
+        } else if (type == 'f') {
+            r.push_back('f');
+            const float y = strtof(v.c_str(), nullptr);
+            add(&y, 4);
+        } else if (type == 'Z' || type == 'H') {
+            r.push_back((uint8_t)type);
+            add(v.c_str(), v.size() + 1);
+        } else if (type == 'B') {
+            r.push_back('B');
+            const char sub = v.empty() ? 'c' : v[0];
+            r.push_back((uint8_t)sub);
+            std::vector<std::string> items;
+            size_t q = 1;
+            while (q < v.size()) {  // ",a,b,c"
+                size_t e = v.find(',', q + 1);
+                items.push_back(v.substr(q + 1, e == std::string::npos ? std::string::npos : e - q - 1));
+                if (e == std::string::npos) break;
+                q = e;
+            }
+            const int32_t cnt = (int32_t)items.size();
+            add(&cnt, 4);
+            for (auto &it : items) {
+                switch (sub) {
+                case 'c': { int8_t y = (int8_t)strtol(it.c_str(), nullptr, 10); add(&y, 1); break; }
+                case 'C': { uint8_t y = (uint8_t)strtoul(it.c_str(), nullptr, 10); add(&y, 1); break; }
+                case 's': { int16_t y = (int16_t)strtol(it.c_str(), nullptr, 10); add(&y, 2); break; }
+                case 'S': { uint16_t y = (uint16_t)strtoul(it.c_str(), nullptr, 10); add(&y, 2); break; }
+                case 'i': { int32_t y = (int32_t)strtol(it.c_str(), nullptr, 10); add(&y, 4); break; }
+                case 'I': { uint32_t y = (uint32_t)strtoul(it.c_str(), nullptr, 10); add(&y, 4); break; }
+                case 'f': { float y = strtof(it.c_str(), nullptr); add(&y, 4); break; }
+                default: bail("Error writing record to output file: bad B array subtype");
+                }
+            }
+        } else {
+            bail("Error writing record to output file: unknown optional field type");
+        }
+    }
+    const int32_t block_size = (int32_t)r.size();
+    put(&block_size, 4);
+    put(r.data(), r.size());
+}
+
+void BamWriter::close() {
+    if (!f) return;
+    if (!block.empty()) flush_block();
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof, 1, sizeof(eof), f);
+    fclose(f);
+    f = nullptr;
+}
+
 int sam_find_tag(const std::string &line, const std::string &tag, std::string *val) {
     size_t b = 0;
     for (int f = 0; f < 11; ++f) {

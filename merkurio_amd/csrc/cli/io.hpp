@@ -64,6 +64,22 @@ struct SamFile {
     std::vector<Rec> recs;
     void parse(const std::string &path);  // by extension: "sam" / "bam" (src/cmd_tag.rs:503-615)
 };
+// BAM writer (BGZF): encodes SAM text lines against the header's @SQ dictionary.  Used for
+// `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.
+struct BamWriter {
+    FILE *f = nullptr;
+    std::vector<uint8_t> block;  // pending uncompressed bytes (< 64 KiB per BGZF block)
+    std::vector<std::string> ref_names;
+    ~BamWriter();
+    void open(const std::string &path, const std::string &header_text);
+    void write_record(const std::string &sam_line);
+    void close();
+
+   private:
+    void put(const void *p, size_t n);
+    void flush_block();
+};
+
 // value of an existing `tag:Z:` field of a SAM line: returns 0 = absent, 1 = Z value in *val,
 // 2 = present with a non-string type (the reference bails: "Invalid tag value format...")
 int sam_find_tag(const std::string &line, const std::string &tag, std::string *val);

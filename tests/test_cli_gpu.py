@@ -153,6 +153,23 @@ def test_example_workflow(golden, tmp_path):
     assert sam_without_own_pg(o) == sam_without_own_pg(os.path.join(wf, "output/mutant_extracted.sorted.tagged.sam"))
 
 
+def test_tag_bam_output_round_trip(golden, tmp_path):
+    """-o x.bam: BGZF/BAM writer; read back through the BAM reader (tag x.bam -> SAM) and compare
+    with the direct SAM output.  (The reference leaves BAM output untested, src/cmd_tag.rs:1134.)"""
+    fx = os.path.join(golden, "fixtures/input")
+    for inp in ("simple.sam", "simple.bam"):
+        run(["tag", "-i", os.path.join(fx, inp), "-o", str(tmp_path / "t.bam"), "-s", "CTC", "-r"])
+        run(["tag", "-i", os.path.join(fx, inp), "-o", str(tmp_path / "direct.sam"), "-s", "CTC", "-r"])
+        # python can gunzip BGZF; the magic and the EOF marker must be in place
+        import gzip
+        raw = open(tmp_path / "t.bam", "rb").read()
+        assert gzip.decompress(raw)[:4] == b"BAM\x01" and raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+        run(["tag", "-i", str(tmp_path / "t.bam"), "-o", str(tmp_path / "back.sam"), "-s", "ZZZZ", "-t", "zz"])
+        back = [ln.rsplit(b"\tzz:Z:", 1)[0] for ln in sam_without_own_pg(tmp_path / "back.sam") if ln and not ln.startswith(b"@")]
+        direct = [ln for ln in sam_without_own_pg(tmp_path / "direct.sam") if ln and not ln.startswith(b"@")]
+        assert back == direct and len(direct) == 3
+
+
 def test_cli_errors(golden, tmp_path):
     fx = os.path.join(golden, "fixtures/input")
     assert run(["extract", "-i", os.path.join(fx, "simple.fasta")], check=False).returncode == 2  # kmers group required
