@@ -36,11 +36,12 @@ constexpr int kChunkBytes = 1024;                          // one wave-iteration
 constexpr int kTileChunks = 31;                            // scanned chunks per wave tile (+1 halo chunk = 32 loads)
 constexpr int kBlockThreads = 1024;                        // 16 waves, one workgroup per CU
 
-// one exact-table slot (8 B, one global_load_dwordx2): a 32-bit fingerprint of the q-gram key
-// and (pattern << 4 | offset of the q-gram inside the pattern).  A fingerprint collision only
-// costs a wasted byte comparison in the resolve kernel.
+// one exact-table slot (8 B): the 32-bit filter hash h of the q-gram key (level 2 is keyed by the
+// hash level 1 has already computed, so a queued candidate is just {h, position}) and
+// (pattern << 4 | offset of the q-gram inside the pattern).  Two keys with the same h only
+// cost a wasted byte comparison in level 3.
 struct alignas(8) TableEntry {
-    uint32_t fp;
+    uint32_t fp;       // = bloom_hash(key)
     uint32_t pat_off;  // kEmptyPat = empty slot
 };
 constexpr uint32_t kMaxPatterns = (1u << 28) - 1;
@@ -48,7 +49,7 @@ constexpr uint32_t kMaxPatterns = (1u << 28) - 1;
 // one whole bucket (2 x global_load_dwordx4, one memory round trip) and moves on to the next
 // bucket only if this one is full.
 constexpr uint32_t kBucketEntries = 4;
-MK_HD uint32_t key_fingerprint(uint64_t key) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u); }
+MK_HD uint32_t table_bucket(uint32_t h, uint32_t bucket_mask) { return ((h * 0x9E3779B1u) >> 6) & bucket_mask; }
 
 MK_HD uint32_t code2(uint8_t c) { return (c >> 1) & 3u; }
 
@@ -78,12 +79,6 @@ MK_HD uint32_t bloom_bit_c(uint32_t h) { return (h >> 17) & 31u; }
 // correlate with the block index.
 MK_HD uint32_t gbloom_block(uint32_t h, uint32_t block_mask) { return (h >> 5) & block_mask; }
 MK_HD uint32_t gbloom_bits(uint32_t h) { return h * 0x9E3779B1u; }  // a,b,c = top three 5-bit groups
-
-// hash for the exact table
-MK_HD uint32_t table_hash(uint64_t key) {
-    uint64_t x = key * 0x9E3779B97F4A7C15ull;
-    return (uint32_t)(x >> 32) ^ (uint32_t)(x >> 11);
-}
 
 MK_HD uint8_t fold_ascii(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c | 0x20) : c; }
 

@@ -185,7 +185,7 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
     m->entries = (uint64_t)n_pat * S;
     uint64_t slots = 64;
     while (slots < 2 * m->entries) slots <<= 1;
-    if (slots > (1ull << 31)) {
+    if (slots > (1ull << 27)) {  // bucket index has 26 bits
         const unsigned long long ne = m->entries;
         delete m;
         return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", ne);
@@ -214,13 +214,13 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
                 bloom[blk] |= 1u << bloom_bit_a(h);
                 bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
             }
-            uint32_t b = table_hash(key) & bmask;
+            uint32_t b = table_bucket(h, bmask);
             for (;;) {  // first bucket from the home bucket on with a free entry
                 TableEntry *e = &table[(size_t)b * kBucketEntries];
                 uint32_t k = 0;
                 while (k < kBucketEntries && e[k].pat_off != kEmptyPat) ++k;
                 if (k < kBucketEntries) {
-                    e[k].fp = key_fingerprint(key);
+                    e[k].fp = h;
                     e[k].pat_off = (pi << 4) | o;
                     break;
                 }
@@ -388,7 +388,7 @@ int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t 
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     if (grid_blocks) *grid_blocks = (uint32_t)m->last_grid;
     if (block_threads) *block_threads = kBlockThreads;
-    if (lds_bytes) *lds_bytes = kBloomBytes + (kBlockThreads / 64) * 128 * 16;
+    if (lds_bytes) *lds_bytes = kBloomBytes + (kBlockThreads / 64) * 128 * 8;
     return MK_OK;
 }
 

@@ -52,14 +52,16 @@ __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ seq, uint64_
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// one filter positive waiting for verification: packed q-gram key + absolute text position
-struct alignas(16) CandEntry {
-    uint64_t key;
-    uint64_t t;
+// one filter positive waiting for level 2: the filter hash of its q-gram (level 2 is keyed by it)
+// and the low 32 bits of its text position (a wave's queued positions span far less than 4 GiB;
+// the high bits are restored from the wave's current position when the entry is taken)
+struct alignas(8) CandEntry {
+    uint32_t h;
+    uint32_t t_lo;
 };
-constexpr uint32_t kRingEntries = 128;  // per wave; < 64 pending before an append of <= 64
-constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry);  // 160 KiB
-static_assert(kLdsBytes == 160 * 1024, "one workgroup owns the whole LDS of its CU");
+constexpr uint32_t kRingEntries = 128;  // per wave; <= 64 pending before an append round of <= 64
+constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry);  // 144 KiB
+static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
 // ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
 // byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
         }
     };
-    auto filter_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt) -> uint32_t {
+    auto filter_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &h0, uint32_t &h1) -> uint32_t {
         const uint32_t w0 = pk_cur;
         uint32_t w1, w2;
         halo(pk_cur, pk_nxt, w1, w2);
@@ -384,6 +386,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             uint32_t h = sample_hash<S, QC>(w0, w1, w2, 2 * j * S, mask_lo, mask_hi);
+            if (j == 0) h0 = h;  // kept for the hand-off when a lane has at most two samples
+            if (j == 1) h1 = h;
             uint2 blk;
             if constexpr ((MK_ABLATE & 2) != 0) {
                 blk = make_uint2(h & 0x10101010u, h);
@@ -414,15 +418,17 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     uint32_t pend_fp = 0, pend_b = 0;
     uint64_t pend_t = 0;
     uint4 pend_v0 = make_uint4(0, 0, 0, 0), pend_v1 = pend_v0;
+    uint64_t newest_end = 0;  // wave-uniform: every queued position is < newest_end (and > newest_end - 4 GiB)
     auto take_from_ring = [&](uint32_t n, bool &active, uint32_t &b, uint32_t &fp, uint64_t &t) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
         __builtin_amdgcn_wave_barrier();
         active = lane < n;
-        b = table_hash(e.key) & P.table_mask;
-        fp = key_fingerprint(e.key);
-        t = e.t;
+        b = table_bucket(e.h, P.table_mask);
+        fp = e.h;
+        t = (newest_end & 0xFFFFFFFF00000000ull) | e.t_lo;
+        if (t >= newest_end) t -= 1ull << 32;
         q_head = (q_head + n) & (kRingEntries - 1);
         q_count -= n;
     };
@@ -448,22 +454,29 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // ---- level 1 -> 2 hand-off (rare): filter positives of one chunk -> per-wave LDS ring
     // (ballot/popcount compaction); 64 at a time they are probed against the exact table, so
     // the L2 round trip is paid once per 64 candidates, not per chunk
-    auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t cand, uint64_t cpos) {
+    auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t cand, uint64_t cpos, uint32_t h0, uint32_t h1) {
         const uint32_t w0 = pk_cur;
-        uint32_t w1, w2;
-        halo(pk_cur, pk_nxt, w1, w2);
+        uint32_t w1 = 0, w2 = 0;
+        if constexpr (NS > 2) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below
+        newest_end = cpos + kChunkBytes;
+        const uint32_t t_base = (uint32_t)cpos + lane * 16;
         uint64_t any = __ballot(cand != 0);
         while (any) {  // wave-uniform
             if (q_count > 64) drain_ring(64);  // an append round adds <= 64 entries to the 128-entry ring
             if (cand != 0) {
                 const uint32_t j = (uint32_t)__ffs(cand) - 1u;
                 cand &= cand - 1;
-                const uint32_t sh = 2u * j * S;
                 CandEntry e;
-                const uint32_t klo = __builtin_amdgcn_alignbit(w1, w0, sh) & mask_lo;  // sh == 0 -> w0
-                const uint32_t khi = __builtin_amdgcn_alignbit(w2, w1, sh) & mask_hi;
-                e.key = ((uint64_t)khi << 32) | klo;
-                e.t = cpos + (lane * 16 + j * S);
+                if constexpr (NS <= 2) {
+                    e.h = j ? h1 : h0;
+                } else {  // same value as sample_hash / filter.hpp's bloom_hash of the masked key
+                    const uint32_t sh = 2u * j * S;
+                    const uint32_t klo = __builtin_amdgcn_alignbit(w1, w0, sh) & mask_lo;  // sh == 0 -> w0
+                    const uint32_t khi = __builtin_amdgcn_alignbit(w2, w1, sh) & mask_hi;
+                    const uint32_t t = __builtin_amdgcn_alignbit(khi, klo, 24);
+                    e.h = __umul24(klo, 0x9E3779u) + __umul24(t, 0x85EBCBu) + (t & 0xFF000000u);
+                }
+                e.t_lo = t_base + j * S;
                 const uint32_t below =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
                 ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
@@ -533,9 +546,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     for (int k = 0; k < 4; ++k) {
                         const int ci = 4 * g + k - 1;
                         if (ci >= 0) {
-                            const uint32_t ck = filter_chunk(pk_prev, q0);
+                            uint32_t h0 = 0, h1 = 0;
+                            const uint32_t ck = filter_chunk(pk_prev, q0, h0, h1);
                             if constexpr ((MK_ABLATE & 4) != 0) n_cand += ck;
-                            if (__ballot(ck != 0)) queue_candidates(pk_prev, q0, ck, base + (uint64_t)ci * kChunkBytes);
+                            if (__ballot(ck != 0)) queue_candidates(pk_prev, q0, ck, base + (uint64_t)ci * kChunkBytes, h0, h1);
                         }
                         pk_prev = q0;
                         q0 = q1;
@@ -545,11 +559,12 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 }
 #else
                 // chunk scanned by pair k is 4g + k - 1; the first pair of a tile straddles tiles
-                uint32_t c0 = filter_chunk(pk_prev, p0);
+                uint32_t ha[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0};
+                uint32_t c0 = filter_chunk(pk_prev, p0, ha[0], hb[0]);
                 if (g == 0) c0 = 0;
-                const uint32_t c1 = filter_chunk(p0, p1);
-                const uint32_t c2 = filter_chunk(p1, p2);
-                const uint32_t c3 = filter_chunk(p2, p3);
+                const uint32_t c1 = filter_chunk(p0, p1, ha[1], hb[1]);
+                const uint32_t c2 = filter_chunk(p1, p2, ha[2], hb[2]);
+                const uint32_t c3 = filter_chunk(p2, p3, ha[3], hb[3]);
                 if constexpr ((MK_ABLATE & 4) != 0) n_cand += c0 + c1 + c2 + c3;
                 if (__ballot((c0 | c1 | c2 | c3) != 0)) {  // rare at useful filter densities
 #pragma unroll 1
@@ -557,8 +572,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                         const uint32_t cur = k == 0 ? pk_prev : k == 1 ? p0 : k == 2 ? p1 : p2;
                         const uint32_t nxt = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
                         const uint32_t ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                        const uint32_t hk0 = k == 0 ? ha[0] : k == 1 ? ha[1] : k == 2 ? ha[2] : ha[3];
+                        const uint32_t hk1 = k == 0 ? hb[0] : k == 1 ? hb[1] : k == 2 ? hb[2] : hb[3];
                         if (__ballot(ck != 0))
-                            queue_candidates(cur, nxt, ck, base + (uint64_t)(4 * g + k - 1) * kChunkBytes);
+                            queue_candidates(cur, nxt, ck, base + (uint64_t)(4 * g + k - 1) * kChunkBytes, hk0, hk1);
                     }
                 }
 #endif
@@ -574,9 +591,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         for (uint64_t cpos = n_main_tiles * kTileBytes; cpos < n_bytes; cpos += kChunkBytes) {
             const uint32_t pk_cur = pack16(load16(seq, cpos + lane * 16, n_bytes));
             const uint32_t pk_nxt = pack16(load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
-            const uint32_t ck = filter_chunk(pk_cur, pk_nxt);
+            uint32_t h0 = 0, h1 = 0;
+            const uint32_t ck = filter_chunk(pk_cur, pk_nxt, h0, h1);
             if constexpr ((MK_ABLATE & 4) != 0) n_cand += ck;
-            if (__ballot(ck != 0)) queue_candidates(pk_cur, pk_nxt, ck, cpos);
+            if (__ballot(ck != 0)) queue_candidates(pk_cur, pk_nxt, ck, cpos, h0, h1);
         }
     }
 

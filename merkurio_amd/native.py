@@ -112,11 +112,13 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     _bind_to_torch_hip_runtime()
-    if build_if_missing and (not os.path.exists(_build.LIB_PATH) or os.environ.get("MERKURIO_REBUILD") == "1"):
+    path = os.environ.get("MERKURIO_LIB_PATH") or _build.LIB_PATH  # override: A/B runs against another build
+    if path == _build.LIB_PATH and build_if_missing and (
+            not os.path.exists(path) or os.environ.get("MERKURIO_REBUILD") == "1"):
         _build.build_lib()  # a present library is used as is (the driver's build() step keeps it fresh)
-    if not os.path.exists(_build.LIB_PATH):
-        raise MerkurioError(MK_E_HIP, f"{_build.LIB_PATH} is missing: run `python -m merkurio_amd.build`")
-    L = C.CDLL(_build.LIB_PATH)
+    if not os.path.exists(path):
+        raise MerkurioError(MK_E_HIP, f"{path} is missing: run `python -m merkurio_amd.build`")
+    L = C.CDLL(path)
     L.mk_last_error.restype = C.c_char_p
     L.mk_matcher_kernel_name.restype = C.c_char_p
     L.mk_matcher_kernel_name.argtypes = [C.c_void_p]
