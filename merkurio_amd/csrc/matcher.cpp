@@ -179,6 +179,7 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         m->num_cus = prop.multiProcessorCount;
 
+    m->uniform_len = (lmin == lmax) ? lmin : 0;
     // ---- compile the pattern set: Bloom filter + exact table
     choose_geometry(lmin, n_pat, &m->q, &m->S, &m->gbloom_blocks);
     const uint32_t q_f = m->q, S = m->S;
@@ -320,6 +321,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.key_mask_lo = (uint32_t)kmask;
     p.key_mask_hi = (uint32_t)(kmask >> 32);
     p.case_insensitive = (m->flags & MK_FLAG_ASCII_CASE_INSENSITIVE) ? 1 : 0;
+    p.uniform_len = m->uniform_len;
     p.rec_flags32 = (uint32_t *)d_rec_flags;
     p.hits = (mk_hit *)d_hits;
     p.hits_cap = (mode == MK_MODE_HITS) ? hits_cap : 0;
@@ -345,6 +347,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));
         m->timed_launches++;
     }
+    if (d_counters) launch_count_flags(p, st);
     m->kernel_name = name;
     m->last_grid = (int)blocks;
     MK_HIP(hipGetLastError());

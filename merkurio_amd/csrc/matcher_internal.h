@@ -17,6 +17,7 @@ struct mk_matcher {
     std::vector<uint8_t> pat_bytes;
     std::vector<uint32_t> pat_off;
     // filter
+    uint32_t uniform_len = 0;  // > 0: all patterns share this length
     uint32_t q = 0, S = 1;
     uint64_t entries = 0;
     uint32_t table_slots = 0;

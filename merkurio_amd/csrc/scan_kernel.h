@@ -35,6 +35,7 @@ struct ScanParams {
     uint32_t key_mask_lo;  // low / high 32 bits of the 2q-bit key mask
     uint32_t key_mask_hi;
     uint32_t case_insensitive;
+    uint32_t uniform_len;  // > 0: every pattern has this length (pattern i starts at i * uniform_len)
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
     // per-scan-wave rings of q-gram hits awaiting resolve_one (global memory, 128 entries each)
     HitCand *wq;
@@ -50,6 +51,9 @@ struct ScanParams {
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
                         hipStream_t stream);
+
+// counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
+void launch_count_flags(const ScanParams &p, hipStream_t stream);
 
 void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
                   const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream);

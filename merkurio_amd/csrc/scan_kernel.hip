@@ -70,8 +70,9 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 template <bool EMIT>
 __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
                                             uint32_t &n_first) {
-    const uint32_t a = P.pat_off[pat];
-    const uint32_t len = P.pat_off[pat + 1] - a;
+    // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
+    const uint32_t a = P.uniform_len ? pat * P.uniform_len : P.pat_off[pat];
+    const uint32_t len = P.uniform_len ? P.uniform_len : P.pat_off[pat + 1] - a;
     if (p + len > P.n_bytes) return;
     const uint8_t *__restrict__ tx = P.seq + p;
     const uint8_t *__restrict__ pt = P.pat_bytes + a;
@@ -145,11 +146,10 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
         rend = P.rec_off[lo + 1];
     }
     if (p + len > rend) return;  // occurrence would cross a record boundary
-    // ---- a true occurrence
-    const uint32_t fsh = (uint32_t)(lo & 3) * 8;
-    const uint32_t old = atomicOr(&P.rec_flags32[lo >> 2], 1u << fsh);
+    // ---- a true occurrence.  The flag is a plain byte store (idempotent; nothing waits for it);
+    // flagged records are counted afterwards by mk_count_flags_kernel when counters are wanted.
+    reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
     n_true++;
-    if (((old >> fsh) & 0xFFu) == 0) n_first++;
     if (P.counters) {
         if (P.n_pat <= 32) {
             // few patterns: a million hits on a handful of addresses would serialise in the
@@ -606,8 +606,41 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
         // uniform addresses: the compiler folds each of these into one atomic per wave
         if (n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
-        if (n_first) atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS_HIT], (unsigned long long)n_first);
     }
+}
+
+// number of records with rec_flags != 0 -> counters[n_pat + MK_SUM_RECORDS_HIT]
+// (flag bytes are 0 or 1; 16-byte loads over the 16-byte aligned middle, bytes at both ends)
+__global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint8_t *__restrict__ flags, uint64_t n_rec,
+                                                             unsigned long long *__restrict__ out) {
+    const uint64_t head = std::min<uint64_t>(n_rec, (16 - ((uintptr_t)flags & 15)) & 15);
+    const uint64_t n16 = (n_rec - head) / 16;
+    const uint4 *__restrict__ v = reinterpret_cast<const uint4 *>(flags + head);
+    unsigned long long c = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {  // four loads in flight per lane
+        const uint4 a = v[i], b = v[i + stride], d = v[i + 2 * stride], e = v[i + 3 * stride];
+        c += __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w) +
+             __popc(d.x) + __popc(d.y) + __popc(d.z) + __popc(d.w) + __popc(e.x) + __popc(e.y) + __popc(e.z) + __popc(e.w);
+    }
+    for (; i < n16; i += stride) {
+        const uint4 a = v[i];
+        c += __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (uint64_t r = 0; r < head; ++r) c += flags[r] != 0;
+        for (uint64_t r = head + n16 * 16; r < n_rec; ++r) c += flags[r] != 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+void launch_count_flags(const ScanParams &p, hipStream_t st) {
+    const uint64_t n16 = p.n_rec / 16;
+    const int blocks = (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, (n16 + 1023) / 1024));
+    hipLaunchKernelGGL(mk_count_flags_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const uint8_t *>(p.rec_flags32),
+                       p.n_rec, p.counters + p.n_pat + MK_SUM_RECORDS_HIT);
 }
 
 template <int S, int QC, bool EMIT, bool GF>
