@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--mode", choices=["any", "hits"], default="any",
                     help="any = per-record flags (extract without logging, the headline); hits = also emit every "
                          "(record, pattern, position) tuple (extract/tag with logging)")
+    ap.add_argument("--no-counters", action="store_true", help="diagnostic: scan without the device counter vector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -120,7 +121,8 @@ def main():
     def step():
         rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec,
                                 mk.MK_MODE_HITS if emit else mk.MK_MODE_ANY, d_flags.data_ptr(),
-                                d_hits.data_ptr() if emit else None, hits_cap, d_nh.data_ptr(), d_cnt.data_ptr(), st)
+                                d_hits.data_ptr() if emit else None, hits_cap, d_nh.data_ptr(),
+                                None if args.no_counters else d_cnt.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(lib.mk_last_error().decode())
 
