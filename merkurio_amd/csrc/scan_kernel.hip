@@ -60,7 +60,8 @@ struct alignas(8) CandEntry {
     uint32_t t_lo;
 };
 constexpr uint32_t kRingEntries = 128;  // per wave; <= 64 pending before an append round of <= 64
-constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry);  // 144 KiB
+constexpr uint32_t kLdsPatCounters = 64;  // pattern sets up to this size count their hits in LDS
+constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) + kLdsPatCounters * 8;  // 144.5 KiB
 static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
 // ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
@@ -69,7 +70,7 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 // hit) and, as overflow fallback, inline by the scan kernel.
 template <bool EMIT>
 __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
-                                            uint32_t &n_first) {
+                                            unsigned long long *lds_pat_cnt) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
     const uint32_t a = P.uniform_len ? pat * P.uniform_len : P.pat_off[pat];
     const uint32_t len = P.uniform_len ? P.uniform_len : P.pat_off[pat + 1] - a;
@@ -151,18 +152,11 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
     n_true++;
     if (P.counters) {
-        if (P.n_pat <= 32) {
-            // few patterns: a million hits on a handful of addresses would serialise in the
-            // atomic unit.  Aggregate per wave: one atomic per distinct pattern among the
-            // lanes that are here (ballot of the active lanes, loop over distinct values).
-            uint64_t todo = __ballot(1);
-            while (todo) {
-                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-                const uint32_t p0 = (uint32_t)__shfl((int)pat, (int)leader);
-                const uint64_t same = __ballot(pat == p0) & todo;
-                if ((threadIdx.x & 63u) == leader) atomicAdd(&P.counters[p0], (unsigned long long)__popcll(same));
-                todo &= ~same;
-            }
+        if (P.n_pat <= kLdsPatCounters) {
+            // few patterns: their counters share a cache line or two, and a million global atomics
+            // on one line serialise in one L2 channel (+0.5 ms at 13 patterns).  Count in LDS,
+            // flush once per workgroup at kernel end.
+            atomicAdd(&lds_pat_cnt[pat], 1ull);
         } else {
             atomicAdd(&P.counters[pat], 1ull);
         }
@@ -192,13 +186,13 @@ struct HitRing {
 
 template <bool EMIT>
 __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint32_t n, uint32_t lane, uint32_t &n_true,
-                                           uint32_t &n_first) {
+                                           unsigned long long *lds_pat_cnt) {
     // entries were stored by other lanes of this wave: same CU, same L1; order the accesses
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (lane < n) {
         const HitCand h = hr.q[(hr.head + lane) & (kHitRing - 1)];
-        resolve_one<EMIT>(P, h.pat, h.p, n_true, n_first);
+        resolve_one<EMIT>(P, h.pat, h.p, n_true, lds_pat_cnt);
     }
     hr.head = (hr.head + n) & (kHitRing - 1);
     hr.count -= n;
@@ -210,7 +204,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
 // hit ring; returns whether this lane must look at the next bucket (its bucket was full).
 template <bool EMIT>
 __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint64_t t, uint4 v0, uint4 v1,
-                                            uint32_t lane, HitRing &hr, uint32_t &n_true, uint32_t &n_first) {
+                                            uint32_t lane, HitRing &hr, uint32_t &n_true, unsigned long long *lds_pat_cnt) {
     const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
     const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
 #pragma unroll
@@ -229,7 +223,7 @@ __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, ui
                 hr.q[(hr.head + hr.count + below) & (kHitRing - 1)] = h;
             }
             hr.count += (uint32_t)__popcll(mm);  // < 64 before, <= 127 now
-            if (hr.count >= 64) drain_hits<EMIT>(P, hr, 64, lane, n_true, n_first);
+            if (hr.count >= 64) drain_hits<EMIT>(P, hr, 64, lane, n_true, lds_pat_cnt);
         }
     }
     return active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
@@ -249,11 +243,11 @@ __device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, ui
 // bucket is full), each iteration one memory round trip
 template <bool EMIT>
 __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint64_t t,
-                                            uint32_t lane, HitRing &hr, uint32_t &n_true, uint32_t &n_first) {
+                                            uint32_t lane, HitRing &hr, uint32_t &n_true, unsigned long long *lds_pat_cnt) {
     while (__ballot(active)) {
         uint4 v0, v1;
         load_bucket(P, active, b, v0, v1);
-        active = probe_round<EMIT>(P, active, fp, t, v0, v1, lane, hr, n_true, n_first);
+        active = probe_round<EMIT>(P, active, fp, t, v0, v1, lane, hr, n_true, lds_pat_cnt);
         b = (b + 1) & P.table_mask;
     }
 }
@@ -328,6 +322,9 @@ template <int S, int QC, bool EMIT, bool GF>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
     using G = Geo<S, QC>;
     __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
+    if (threadIdx.x < kLdsPatCounters)
+        reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2)[threadIdx.x] = 0;
+    if constexpr (GF) __syncthreads();
     if constexpr (!GF) {  // stage the filter image of the pattern set in LDS
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
@@ -356,7 +353,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     hr.q = P.wq + wave_id * (uint64_t)kHitRing;
     hr.head = 0;
     hr.count = 0;
-    uint32_t n_true = 0, n_first = 0;  // per lane: occurrences found / records newly flagged
+    uint32_t n_true = 0;  // per lane: occurrences found
+    unsigned long long *lds_pat_cnt = reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2);
     uint32_t abl_acc = 0;              // ablation builds only
 
     // ---- level 1 for one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
@@ -437,7 +435,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint32_t b, fp;
         uint64_t t;
         take_from_ring(n, active, b, fp, t);
-        probe_chain<EMIT>(P, active, b, fp, t, lane, hr, n_true, n_first);
+        probe_chain<EMIT>(P, active, b, fp, t, lane, hr, n_true, lds_pat_cnt);
     };
     auto issue_probe = [&](uint32_t n) {  // asynchronous: loads only
         take_from_ring(n, pend_active, pend_b, pend_fp, pend_t);
@@ -445,9 +443,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         pend_on = true;
     };
     auto consume_probe = [&]() {
-        const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, n_true, n_first);
+        const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, n_true, lds_pat_cnt);
         if (__ballot(more))  // some home bucket was full: finish those chains synchronously
-            probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, n_true, n_first);
+            probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, n_true, lds_pat_cnt);
         pend_on = false;
     };
 
@@ -600,12 +598,16 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
 
     // drain what is left in this wave's rings
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
-    if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, n_first);
+    if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, lds_pat_cnt);
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
         if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
         // uniform addresses: the compiler folds each of these into one atomic per wave
         if (n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
+    }
+    if (P.counters && P.n_pat <= kLdsPatCounters) {  // flush the workgroup's per-pattern counts
+        __syncthreads();
+        if (threadIdx.x < P.n_pat && lds_pat_cnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x], lds_pat_cnt[threadIdx.x]);
     }
 }
 
