@@ -261,7 +261,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_wq})
+                    (void *)m->d_wq, (void *)m->d_stage})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -308,7 +308,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.rec_off = (const uint64_t *)d_seq_off;
     p.n_rec = n_rec;
     const uint64_t tile_bytes = (uint64_t)kTileChunks * kChunkBytes;
-    p.n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
+    const uint64_t n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
     p.bloom = m->d_bloom;
     p.gbloom_mask = m->gbloom_blocks ? m->gbloom_blocks - 1 : 0;
     p.table = m->d_table;
@@ -328,7 +328,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.n_hits = (unsigned long long *)d_n_hits;
     p.counters = (unsigned long long *)d_counters;
     const uint64_t waves_per_block = kBlockThreads / 64;
-    uint64_t blocks = (p.n_tiles + waves_per_block - 1) / waves_per_block;
+    uint64_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
     // q-gram-hit rings: 128 entries per scan wave (allocated once for the largest grid)
     if (!m->d_wq) {
@@ -337,6 +337,10 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
         m->d_wq_bytes = need;
     }
     p.wq = m->d_wq;
+    if (mode == MK_MODE_HITS && !m->d_stage) {  // staging of verified occurrences, kHitStage per scan wave
+        MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * waves_per_block * kHitStage * sizeof(mk_hit)));
+    }
+    p.stage = m->d_stage;
     p.rec_per_byte = (double)n_rec / (double)n_bytes;
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
@@ -391,7 +395,7 @@ int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t 
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     if (grid_blocks) *grid_blocks = (uint32_t)m->last_grid;
     if (block_threads) *block_threads = kBlockThreads;
-    if (lds_bytes) *lds_bytes = kBloomBytes + (kBlockThreads / 64) * 128 * 8;
+    if (lds_bytes) *lds_bytes = scan_lds_bytes();
     return MK_OK;
 }
 

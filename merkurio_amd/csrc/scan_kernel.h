@@ -16,13 +16,14 @@ struct alignas(16) HitCand {
     uint32_t pad;
 };
 
+constexpr uint32_t kHitStage = 1024;  // tuples a wave stages before it reserves output slots
+
 struct ScanParams {
     // text: concatenated records
     const uint8_t *seq;       // 16-byte aligned
     uint64_t n_bytes;         // == rec_off[n_rec]
     const uint64_t *rec_off;  // n_rec + 1
     uint64_t n_rec;
-    uint64_t n_tiles;  // ceil(n_bytes / (kTileChunks * kChunkBytes))
     // compiled pattern set
     const uint32_t *bloom;    // LDS mode: kBloomWords words; global mode: 2 * (gbloom_mask + 1) words
     uint32_t gbloom_mask;     // global mode: 64-bit-block index mask (0 = LDS mode)
@@ -39,6 +40,8 @@ struct ScanParams {
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
     // per-scan-wave rings of q-gram hits awaiting resolve_one (global memory, 128 entries each)
     HitCand *wq;
+    // per-scan-wave staging of verified occurrences (EMIT kernels; kHitStage tuples each)
+    mk_hit *stage;
     // outputs
     uint32_t *rec_flags32;  // rec_flags viewed as 32-bit words (byte r = record r)
     mk_hit *hits;           // may be null when !EMIT
@@ -51,6 +54,9 @@ struct ScanParams {
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
                         hipStream_t stream);
+
+// static LDS bytes of one scan workgroup (filter + candidate rings + pattern counters)
+uint32_t scan_lds_bytes();
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

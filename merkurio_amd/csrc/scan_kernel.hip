@@ -6,19 +6,25 @@
 // Result set = every (record, pattern, start) occurrence + per-record any-hit flags
 // (bit-exact vs the oracle); emission ORDER is restored on the host (matcher.cpp).
 //
-// Shape of the work (integer, HBM-streaming; no MFMA):
-//   * one persistent 1024-thread workgroup per CU (16 waves); the 128 KiB q-gram Bloom filter
-//     of the pattern set lives in LDS for the life of the workgroup;
-//   * the concatenated text is cut into 16 KiB tiles; a wave walks a tile in 1 KiB chunks:
-//     each lane issues ONE global_load_dwordx4 (64 lanes x 16 B = 1 KiB, fully coalesced) per
-//     chunk, the next chunk's load is in flight while the current one is processed;
-//   * a lane 2-bit-packs its 16 bytes into one dword, gets the 32-base halo from lanes +1/+2
-//     (cross-lane, no LDS memory traffic), forms the 16/S sampled q-gram keys with
-//     v_alignbit, hashes, and probes the LDS filter (one ds_read_b32 per sample);
-//   * filter positives (rare) take a divergent slow path: exact table in L2/HBM -> byte-exact
-//     verification against the pattern text -> binary search of the record offsets ->
-//     boundary check -> flag / hit tuple / counters via atomics (wave-aggregated by the
-//     compiler's atomic optimizer).
+// Shape of the work (integer, HBM-streaming; no MFMA -- DESIGN.md §3/§4):
+//   * one persistent 1024-thread workgroup per CU (16 waves); level 1, the 128 KiB blocked
+//     q-gram Bloom filter of the pattern set, lives in LDS for the life of the workgroup
+//     (pattern sets too large for it use the same filter layout in global memory / L2: GF);
+//   * the concatenated text is cut into 31 KiB tiles dealt round-robin to the 4096 waves; a wave
+//     walks a tile in 1 KiB chunks: each lane issues ONE non-temporal global_load_dwordx4
+//     (64 lanes x 16 B, fully coalesced) per chunk, four chunks (one group) are in flight while
+//     the previous group is filtered;
+//   * a lane 2-bit-packs its 16 bytes into one dword (11 VALU ops), gets the 32-base halo from
+//     lanes +1/+2 by DPP wave_shl (no LDS traffic), forms the 16/S sampled q-gram keys with
+//     v_alignbit, hashes with two 24-bit multiplies and probes the filter with one ds_read_b64
+//     per sample;
+//   * filter positives are compacted (ballot + mbcnt) into a per-wave LDS ring; when the ring
+//     fills, 64 candidates at a time go through level 2 (bucketised exact table in L2, loads
+//     issued at the end of one group and consumed at the top of the next) and level 3
+//     (byte-exact compare, record lookup, boundary check) with all 64 lanes busy;
+//   * results: one byte store per hit record (flags), per-pattern counters (LDS for tiny sets,
+//     global atomics otherwise), optional (record, pattern, position) tuples staged through a
+//     per-wave ring so the output cursor sees one atomic per 64 hits.
 #include <algorithm>
 
 #include "scan_kernel.h"
@@ -66,15 +72,15 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
 // ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
 // byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
-// check, then flag / hit tuple / counters.  Used by the resolve kernel (one lane per q-gram
-// hit) and, as overflow fallback, inline by the scan kernel.
+// check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
+// its tuple in `out`.
 template <bool EMIT>
-__device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt) {
+__device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
+                                            unsigned long long *lds_pat_cnt, mk_hit &out) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
     const uint32_t a = P.uniform_len ? pat * P.uniform_len : P.pat_off[pat];
     const uint32_t len = P.uniform_len ? P.uniform_len : P.pat_off[pat + 1] - a;
-    if (p + len > P.n_bytes) return;
+    if (p + len > P.n_bytes) return false;
     const uint8_t *__restrict__ tx = P.seq + p;
     const uint8_t *__restrict__ pt = P.pat_bytes + a;
     // Everything below that touches memory is independent of everything else, so it is issued
@@ -87,7 +93,7 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
     uint64_t rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];  // seq_off[0] == 0 is part of the ABI
     if (P.case_insensitive) {
         for (uint32_t i = 0; i < len; ++i)
-            if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return;
+            if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return false;
     } else {
         // independent 8-byte (unaligned) loads, no early-exit chain; the clamped offsets of
         // patterns up to 32 bytes (every k-mer) overlap harmlessly
@@ -112,7 +118,7 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
         } else {
             for (uint32_t i = 0; i < len; ++i) diff |= (uint64_t)(tx[i] ^ pt[i]);
         }
-        if (diff) return;
+        if (diff) return false;
     }
     // record containing p: largest r with rec_off[r] <= p.  Wrong guess (ragged records):
     // gallop from it to a bracket, then bisect.
@@ -146,7 +152,7 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
         rstart = P.rec_off[lo];
         rend = P.rec_off[lo + 1];
     }
-    if (p + len > rend) return;  // occurrence would cross a record boundary
+    if (p + len > rend) return false;  // occurrence would cross a record boundary
     // ---- a true occurrence.  The flag is a plain byte store (idempotent; nothing waits for it);
     // flagged records are counted afterwards by mk_count_flags_kernel when counters are wanted.
     reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
@@ -161,16 +167,12 @@ __device__ __forceinline__ void resolve_one(const ScanParams &P, uint32_t pat, u
             atomicAdd(&P.counters[pat], 1ull);
         }
     }
-    if (EMIT) {
-        const unsigned long long idx = atomicAdd(P.n_hits, 1ull);
-        if (idx < P.hits_cap) {
-            mk_hit h;
-            h.rec = lo;
-            h.pat = pat;
-            h.pos = (uint32_t)(p - rstart);
-            P.hits[idx] = h;
-        }
+    if (EMIT) {  // the caller stages the tuple (HitStage)
+        out.rec = lo;
+        out.pat = pat;
+        out.pos = (uint32_t)(p - rstart);
     }
+    return true;
 }
 
 // ---- per-wave ring of q-gram hits (global memory, L2-resident: 128 x 16 B per wave) --------
@@ -182,7 +184,34 @@ struct HitRing {
     HitCand *q;      // this wave's ring
     uint32_t head;   // wave-uniform
     uint32_t count;  // wave-uniform
+    // EMIT: verified occurrences of this wave, staged in global memory and moved to the output
+    // array kHitStage - 64 or more at a time.  The output cursor is ONE address: an atomic on it
+    // costs ~10 ns whoever issues it, so reserving 64 slots per atomic caps the kernel at ~6 G
+    // occurrences/s (every read hitting: 20.8 ms per 100 M reads instead of 10.2 without tuples).
+    mk_hit *stage;
+    uint32_t staged;  // wave-uniform
 };
+
+// move this wave's staged tuples to the output array: one cursor atomic for all of them
+__device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, uint32_t lane) {
+    const uint32_t n = hr.staged;
+    if (n == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(P.n_hits, (unsigned long long)n);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    // the entries were stored by other lanes of this wave (same CU, same L1)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint4 v = reinterpret_cast<const uint4 *>(hr.stage)[i];
+        if (base + i < P.hits_cap) reinterpret_cast<uint4 *>(P.hits)[base + i] = v;
+    }
+    // the next tuples staged must not overtake these reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    hr.staged = 0;
+}
 
 template <bool EMIT>
 __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint32_t n, uint32_t lane, uint32_t &n_true,
@@ -190,12 +219,26 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
     // entries were stored by other lanes of this wave: same CU, same L1; order the accesses
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bool hit = false;
+    mk_hit out;
     if (lane < n) {
         const HitCand h = hr.q[(hr.head + lane) & (kHitRing - 1)];
-        resolve_one<EMIT>(P, h.pat, h.p, n_true, lds_pat_cnt);
+        hit = resolve_one<EMIT>(P, h.pat, h.p, n_true, lds_pat_cnt, out);
     }
     hr.head = (hr.head + n) & (kHitRing - 1);
     hr.count -= n;
+    if constexpr (EMIT) {
+        const uint64_t mm = __ballot(hit);
+        if (mm) {
+            if (hit) {
+                const uint32_t below =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                hr.stage[hr.staged + below] = out;
+            }
+            hr.staged += (uint32_t)__popcll(mm);
+            if (hr.staged > kHitStage - 64) flush_stage(P, hr, lane);  // no room for another full round
+        }
+    }
 }
 
 // ---- level 2: up to 64 filter positives (one per lane) against the exact q-gram table -----
@@ -259,6 +302,9 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 #endif
 #ifndef MK_LOOPV
 #define MK_LOOPV 1  // 1: one looped copy of filter + hand-off per chunk (2 % faster at S=8, tools/loopv_ab.sh); 0: four straight-line filter passes per group
+#endif
+#ifndef MK_STREAM_NT
+#define MK_STREAM_NT 1  // 1: non-temporal stream loads; 0: plain loads (tools/hitpath_ab2.sh: 6 % slower on the headline workload, 12 % faster when every read hits)
 #endif
 #ifndef MK_ISSUE_AT
 #define MK_ISSUE_AT 56  // ring fill at which a group ends with an asynchronous level-2 probe
@@ -353,6 +399,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     hr.q = P.wq + wave_id * (uint64_t)kHitRing;
     hr.head = 0;
     hr.count = 0;
+    hr.stage = EMIT ? P.stage + wave_id * (uint64_t)kHitStage : nullptr;
+    hr.staged = 0;
     uint32_t n_true = 0;  // per lane: occurrences found
     unsigned long long *lds_pat_cnt = reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2);
     uint32_t abl_acc = 0;              // ablation builds only
@@ -499,7 +547,11 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         const uint8_t *ld_ptr = seq + wave_id * kTileBytes + lane * 16;
         auto nt_load = [](const uint8_t *p) -> uint4 {
             // non-temporal: the text is read once; keep L2 for the exact table and the filter image
+#if MK_STREAM_NT
             const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+#else
+            const u32x4 nv = *reinterpret_cast<const u32x4 *>(p);
+#endif
             return make_uint4(nv.x, nv.y, nv.z, nv.w);
         };
         // four loads off one address register (immediate offsets); the tile wrap is checked
@@ -599,6 +651,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // drain what is left in this wave's rings
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
     if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, lds_pat_cnt);
+    if constexpr (EMIT) flush_stage(P, hr, lane);
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
         if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
@@ -644,6 +697,8 @@ __global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint8_t *__re
         if (t) atomicAdd(out, t);
     }
 }
+
+uint32_t scan_lds_bytes() { return kLdsBytes; }
 
 void launch_count_flags(const ScanParams &p, hipStream_t st) {
     const uint64_t n16 = p.n_rec / 16;
