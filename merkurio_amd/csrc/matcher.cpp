@@ -67,19 +67,34 @@ static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t
         *S = 1;
         return;
     }
-    // Large set: the filter moves to global memory (L2 / Infinity Cache resident), where
-    // every sample costs a random 8-byte read -> take the largest stride that keeps the
-    // q-grams selective (q >= 16) and the filter at most 256 MiB.
+    // Large set: the filter moves to global memory, where every sample costs a random 8-byte
+    // read.  The L2 serves one request per channel and clock: ~270 G probes/s while the filter
+    // stays within the 4 MiB of an XCD's L2, 120 G/s at 8 MiB, 56 G/s from HBM
+    // (profiles/r01_gather_rate.txt) -- and the scan runs at that limit (S=4: 781 M probes in
+    // 2.85 ms).  So: the largest stride whose filter (8 entries per 64-bit block) still fits in
+    // L2 and whose q-grams keep 14 bases (S=8, q=14 on 500 k 21-mers: 3.35 ms against 3.85 ms
+    // at S=4, tools/c5_stride8.sh); failing that, the largest stride with q >= 16.
     *q = std::min<uint32_t>(32, lmin);
     *S = 1;
+    bool chosen = false;
     for (uint32_t s : {16u, 8u, 4u, 2u}) {
         if (s > lmin) continue;
         const uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
-        if (forced ? (int)s != forced : (qq < 16 || n_pat * s * 4 > (1ull << 25))) continue;
+        if (forced ? (int)s != forced : (qq < 14 || n_pat * s > (8ull << 19))) continue;
         *q = qq;
         *S = s;
+        chosen = true;
         break;
     }
+    if (!chosen && !forced)
+        for (uint32_t s : {16u, 8u, 4u, 2u}) {
+            if (s > lmin) continue;
+            const uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
+            if (qq < 16 || n_pat * s * 4 > (1ull << 25)) continue;
+            *q = qq;
+            *S = s;
+            break;
+        }
     // Filter size: measured with 500 k 21-mers (2 M entries, profiles/r01_gbloom_sweep.txt) a
     // 2 MiB image (8 entries per 64-bit block, 1.2 % of samples pass) is fastest because it
     // stays resident in the 4 MiB XCD L2; 8 MiB (0.09 % pass) is 1.8x slower.  ~8 entries/block.

@@ -720,7 +720,8 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
                         hipStream_t stream) {
     if (global_filter) {  // large pattern sets: filter blocks in global memory
-        if (S == 4 && p.q == 18) MK_VARIANT(4, 18, true);  // 21-mers
+        if (S == 8 && p.q == 14) MK_VARIANT(8, 14, true);  // 21-mers
+        if (S == 4 && p.q == 18) MK_VARIANT(4, 18, true);
         if (S == 8 && p.q == 24) MK_VARIANT(8, 24, true);  // 31-mers
         if (wide) switch (S) {
                 case 1: MK_VARIANT(1, -1, true);

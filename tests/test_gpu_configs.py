@@ -81,13 +81,22 @@ def test_config4_scaled_tag(mk):
     assert sum(keep) >= 1000
 
 
-def test_config5_large_pattern_set(mk):
-    """500 k 21-mers: the set no longer fits the LDS filter (every stride but 1 is too dense);
-    correctness must hold regardless"""
+@pytest.mark.parametrize("stride", [None, 4])
+def test_config5_large_pattern_set(mk, stride, monkeypatch):
+    """500 k 21-mers: the set no longer fits the LDS filter; the filter moves to global memory
+    (stride 8, 14-base q-grams, 4 MiB: the largest L2-resident geometry; stride 4 is the
+    18-base alternative).  Correctness must hold regardless"""
+    if stride:
+        monkeypatch.setenv("MERKURIO_FORCE_STRIDE", str(stride))
     patterns = mk.parse_pattern_list(kmer_seq=_kmers(500_000, 21, 5))
     recs = _reads(20_000, 250, 51, plant=patterns, every=10)
     m = mk.Matcher(patterns)
-    assert m.use_ac and m.filter_mode()["in_lds"] is False and m.filter_info()["stride"] == 4
+    assert m.use_ac and m.filter_mode()["in_lds"] is False
+    if stride is None:
+        assert m.filter_info()["stride"] == 8 and m.filter_info()["q_gram"] == 14
+        assert m.filter_mode()["filter_bytes"] == 4 << 20
+    else:
+        assert m.filter_info()["stride"] == stride
     om = ob.Matcher(patterns, True, 0, False)
     assert m.extract_single(recs, logging=True) == ob.extract_single(om, recs, logging=True)
 
