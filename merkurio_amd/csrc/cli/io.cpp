@@ -12,6 +12,106 @@
 
 namespace cli {
 
+unsigned io_threads() {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("MERKURIO_IO_THREADS")) hw = (unsigned)atoi(e);
+    return std::max(1u, std::min(hw ? hw : 1u, 32u));
+}
+
+// BGZF = a series of gzip members, each with the extra subfield 'B','C' holding the member's
+// size (SAM spec 4.1).  Walk the member headers, size the output from the ISIZE trailers, then
+// inflate the members independently.  Returns false (out untouched) if the file is not BGZF all
+// the way through -- the caller falls back to the serial gzip reader.
+static bool inflate_bgzf_parallel(const std::string &path, std::vector<char> &out) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) {
+        close(fd);
+        return false;
+    }
+    const size_t n = (size_t)st.st_size;
+    void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    const uint8_t *d = (const uint8_t *)m;
+    struct Member {
+        size_t data_off, data_len;  // raw deflate stream
+        size_t out_off;
+        uint32_t isize, crc;
+    };
+    std::vector<Member> mem;
+    size_t p = 0, total = 0;
+    bool ok = true;
+    while (p < n) {
+        if (n - p < 18 || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) {
+            ok = false;
+            break;
+        }
+        const size_t xlen = d[p + 10] | (size_t)d[p + 11] << 8;
+        if (n - p < 12 + xlen + 8) {
+            ok = false;
+            break;
+        }
+        size_t bsize = 0;
+        for (size_t x = p + 12; x + 4 <= p + 12 + xlen;) {  // extra subfields
+            const size_t slen = d[x + 2] | (size_t)d[x + 3] << 8;
+            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= p + 12 + xlen) bsize = (d[x + 4] | (size_t)d[x + 5] << 8) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || (d[p + 3] & ~4) || n - p < bsize) {  // other header flags: not BGZF as written by anyone
+            ok = false;
+            break;
+        }
+        Member b;
+        b.data_off = p + 12 + xlen;
+        b.data_len = bsize - (12 + xlen) - 8;
+        memcpy(&b.crc, d + p + bsize - 8, 4);
+        memcpy(&b.isize, d + p + bsize - 4, 4);
+        b.out_off = total;
+        total += b.isize;
+        mem.push_back(b);
+        p += bsize;
+    }
+    if (!ok || mem.empty()) {
+        munmap(m, n);
+        return false;
+    }
+    out.resize(total);
+    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), mem.size() / 16 + 1));
+    std::vector<int> bad(T, 0);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            z_stream z;
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, -15) != Z_OK) {
+                bad[t] = 1;
+                return;
+            }
+            for (size_t i = mem.size() * t / T; i < mem.size() * (t + 1) / T; ++i) {
+                const Member &b = mem[i];
+                inflateReset(&z);
+                z.next_in = const_cast<Bytef *>(d + b.data_off);
+                z.avail_in = (uInt)b.data_len;
+                z.next_out = (Bytef *)out.data() + b.out_off;
+                z.avail_out = b.isize;
+                const int r = inflate(&z, Z_FINISH);
+                if ((r != Z_STREAM_END && !(b.isize == 0 && r == Z_BUF_ERROR)) || z.avail_out != 0 ||
+                    (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef *)out.data() + b.out_off, b.isize) != b.crc) {
+                    bad[t] = 1;
+                    break;
+                }
+            }
+            inflateEnd(&z);
+        });
+    for (auto &x : th) x.join();
+    munmap(m, n);
+    for (int b : bad)
+        if (b) bail("Error while decompressing " + path);
+    return true;
+}
+
 std::vector<char> read_file_maybe_gz(const std::string &path) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) bail("No such file or directory: " + path);
@@ -24,7 +124,11 @@ std::vector<char> read_file_maybe_gz(const std::string &path) {
         bail("xz input is not supported by this build (gzip and plain text are): " + path);
     if (got >= 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD)
         bail("zstd input is not supported by this build (gzip and plain text are): " + path);
-    // gzopen reads plain files transparently and walks concatenated gzip members (BGZF)
+    {  // BGZF (BAM, bgzip'ed FASTQ): independent <= 64 KiB members, inflated on every host thread
+        std::vector<char> out;
+        if (inflate_bgzf_parallel(path, out)) return out;
+    }
+    // gzopen reads plain files transparently and walks concatenated gzip members
     gzFile g = gzopen(path.c_str(), "rb");
     if (!g) bail("Cannot open " + path);
     gzbuffer(g, 1 << 20);
@@ -449,13 +553,14 @@ void BamWriter::put(const void *p, size_t n) {
     }
 }
 
-void BamWriter::flush_block() {  // one BGZF member: gzip header with the BC extra field, raw deflate, crc32, isize
-    std::vector<uint8_t> out(block.size() + block.size() / 8 + 1024);
+// one BGZF member: gzip header with the BC extra field, raw deflate, crc32, isize
+static void bgzf_compress(const std::vector<uint8_t> &in, std::vector<uint8_t> &out) {
+    out.resize(in.size() + in.size() / 8 + 1024);
     z_stream z;
     memset(&z, 0, sizeof(z));
     if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) bail("Error writing BAM file: zlib init failed");
-    z.next_in = block.data();
-    z.avail_in = (uInt)block.size();
+    z.next_in = const_cast<Bytef *>(in.data());
+    z.avail_in = (uInt)in.size();
     z.next_out = out.data() + 18;
     z.avail_out = (uInt)(out.size() - 26);
     if (deflate(&z, Z_FINISH) != Z_STREAM_END) bail("Error writing BAM file: deflate failed");
@@ -465,12 +570,42 @@ void BamWriter::flush_block() {  // one BGZF member: gzip header with the BC ext
     memcpy(out.data(), hdr, 16);
     const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
     memcpy(out.data() + 16, &bsize, 2);
-    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), block.data(), (uInt)block.size());
-    const uint32_t isize = (uint32_t)block.size();
+    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), in.data(), (uInt)in.size());
+    const uint32_t isize = (uint32_t)in.size();
     memcpy(out.data() + 18 + clen, &crc, 4);
     memcpy(out.data() + 22 + clen, &isize, 4);
-    if (fwrite(out.data(), 1, clen + 26, f) != clen + 26) bail("Error writing BAM file");
-    block.clear();
+    out.resize(clen + 26);
+}
+
+// full blocks are collected and compressed a batch at a time on every host thread (deflate is
+// the slow side of BAM output: ~50 MB/s per core); the members are written in order
+void BamWriter::flush_block() {
+    pending.emplace_back();
+    pending.back().swap(block);
+    block.reserve(0xff00);
+    if (pending.size() >= 8 * (size_t)io_threads()) flush_pending();
+}
+
+void BamWriter::flush_pending() {
+    if (pending.empty()) return;
+    std::vector<std::vector<uint8_t>> outs(pending.size());
+    const size_t T = std::min<size_t>(io_threads(), pending.size());
+    std::vector<std::string> errs(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            try {
+                for (size_t i = t; i < pending.size(); i += T) bgzf_compress(pending[i], outs[i]);
+            } catch (const Error &e) {
+                errs[t] = e.what();
+            }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : errs)
+        if (!e.empty()) bail(e);
+    for (auto &o : outs)
+        if (fwrite(o.data(), 1, o.size(), f) != o.size()) bail("Error writing BAM file");
+    pending.clear();
 }
 
 void BamWriter::open(const std::string &path, const std::string &header_text) {
@@ -650,6 +785,7 @@ void BamWriter::write_record(const std::string &line) {
 void BamWriter::close() {
     if (!f) return;
     if (!block.empty()) flush_block();
+    flush_pending();
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, sizeof(eof), f);
     fclose(f);

@@ -11,7 +11,10 @@
 
 namespace cli {
 
-// whole file into memory; transparently inflates gzip / BGZF (magic 1f 8b).  bz2 / xz / zstd
+// host threads for ingest / codec work: hardware concurrency, capped at 32, MERKURIO_IO_THREADS overrides
+unsigned io_threads();
+
+// whole file into memory; transparently inflates gzip (magic 1f 8b); BGZF members in parallel.  bz2 / xz / zstd
 // inputs are recognised and rejected with a clear message (no such libraries in this build).
 std::vector<char> read_file_maybe_gz(const std::string &path);
 
@@ -68,7 +71,8 @@ struct SamFile {
 // `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.
 struct BamWriter {
     FILE *f = nullptr;
-    std::vector<uint8_t> block;  // pending uncompressed bytes (< 64 KiB per BGZF block)
+    std::vector<uint8_t> block;  // uncompressed bytes of the block being filled (< 64 KiB per BGZF block)
+    std::vector<std::vector<uint8_t>> pending;  // full blocks waiting for the next parallel deflate
     std::vector<std::string> ref_names;
     ~BamWriter();
     void open(const std::string &path, const std::string &header_text);
@@ -78,6 +82,7 @@ struct BamWriter {
    private:
     void put(const void *p, size_t n);
     void flush_block();
+    void flush_pending();
 };
 
 // value of an existing `tag:Z:` field of a SAM line: returns 0 = absent, 1 = Z value in *val,

@@ -170,6 +170,64 @@ def test_tag_bam_output_round_trip(golden, tmp_path):
         assert back == direct and len(direct) == 3
 
 
+def _bgzf(data, block=0xff00):
+    """data as BGZF (SAM spec 4.1): independent gzip members with the BC extra field + EOF marker"""
+    import struct
+    import zlib
+    out = bytearray()
+    for b in range(0, len(data), block):
+        chunk = data[b:b + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = co.compress(chunk) + co.flush()
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(c) + 25)
+        out += c + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return bytes(out) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def test_bgzf_input_and_large_bam_round_trip(tmp_path):
+    """many-member BGZF inputs take the parallel inflate path; BAM output of many blocks takes the
+    parallel deflate path.  Results must equal those of the plain-text inputs / SAM output."""
+    import gzip
+    import random
+    rnd = random.Random(11)
+    kmers = ["".join(rnd.choice("ACGT") for _ in range(21)) for _ in range(40)]
+    reads = []
+    for i in range(30000):
+        s = "".join(rnd.choice("ACGT") for _ in range(rnd.choice((80, 100, 151))))
+        if i % 9 == 0:
+            k = rnd.choice(kmers)
+            o = rnd.randrange(len(s) - 21)
+            s = s[:o] + k + s[o + 21:]
+        reads.append(s)
+    fq = "".join(f"@r{i} x\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(reads)).encode()
+    (tmp_path / "k.txt").write_text("\n".join(kmers) + "\n")
+    (tmp_path / "plain.fastq").write_bytes(fq)
+    (tmp_path / "bgzf.fastq.gz").write_bytes(_bgzf(fq))
+    (tmp_path / "mono.fastq.gz").write_bytes(gzip.compress(fq, 1))  # ordinary single-member gzip: serial path
+    outs = {}
+    for name in ("plain.fastq", "bgzf.fastq.gz", "mono.fastq.gz"):
+        run(["extract", "-i", str(tmp_path / name), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / ("o_" + name.split(".")[0])),
+             "-l", str(tmp_path / (name + ".log"))])
+        body = log_body(tmp_path / (name + ".log")).replace(name.encode() + b"\t", b"<file>\t")  # rows start with the file name
+        outs[name] = (open(tmp_path / ("o_" + name.split(".")[0] + ".fastq"), "rb").read(), body)
+    assert outs["plain.fastq"][0].count(b"\n") >= 4 * 3000
+    assert outs["bgzf.fastq.gz"] == outs["plain.fastq"] == outs["mono.fastq.gz"]
+    # SAM (30 k unmapped records, ~5 MB) -> tagged BAM (dozens of BGZF blocks) -> back to SAM
+    sam = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:100000\n" + "".join(
+        f"r{i}\t4\t*\t0\t0\t*\t*\t0\t0\t{s}\t{'I' * len(s)}\tNM:i:{i % 7}\n" for i, s in enumerate(reads))
+    (tmp_path / "in.sam").write_text(sam)
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "direct.sam")])
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "t.bam")])
+    raw = open(tmp_path / "t.bam", "rb").read()
+    assert raw.count(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0])) > 20
+    assert gzip.decompress(raw)[:4] == b"BAM\x01"
+    run(["tag", "-i", str(tmp_path / "t.bam"), "-s", "ZZZZ", "-t", "zz", "-o", str(tmp_path / "back.sam")])
+    back = [ln.rsplit(b"\tzz:Z:", 1)[0] for ln in sam_without_own_pg(tmp_path / "back.sam") if ln and not ln.startswith(b"@")]
+    direct = [ln for ln in sam_without_own_pg(tmp_path / "direct.sam") if ln and not ln.startswith(b"@")]
+    assert back == direct and len(direct) == 30000
+    assert sum(1 for ln in direct if b"\tkm:Z:" in ln) >= 3000
+
+
 def test_cli_errors(golden, tmp_path):
     fx = os.path.join(golden, "fixtures/input")
     assert run(["extract", "-i", os.path.join(fx, "simple.fasta")], check=False).returncode == 2  # kmers group required
