@@ -348,10 +348,13 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     }
     if (lg.active) write_log_header(lg.text, "tag", argv, &a.tag, pats.list.size(), a.invert_match);
     bool use_ac = false;
+    PhaseTimer tm;
     mk_matcher *m = make_matcher(a, pats, &use_ac);
+    tm.mark("matcher");
 
     SamFile sam;
     sam.parse(a.in_file);  // "Input file must be a BAM or SAM file." for other extensions
+    tm.mark("parse");
     if (out_ext != "sam" && out_ext != "bam" && out_ext != "STDOUT") bail("Output file must be a BAM or SAM file.");
     Sink w;
     BamWriter bw;
@@ -359,8 +362,11 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     // header + @PG line (src/cmd_tag.rs:509-514)
     const std::string out_header =
         sam.header + "@PG\tID:" + kProgram + "\tPN:" + kProgram + "\tCL:" + join(argv) + "\tVN:" + kVersion + "\n";
-    if (to_bam) {
-        bw.open(with_extension(*a.out_file, out_ext), out_header);
+    if (to_bam) {  // BAM -> BAM passes raw records through: they keep the input's reference ids
+        if (sam.is_bam)
+            bw.open(with_extension(*a.out_file, out_ext), out_header, &sam.ref_names, &sam.ref_lens);
+        else
+            bw.open(with_extension(*a.out_file, out_ext), out_header);
     } else if (!a.suppress_output) {
         w.open(out_ext == "STDOUT" ? "STDOUT" : with_extension(*a.out_file, out_ext));
         if (!w.f) bail("Error writing SAM file: " + with_extension(*a.out_file, out_ext));
@@ -369,12 +375,9 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
 
     const size_t n = sam.recs.size();
     std::vector<uint8_t> seq;
-    std::vector<uint64_t> off(1, 0);
-    for (auto &r : sam.recs) {
-        seq.insert(seq.end(), r.seq.begin(), r.seq.end());
-        off.push_back(seq.size());
-    }
-    seq.push_back(0);
+    std::vector<uint64_t> off;
+    sam.gather(seq, off);
+    tm.mark("gather sequences");
     mk_counters c;
     memset(&c, 0, sizeof(c));
     std::vector<uint32_t> counts(pats.list.size(), 0);
@@ -396,41 +399,81 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         mk_check(rc, "Error during matching");
         break;
     }
+    tm.mark("scan");
     if (lg.active)
         for (uint64_t k = 0; k < n_rows; ++k) {
             const mk_row &r = rows[k];
-            lg.text.row(in_name, sam.recs[r.rec].name, pats.list[r.pat], r.pos);
-            if (lg.has_json) lg.json.row(in_name, sam.recs[r.rec].name, pats.list[r.pat], r.pos);
+            const std::string name = sam.name(r.rec);
+            lg.text.row(in_name, name, pats.list[r.pat], r.pos);
+            if (lg.has_json) lg.json.row(in_name, name, pats.list[r.pat], r.pos);
         }
-    // tag + write kept records (src/cmd_tag.rs:457-497)
-    std::vector<char> val(4096);
-    for (size_t k = 0; k < n; ++k) {
-        if (!keep[k]) continue;
-        std::string existing;
-        const int has = sam_find_tag(sam.recs[k].line, a.tag, &existing);
-        if (has == 2) bail("Invalid tag value format. Expected string value.");
-        size_t need = 0;
-        for (;;) {
-            int rc = mk_tag_value(m, fpat.data() + foff[k], foff[k + 1] - foff[k], has == 1 ? existing.c_str() : nullptr, val.data(),
-                                  val.size(), &need);
-            if (rc == MK_E_CAPACITY) {
-                val.resize(need + 1);
-                continue;
+    // tag + write kept records (src/cmd_tag.rs:457-497): tag values and output encoding are built
+    // on every host thread, a slab of records at a time, and written in record order
+    std::vector<size_t> kept;
+    kept.reserve(n);
+    for (size_t k = 0; k < n; ++k)
+        if (keep[k]) kept.push_back(k);
+    const size_t kSlab = 1 << 17;
+    for (size_t c0 = 0; c0 < kept.size() && !a.suppress_output; c0 += kSlab) {
+        const size_t c1 = std::min(kept.size(), c0 + kSlab);
+        const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (c1 - c0) / 4096 + 1));
+        std::vector<std::vector<uint8_t>> bin(to_bam ? T : 0);
+        std::vector<std::string> txt(to_bam ? 0 : T);
+        run_threads(T, [&](size_t t) {
+            std::vector<char> val(4096);
+            std::string line;
+            for (size_t i = c0 + (c1 - c0) * t / T; i < c0 + (c1 - c0) * (t + 1) / T; ++i) {
+                const size_t k = kept[i];
+                std::string existing;
+                const int has = sam.find_tag(k, a.tag, &existing);
+                if (has == 2) bail("Invalid tag value format. Expected string value.");
+                size_t need = 0;
+                for (;;) {
+                    int rc = mk_tag_value(m, fpat.data() + foff[k], foff[k + 1] - foff[k], has == 1 ? existing.c_str() : nullptr,
+                                          val.data(), val.size(), &need);
+                    if (rc == MK_E_CAPACITY) {
+                        val.resize(need + 1);
+                        continue;
+                    }
+                    mk_check(rc, "Error building tag value");
+                    break;
+                }
+                if (to_bam && sam.is_bam) {
+                    BamWriter::append_tagged_raw(sam.raw(k), sam.raw_len(k), a.tag, val.data(), need, bin[t]);
+                } else if (to_bam) {
+                    line.clear();
+                    sam.append_line(k, line);
+                    line += '\t';
+                    line += a.tag;
+                    line += ":Z:";
+                    line.append(val.data(), need);
+                    bw.encode_record(line, bin[t]);
+                } else {
+                    std::string &o = txt[t];
+                    sam.append_line(k, o);
+                    o += '\t';
+                    o += a.tag;
+                    o += ":Z:";
+                    o.append(val.data(), need);
+                    o += '\n';
+                }
             }
-            mk_check(rc, "Error building tag value");
-            break;
-        }
-        if (to_bam) {
-            bw.write_record(sam.recs[k].line + "\t" + a.tag + ":Z:" + std::string(val.data(), need));
-        } else if (!a.suppress_output) {
-            w.write(sam.recs[k].line);
-            w.write("\t" + a.tag + ":Z:");
-            w.write(val.data(), need);
-            w.write("\n", 1);
+        });
+        for (size_t t = 0; t < T; ++t) {
+            if (to_bam)
+                bw.put_encoded(bin[t]);
+            else
+                w.write(txt[t]);
         }
     }
+    if (a.suppress_output)  // the reference still validates existing tags of kept records
+        for (size_t k : kept) {
+            std::string existing;
+            if (sam.find_tag(k, a.tag, &existing) == 2) bail("Invalid tag value format. Expected string value.");
+        }
     w.flush();
     bw.close();
+    tm.mark("write");
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, false);

@@ -1,6 +1,7 @@
 #include "io.hpp"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -8,14 +9,41 @@
 
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <thread>
 
 namespace cli {
 
+// MERKURIO_TIMING=1: wall time of the codec phases on stderr
+static void io_mark(const char *what) {
+    static const bool on = getenv("MERKURIO_TIMING") != nullptr;
+    static double t0 = 0;
+    if (!on) return;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t = ts.tv_sec + ts.tv_nsec * 1e-9;
+    if (what && t0 > 0) fprintf(stderr, "[timing]   io: %-22s %8.3f s\n", what, t - t0);
+    t0 = t;
+}
+
 unsigned io_threads() {
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("MERKURIO_IO_THREADS")) hw = (unsigned)atoi(e);
-    return std::max(1u, std::min(hw ? hw : 1u, 32u));
+    static const unsigned cached = [] {
+        if (const char *e = getenv("MERKURIO_IO_THREADS")) return (unsigned)std::max(1, atoi(e));
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        // containers: the cgroup CPU quota, not the machine's core count, is what this process gets
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            long long period = 0;
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+                hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, atoll(q) / period));
+            fclose(f);
+        }
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
+        return std::min(hw, 32u);
+    }();
+    return cached;
 }
 
 // BGZF = a series of gzip members, each with the extra subfield 'B','C' holding the member's
@@ -273,9 +301,7 @@ void FastxFile::parse(const std::string &path) {
     if (data[p] != '>' && data[p] != '@') bail("Error during FASTQ/A record parsing.");
     fastq = data[p] == '@';
     // split at record starts and parse the pieces on host threads (the ingest side of the hot path)
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("MERKURIO_IO_THREADS")) hw = (unsigned)atoi(e);
-    uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(hw ? hw : 1), 32, n / (16u << 20) + 1}));
+    uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)io_threads(), n / (16u << 20) + 1));
     std::vector<uint64_t> cut(T + 1);
     cut[0] = p;
     cut[T] = n;
@@ -328,9 +354,7 @@ void FastxFile::gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vec
     }
     for (size_t i = 0; i < nb; ++i) off[i + 1] = off[i] + raw_len(b0 + i);
     seq.resize(off[nb] + 1);
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("MERKURIO_IO_THREADS")) hw = (unsigned)atoi(e);
-    const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), 32, nb / 65536 + 1}));
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)io_threads(), nb / 65536 + 1));
     std::vector<std::thread> th;
     for (size_t t = 0; t < T; ++t)
         th.emplace_back([&, t] {
@@ -356,43 +380,58 @@ void FastxFile::write(size_t i, Sink &w) const {
 }
 
 // ---- SAM / BAM ------------------------------------------------------------------------------------
-static std::string upper_seq(const std::string &s) {
-    if (s == "*") return "";
-    std::string o = s;
-    for (auto &c : o)
-        if (c >= 'a' && c <= 'z') c = (char)(c & ~0x20);
-    return o;
-}
-
-static void parse_sam_text(const std::vector<char> &dv, SamFile &out) {
-    uint64_t p = 0;
-    const uint64_t n = dv.size();
-    const char *d = dv.data();
-    while (p < n) {
-        uint64_t e = line_end(d, n, p);
-        uint64_t le = strip_cr(d, p, e);
-        if (le > p) {
-            if (d[p] == '@') {
-                out.header.append(d + p, le - p);
-                out.header += '\n';
-            } else {
-                SamFile::Rec r;
-                r.line.assign(d + p, le - p);
-                size_t t1 = r.line.find('\t');
-                if (t1 == std::string::npos) bail("Error during SAM record parsing: too few fields");
-                r.name = r.line.substr(0, t1);
-                size_t b = 0;
-                for (int f = 0; f < 9; ++f) {
-                    b = r.line.find('\t', b);
-                    if (b == std::string::npos) bail("Error during SAM record parsing: too few fields");
-                    ++b;
+// SAM text: header lines ('@') may appear anywhere a line starts; records keep their file order.
+// The text is cut at line starts into one piece per host thread; a record is five offsets.
+static void parse_sam_text(const char *d, uint64_t n, SamFile &out) {
+    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), n / (8u << 20) + 1));
+    std::vector<uint64_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (size_t t = 1; t < T; ++t) {
+        uint64_t p = std::max<uint64_t>(cut[t - 1], n * t / T);
+        if (p > 0 && p < n) p = line_end(d, n, p - 1) + 1;  // first line start at or after p
+        cut[t] = std::min(p, n);
+    }
+    std::vector<std::vector<SamFile::Rec>> parts(T);
+    std::vector<std::string> headers(T);
+    run_threads(T, [&](size_t t) {
+        uint64_t p = cut[t];
+        const uint64_t stop = cut[t + 1];
+        parts[t].reserve((stop - p) / 300 + 16);
+        while (p < stop) {
+            const uint64_t e = line_end(d, n, p);
+            const uint64_t le = strip_cr(d, p, e);
+            if (le > p) {
+                if (d[p] == '@') {
+                    headers[t].append(d + p, le - p);
+                    headers[t] += '\n';
+                } else {
+                    SamFile::Rec r;
+                    r.off = p;
+                    r.len = (uint32_t)(le - p);
+                    const char *q = (const char *)memchr(d + p, '\t', le - p);
+                    if (!q) bail("Error during SAM record parsing: too few fields");
+                    r.name_len = (uint32_t)(q - (d + p));
+                    for (int f = 1; f < 9; ++f) {  // q: the tab in front of field f + 1
+                        q = (const char *)memchr(q + 1, '\t', d + le - (q + 1));
+                        if (!q) bail("Error during SAM record parsing: too few fields");
+                    }
+                    const char *sb = q + 1;
+                    const char *se = (const char *)memchr(sb, '\t', d + le - sb);
+                    if (!se) se = d + le;
+                    r.seq_off = (uint64_t)(sb - d);
+                    r.l_seq = (se - sb == 1 && *sb == '*') ? 0 : (uint32_t)(se - sb);
+                    parts[t].push_back(r);
                 }
-                size_t e10 = r.line.find('\t', b);
-                r.seq = upper_seq(r.line.substr(b, e10 == std::string::npos ? std::string::npos : e10 - b));
-                out.recs.push_back(std::move(r));
             }
+            p = e + 1;
         }
-        p = e + 1;
+    });
+    size_t total = 0;
+    for (auto &v : parts) total += v.size();
+    out.recs.reserve(total);
+    for (size_t t = 0; t < T; ++t) {
+        out.header += headers[t];
+        out.recs.insert(out.recs.end(), parts[t].begin(), parts[t].end());
     }
 }
 
@@ -466,62 +505,96 @@ static void aux_to_text(Cur &c, std::string &out) {
     }
 }
 
-static void parse_bam(const std::vector<char> &d, SamFile &out) {
-    Cur c{(const uint8_t *)d.data(), (const uint8_t *)d.data() + d.size()};
+static const char kBamSeq[] = "=ACMGRSVTWYHKDBN";
+
+// one BAM alignment record (at its block_size field) -> SAM text line appended to s
+static void bam_record_to_sam(const uint8_t *at, const std::vector<std::string> &refs, std::string &s) {
+    static const char kCig[] = "MIDNSHP=X";
+    const int32_t n_ref = (int32_t)refs.size();
+    int32_t block;
+    memcpy(&block, at, 4);
+    Cur r{at + 4, at + 4 + block};
+    int32_t ref_id = r.get<int32_t>(), pos = r.get<int32_t>();
+    uint8_t l_name = r.get<uint8_t>(), mapq = r.get<uint8_t>();
+    (void)r.get<uint16_t>();
+    uint16_t n_cig = r.get<uint16_t>(), flag = r.get<uint16_t>();
+    int32_t l_seq = r.get<int32_t>(), next_ref = r.get<int32_t>(), next_pos = r.get<int32_t>(), tlen = r.get<int32_t>();
+    const uint8_t *nm = r.take(l_name);
+    s.reserve(s.size() + (size_t)block + (size_t)l_seq + 64);
+    s.append((const char *)nm, l_name ? l_name - 1u : 0u);
+    s += '\t' + std::to_string(flag) + '\t';
+    s += ref_id >= 0 && ref_id < n_ref ? refs[ref_id] : "*";
+    s += '\t' + std::to_string(pos + 1) + '\t' + std::to_string(mapq) + '\t';
+    if (n_cig == 0) s += '*';
+    for (uint16_t k = 0; k < n_cig; ++k) {
+        uint32_t v = r.get<uint32_t>();
+        s += std::to_string(v >> 4);
+        s += (v & 15) < 9 ? kCig[v & 15] : '?';
+    }
+    s += '\t';
+    s += next_ref < 0 ? "*" : (next_ref == ref_id ? "=" : (next_ref < n_ref ? refs[next_ref] : "*"));
+    s += '\t' + std::to_string(next_pos + 1) + '\t' + std::to_string(tlen) + '\t';
+    if (l_seq < 0) bail("Error during BAM record parsing: truncated file");
+    const uint8_t *sq = r.take(((size_t)l_seq + 1) / 2);
+    if (l_seq == 0) {
+        s += '*';
+    } else {
+        const size_t at0 = s.size();
+        s.resize(at0 + (size_t)l_seq);
+        for (int32_t k = 0; k < l_seq; ++k) s[at0 + k] = kBamSeq[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
+    }
+    s += '\t';
+    const uint8_t *ql = r.take((size_t)l_seq);
+    if (l_seq == 0 || ql[0] == 0xFF) {
+        s += '*';
+    } else {
+        const size_t at0 = s.size();
+        s.resize(at0 + (size_t)l_seq);
+        for (int32_t k = 0; k < l_seq; ++k) s[at0 + k] = (char)(ql[k] + 33);
+    }
+    aux_to_text(r, s);
+}
+
+static void parse_bam(const char *d, uint64_t n, SamFile &out) {
+    Cur c{(const uint8_t *)d, (const uint8_t *)d + n};
     if (memcmp(c.take(4), "BAM\1", 4) != 0) bail("Error reading BAM file: bad magic");
     int32_t l_text = c.get<int32_t>();
+    if (l_text < 0) bail("Error during BAM record parsing: truncated file");
     const uint8_t *text = c.take((size_t)l_text);
     size_t tl = (size_t)l_text;
     while (tl && text[tl - 1] == 0) --tl;
     out.header.assign((const char *)text, tl);
     if (!out.header.empty() && out.header.back() != '\n') out.header += '\n';
     int32_t n_ref = c.get<int32_t>();
-    std::vector<std::string> refs;
     for (int32_t i = 0; i < n_ref; ++i) {
         int32_t l_name = c.get<int32_t>();
+        if (l_name < 0) bail("Error during BAM record parsing: truncated file");
         const uint8_t *nm = c.take((size_t)l_name);
-        refs.emplace_back((const char *)nm, l_name > 0 ? (size_t)l_name - 1 : 0);
-        (void)c.get<int32_t>();
+        out.ref_names.emplace_back((const char *)nm, l_name > 0 ? (size_t)l_name - 1 : 0);
+        out.ref_lens.push_back(c.get<uint32_t>());
     }
-    static const char kSeq[] = "=ACMGRSVTWYHKDBN", kCig[] = "MIDNSHP=X";
+    // records: a chain of block_size fields; the fixed part of each record is validated here so
+    // that later (parallel) accesses stay inside the record
     while (c.p < c.e) {
-        int32_t block = c.get<int32_t>();
-        Cur r{c.take((size_t)block), nullptr};
-        r.e = r.p + block;
-        int32_t ref_id = r.get<int32_t>(), pos = r.get<int32_t>();
-        uint8_t l_name = r.get<uint8_t>(), mapq = r.get<uint8_t>();
-        (void)r.get<uint16_t>();
-        uint16_t n_cig = r.get<uint16_t>(), flag = r.get<uint16_t>();
-        int32_t l_seq = r.get<int32_t>(), next_ref = r.get<int32_t>(), next_pos = r.get<int32_t>(), tlen = r.get<int32_t>();
-        const uint8_t *nm = r.take(l_name);
+        const uint8_t *at = c.p;
+        const int32_t block = c.get<int32_t>();
+        if (block < 32) bail("Error during BAM record parsing: truncated file");
+        const uint8_t *r = c.take((size_t)block);
+        const uint8_t l_name = r[8];
+        uint16_t n_cig;
+        int32_t l_seq;
+        memcpy(&n_cig, r + 12, 2);
+        memcpy(&l_seq, r + 16, 4);
+        const uint64_t fixed = 32ull + l_name + 4ull * n_cig;
+        if (l_seq < 0 || fixed + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > (uint64_t)block)
+            bail("Error during BAM record parsing: truncated file");
         SamFile::Rec rec;
-        rec.name.assign((const char *)nm, l_name ? l_name - 1u : 0u);
-        std::string &s = rec.line;
-        s = rec.name;
-        s += '\t' + std::to_string(flag) + '\t';
-        s += ref_id >= 0 && ref_id < n_ref ? refs[ref_id] : "*";
-        s += '\t' + std::to_string(pos + 1) + '\t' + std::to_string(mapq) + '\t';
-        if (n_cig == 0) s += '*';
-        for (uint16_t k = 0; k < n_cig; ++k) {
-            uint32_t v = r.get<uint32_t>();
-            s += std::to_string(v >> 4);
-            s += (v & 15) < 9 ? kCig[v & 15] : '?';
-        }
-        s += '\t';
-        s += next_ref < 0 ? "*" : (next_ref == ref_id ? "=" : (next_ref < n_ref ? refs[next_ref] : "*"));
-        s += '\t' + std::to_string(next_pos + 1) + '\t' + std::to_string(tlen) + '\t';
-        const uint8_t *sq = r.take(((size_t)l_seq + 1) / 2);
-        rec.seq.resize((size_t)l_seq);
-        for (int32_t k = 0; k < l_seq; ++k) rec.seq[k] = kSeq[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
-        s += l_seq ? rec.seq : "*";
-        s += '\t';
-        const uint8_t *ql = r.take((size_t)l_seq);
-        if (l_seq == 0 || ql[0] == 0xFF)
-            s += '*';
-        else
-            for (int32_t k = 0; k < l_seq; ++k) s += (char)(ql[k] + 33);
-        aux_to_text(r, s);
-        out.recs.push_back(std::move(rec));
+        rec.off = (uint64_t)((const char *)at - d);
+        rec.len = (uint32_t)block + 4;
+        rec.name_len = l_name ? l_name - 1u : 0u;
+        rec.seq_off = rec.off + 4 + fixed;
+        rec.l_seq = (uint32_t)l_seq;
+        out.recs.push_back(rec);
     }
 }
 
@@ -531,11 +604,103 @@ void SamFile::parse(const std::string &path) {
     if (ext != "sam" && ext != "bam") bail("Input file must be a BAM or SAM file.");
     header.clear();
     recs.clear();
-    std::vector<char> d = read_file_maybe_gz(path);
-    if (ext == "bam")
-        parse_bam(d, *this);
+    ref_names.clear();
+    ref_lens.clear();
+    io_mark(nullptr);
+    fb.load(path);  // mmap for plain SAM, (parallel) inflate for BAM / gzip
+    data = fb.p;
+    is_bam = ext == "bam";
+    io_mark("load / inflate");
+    if (is_bam)
+        parse_bam(fb.p, fb.n, *this);
     else
-        parse_sam_text(d, *this);
+        parse_sam_text(fb.p, fb.n, *this);
+    io_mark("record index");
+}
+
+void SamFile::gather(std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const {
+    const size_t n = recs.size();
+    off.resize(n + 1);
+    off[0] = 0;
+    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + recs[i].l_seq;
+    seq.resize(off[n] + 1);
+    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), n / 65536 + 1));
+    run_threads(T, [&](size_t t) {
+        for (size_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+            uint8_t *o = seq.data() + off[i];
+            const uint32_t l = recs[i].l_seq;
+            const uint8_t *src = (const uint8_t *)data + recs[i].seq_off;
+            if (is_bam) {
+                for (uint32_t k = 0; k < l; ++k) o[k] = (uint8_t)kBamSeq[(src[k >> 1] >> ((~k & 1) << 2)) & 15];
+            } else {  // the matcher sees upper-case text (bam crate: sequences are stored packed, case is lost)
+                for (uint32_t k = 0; k < l; ++k) o[k] = (src[k] >= 'a' && src[k] <= 'z') ? (uint8_t)(src[k] & ~0x20) : src[k];
+            }
+        }
+    });
+    seq[off[n]] = 0;
+}
+
+void SamFile::append_line(size_t i, std::string &out) const {
+    if (is_bam)
+        bam_record_to_sam((const uint8_t *)data + recs[i].off, ref_names, out);
+    else
+        out.append(data + recs[i].off, recs[i].len);
+}
+
+int SamFile::find_tag(size_t i, const std::string &tag, std::string *val) const {
+    if (!is_bam) {
+        const char *b = data + recs[i].off, *e = b + recs[i].len;
+        for (int f = 0; f < 11; ++f) {
+            b = (const char *)memchr(b, '\t', e - b);
+            if (!b) return 0;
+            ++b;
+        }
+        while (b < e) {
+            const char *t = (const char *)memchr(b, '\t', e - b);
+            if (!t) t = e;
+            if (t - b >= 5 && b[0] == tag[0] && b[1] == tag[1] && b[2] == ':') {
+                if (b[3] != 'Z' || b[4] != ':') return 2;
+                val->assign(b + 5, t - (b + 5));
+                return 1;
+            }
+            b = t + 1;
+        }
+        return 0;
+    }
+    // BAM: walk the optional fields behind name, CIGAR, SEQ and QUAL
+    const uint8_t *r = raw(i);
+    Cur c{r + (recs[i].seq_off - recs[i].off - 4) + ((size_t)recs[i].l_seq + 1) / 2 + recs[i].l_seq, r + raw_len(i)};
+    while (c.p < c.e) {
+        const uint8_t *tg = c.take(2);
+        const char type = (char)c.get<uint8_t>();
+        const bool mine = tg[0] == (uint8_t)tag[0] && tg[1] == (uint8_t)tag[1];
+        if (mine && type != 'Z') return 2;
+        switch (type) {
+        case 'A': case 'c': case 'C': c.take(1); break;
+        case 's': case 'S': c.take(2); break;
+        case 'i': case 'I': case 'f': c.take(4); break;
+        case 'Z': case 'H': {
+            const uint8_t *s0 = c.p;
+            while (c.p < c.e && *c.p) ++c.p;
+            if (mine) {
+                val->assign((const char *)s0, c.p - s0);
+                return 1;
+            }
+            if (c.p < c.e) ++c.p;
+            break;
+        }
+        case 'B': {
+            const char sub = (char)c.get<uint8_t>();
+            const int32_t cnt = c.get<int32_t>();
+            const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (cnt < 0) bail("Error during BAM record parsing: truncated file");
+            c.take(w * (size_t)cnt);
+            break;
+        }
+        default: bail("Error during BAM record parsing: unknown tag type");
+        }
+    }
+    return 0;
 }
 
 // ---- BAM output ---------------------------------------------------------------------------------
@@ -608,11 +773,16 @@ void BamWriter::flush_pending() {
     pending.clear();
 }
 
-void BamWriter::open(const std::string &path, const std::string &header_text) {
+void BamWriter::open(const std::string &path, const std::string &header_text, const std::vector<std::string> *names,
+                     const std::vector<uint32_t> *lens) {
     f = fopen(path.c_str(), "wb");
     if (!f) bail("Error writing BAM file: " + path);
     std::vector<uint32_t> ref_len;
-    size_t b = 0;
+    if (names && lens) {
+        ref_names = *names;
+        ref_len = *lens;
+    }
+    size_t b = names && lens ? header_text.size() : 0;
     while (b < header_text.size()) {  // @SQ SN:name LN:len
         size_t e = header_text.find('\n', b);
         if (e == std::string::npos) e = header_text.size();
@@ -658,6 +828,12 @@ static int reg2bin(int64_t beg, int64_t end) {  // SAM spec 5.3
 }
 
 void BamWriter::write_record(const std::string &line) {
+    std::vector<uint8_t> r;
+    encode_record(line, r);
+    put(r.data(), r.size());
+}
+
+void BamWriter::encode_record(const std::string &line, std::vector<uint8_t> &dst) const {
     std::vector<std::string> fld;
     size_t b = 0;
     for (;;) {
@@ -778,8 +954,8 @@ void BamWriter::write_record(const std::string &line) {
         }
     }
     const int32_t block_size = (int32_t)r.size();
-    put(&block_size, 4);
-    put(r.data(), r.size());
+    dst.insert(dst.end(), (const uint8_t *)&block_size, (const uint8_t *)&block_size + 4);
+    dst.insert(dst.end(), r.begin(), r.end());
 }
 
 void BamWriter::close() {
@@ -792,24 +968,16 @@ void BamWriter::close() {
     f = nullptr;
 }
 
-int sam_find_tag(const std::string &line, const std::string &tag, std::string *val) {
-    size_t b = 0;
-    for (int f = 0; f < 11; ++f) {
-        b = line.find('\t', b);
-        if (b == std::string::npos) return 0;
-        ++b;
-    }
-    while (b < line.size()) {
-        size_t e = line.find('\t', b);
-        if (e == std::string::npos) e = line.size();
-        if (e - b >= 5 && line.compare(b, 2, tag) == 0 && line[b + 2] == ':') {
-            if (line[b + 3] != 'Z' || line[b + 4] != ':') return 2;
-            *val = line.substr(b + 5, e - b - 5);
-            return 1;
-        }
-        b = e + 1;
-    }
-    return 0;
+void BamWriter::append_tagged_raw(const uint8_t *rec, uint32_t len, const std::string &tag, const char *val, size_t val_len,
+                                  std::vector<uint8_t> &dst) {
+    const int32_t block_size = (int32_t)(len + 3 + val_len + 1);
+    dst.insert(dst.end(), (const uint8_t *)&block_size, (const uint8_t *)&block_size + 4);
+    dst.insert(dst.end(), rec, rec + len);
+    dst.push_back((uint8_t)tag[0]);
+    dst.push_back((uint8_t)tag[1]);
+    dst.push_back('Z');
+    dst.insert(dst.end(), (const uint8_t *)val, (const uint8_t *)val + val_len);
+    dst.push_back(0);
 }
 
 }  // namespace cli

@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "util.hpp"
@@ -13,6 +14,28 @@ namespace cli {
 
 // host threads for ingest / codec work: hardware concurrency, capped at 32, MERKURIO_IO_THREADS overrides
 unsigned io_threads();
+
+// runs fn(t) for t in [0, T) on T host threads; the first cli::Error is re-raised on the caller
+template <class F>
+void run_threads(size_t T, F fn) {
+    if (T <= 1) {
+        fn((size_t)0);
+        return;
+    }
+    std::vector<std::string> errs(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            try {
+                fn(t);
+            } catch (const Error &e) {
+                errs[t] = e.what()[0] ? e.what() : "error";
+            }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : errs)
+        if (!e.empty()) bail(e);
+}
 
 // whole file into memory; transparently inflates gzip (magic 1f 8b); BGZF members in parallel.  bz2 / xz / zstd
 // inputs are recognised and rejected with a clear message (no such libraries in this build).
@@ -57,15 +80,38 @@ struct FastxFile {
 };
 
 // ---- SAM / BAM ------------------------------------------------------------------------------------
+// A whole SAM or BAM input held as ONE buffer (mmap of the text / inflated BAM); records are
+// index entries into it, nothing is copied or converted until it is needed: sequences are
+// gathered (upper-cased / un-nibbled) straight into the concatenated scan buffer, SAM text of a
+// BAM record is produced only for records that are written as text, and BAM -> BAM output passes
+// the raw record through with the new tag appended (as the reference's bam crate does).
 struct SamFile {
     std::string header;  // header text, every line '\n'-terminated
+    FileBytes fb;
+    const char *data = nullptr;  // = fb.p
+    bool is_bam = false;
+    std::vector<std::string> ref_names;  // BAM: reference dictionary of the binary header
+    std::vector<uint32_t> ref_lens;
     struct Rec {
-        std::string line;  // the record as one SAM text line, no line end (BAM input: converted)
-        std::string name;  // QNAME
-        std::string seq;   // SEQ as the matcher sees it: upper-case, "" for '*'
+        uint64_t off;      // SAM: start of the text line; BAM: the record's block_size field
+        uint32_t len;      // SAM: line length without line end; BAM: 4 + block_size
+        uint32_t name_len; // QNAME length (SAM: at off; BAM: at off + 36)
+        uint64_t seq_off;  // SAM: SEQ field text; BAM: packed 4-bit sequence
+        uint32_t l_seq;    // bases ('*' -> 0)
     };
     std::vector<Rec> recs;
     void parse(const std::string &path);  // by extension: "sam" / "bam" (src/cmd_tag.rs:503-615)
+    std::string name(size_t i) const { return std::string(data + recs[i].off + (is_bam ? 36 : 0), recs[i].name_len); }
+    // SEQ of every record as the matcher sees it (upper-case ASCII), concatenated (+1 pad byte)
+    void gather(std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const;
+    // record i as one SAM text line (no line end) appended to out
+    void append_line(size_t i, std::string &out) const;
+    // BAM input: raw record bytes after the block_size field
+    const uint8_t *raw(size_t i) const { return (const uint8_t *)data + recs[i].off + 4; }
+    uint32_t raw_len(size_t i) const { return recs[i].len - 4; }
+    // value of an existing `tag` field: 0 = absent, 1 = Z value in *val, 2 = present with a
+    // non-string type (the reference bails: "Invalid tag value format...")
+    int find_tag(size_t i, const std::string &tag, std::string *val) const;
 };
 // BAM writer (BGZF): encodes SAM text lines against the header's @SQ dictionary.  Used for
 // `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.
@@ -75,8 +121,18 @@ struct BamWriter {
     std::vector<std::vector<uint8_t>> pending;  // full blocks waiting for the next parallel deflate
     std::vector<std::string> ref_names;
     ~BamWriter();
-    void open(const std::string &path, const std::string &header_text);
+    // reference dictionary from the @SQ lines of header_text, or (BAM -> BAM pass-through, where
+    // records keep their reference ids) the input's own binary dictionary
+    void open(const std::string &path, const std::string &header_text, const std::vector<std::string> *names = nullptr,
+              const std::vector<uint32_t> *lens = nullptr);
+    // pass-through of a raw BAM record with one more Z tag appended (thread-safe, see encode_record)
+    static void append_tagged_raw(const uint8_t *rec, uint32_t len, const std::string &tag, const char *val, size_t val_len,
+                                  std::vector<uint8_t> &dst);
     void write_record(const std::string &sam_line);
+    // block_size + record bytes of one SAM text line appended to dst (thread-safe: encoding is the
+    // slow part of SAM -> BAM and runs on every host thread), then put_encoded() in record order
+    void encode_record(const std::string &sam_line, std::vector<uint8_t> &dst) const;
+    void put_encoded(const std::vector<uint8_t> &bytes) { put(bytes.data(), bytes.size()); }
     void close();
 
    private:
@@ -84,9 +140,5 @@ struct BamWriter {
     void flush_block();
     void flush_pending();
 };
-
-// value of an existing `tag:Z:` field of a SAM line: returns 0 = absent, 1 = Z value in *val,
-// 2 = present with a non-string type (the reference bails: "Invalid tag value format...")
-int sam_find_tag(const std::string &line, const std::string &tag, std::string *val);
 
 }  // namespace cli
