@@ -237,23 +237,42 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     std::vector<uint32_t> counts(pats.list.size(), 0);
     const size_t n = f1.recs.size();
     const uint64_t batch_bytes = (uint64_t)a.batch_mb << 20;
-    std::vector<uint8_t> s1, s2, keep;
-    std::vector<uint64_t> o1, o2;
+    // double-buffered batches: while batch k is on the GPU and its records are written out, a
+    // second thread gathers the sequences of batch k + 1
+    struct Batch {
+        size_t b0 = 0, b1 = 0;
+        std::vector<uint8_t> s1, s2;
+        std::vector<uint64_t> o1, o2;
+    } bufs[2];
+    std::vector<uint8_t> keep;
     std::vector<mk_row> rows(4096);
-    size_t i = 0;
-    while (i < n) {
-        const size_t b0 = i;
+    auto fill = [&](Batch &b, size_t from) {
+        size_t i = from;
         uint64_t bytes = 0;
-        while (i < n && (bytes < batch_bytes || i == b0)) {
+        while (i < n && (bytes < batch_bytes || i == from)) {
             bytes += f1.raw_len(i) + (paired ? f2.raw_len(i) : 0);
             ++i;
         }
-        f1.gather(b0, i, s1, o1);
-        if (paired) f2.gather(b0, i, s2, o2);
+        b.b0 = from;
+        b.b1 = i;
+        f1.gather(from, i, b.s1, b.o1);
+        if (paired) f2.gather(from, i, b.s2, b.o2);
+    };
+    int cur = 0;
+    if (n) fill(bufs[0], 0);
+    tm.mark("batch: gather sequences (first)");
+    while (n && bufs[cur].b0 < n) {
+        Batch &B = bufs[cur];
+        const size_t b0 = B.b0, i = B.b1;
+        std::vector<uint8_t> &s1 = B.s1, &s2 = B.s2;
+        std::vector<uint64_t> &o1 = B.o1, &o2 = B.o2;
+        std::future<void> next;
+        Batch &N = bufs[cur ^ 1];
+        N.b0 = n;  // "no further batch" unless filled below
+        if (i < n) next = std::async(std::launch::async, [&, i] { fill(N, i); });
         const uint64_t nb = i - b0;
         keep.assign(nb, 0);
         uint64_t n_rows = 0;
-        tm.mark("batch: gather sequences");
         for (;;) {
             mk_counters cb;
             memset(&cb, 0, sizeof(cb));
@@ -289,6 +308,9 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                     f1.write(b0 + k, w1);
                     if (paired) f2.write(b0 + k, w2);
                 }
+        if (next.valid()) next.get();
+        tm.mark("batch: rows + records out, wait for next gather");
+        cur ^= 1;
     }
     w1.flush();
     w2.flush();

@@ -25,7 +25,7 @@ struct CommonArgs {
     bool aho_corasick = false;             // -a
     // opt-in extras of this build (defaults reproduce the reference behaviour)
     int device = 0;       // --device
-    int batch_mb = 1024;  // --batch-mb: sequence bytes per GPU batch
+    int batch_mb = 128;  // --batch-mb: sequence bytes per GPU batch (tools/batch_mb.sh: 128-256 MB is fastest end to end)
 };
 
 struct ExtractArgs : CommonArgs {

@@ -194,7 +194,8 @@ void FileBytes::load(const std::string &path) {
     struct stat st;
     const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (!gz && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        const char *pop = getenv("MERKURIO_MMAP_POPULATE");  // tuning hook
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | ((pop && atoi(pop) == 0) ? 0 : MAP_POPULATE), fd, 0);
         if (m != MAP_FAILED) {
             close(fd);
             map = m;

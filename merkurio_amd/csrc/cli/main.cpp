@@ -44,7 +44,7 @@ void print_help(const char *sub) {
              "  -v, --invert-match           select non-matching records\n  -I, --case-insensitive       (always Aho-Corasick)\n"
              "  -L, --lowercase | -U, --uppercase   convert the patterns\n  -q, --q-size <Q>             force BNDMq with this q\n"
              "  -a, --aho-corasick           force Aho-Corasick\n      --device <N>             HIP device ordinal [0]\n"
-             "      --batch-mb <MB>          sequence bytes per GPU batch [1024]");
+             "      --batch-mb <MB>          sequence bytes per GPU batch [128]");
     } else {
         puts("Usage: merkurio tag [OPTIONS] --in-file <IN_FILE> <--kmer-seq <KMER_SEQ>...|--kmer-file <KMER_FILE>>\n\n"
              "  -i, --in-file <PATH>         SAM/BAM input\n  -o, --out-file <PATH>        SAM output (stdout if absent)\n"
