@@ -70,6 +70,15 @@ constexpr uint32_t kLdsPatCounters = 64;  // pattern sets up to this size count 
 constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) + kLdsPatCounters * 8;  // 144.5 KiB
 static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
+// compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
+//   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only,
+//   8 = filter positives are queued in the LDS ring but never probed (level 1 -> 2 hand-off cost),
+//   16 = level 3 dropped (q-gram hits are queued, never resolved), 32 = level 3 without its stores / atomics,
+//   64 = q-gram hits are not even queued
+#ifndef MK_ABLATE
+#define MK_ABLATE 0
+#endif
+
 // ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
 // byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
 // check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
@@ -78,6 +87,7 @@ template <bool EMIT>
 __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
                                             unsigned long long *lds_pat_cnt, mk_hit &out) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
+    if constexpr ((MK_ABLATE & 16) != 0) return false;
     const uint32_t a = P.uniform_len ? pat * P.uniform_len : P.pat_off[pat];
     const uint32_t len = P.uniform_len ? P.uniform_len : P.pat_off[pat + 1] - a;
     if (p + len > P.n_bytes) return false;
@@ -155,6 +165,10 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     if (p + len > rend) return false;  // occurrence would cross a record boundary
     // ---- a true occurrence.  The flag is a plain byte store (idempotent; nothing waits for it);
     // flagged records are counted afterwards by mk_count_flags_kernel when counters are wanted.
+    if constexpr ((MK_ABLATE & 32) != 0) {
+        n_true++;
+        return false;
+    }
     reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
     n_true++;
     if (P.counters) {
@@ -254,7 +268,7 @@ __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, ui
     for (int k = 0; k < 4; ++k) {
         const uint32_t e_off = epo[k] & 15u, e_pat = epo[k] >> 4;
         const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
-        const uint64_t mm = __ballot(match);
+        const uint64_t mm = (MK_ABLATE & 64) ? 0ull : __ballot(match);
         if (mm) {  // uniform, rare
             if (match) {
                 const uint32_t below =
@@ -295,11 +309,6 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
     }
 }
 
-// compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
-//   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only
-#ifndef MK_ABLATE
-#define MK_ABLATE 0
-#endif
 #ifndef MK_LOOPV
 #define MK_LOOPV 1  // 1: one looped copy of filter + hand-off per chunk (2 % faster at S=8, tools/loopv_ab.sh); 0: four straight-line filter passes per group
 #endif
@@ -629,7 +638,14 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     }
                 }
 #endif
-                if (!pend_on && q_count >= MK_ISSUE_AT) issue_probe(q_count < 64 ? q_count : 64);
+                if constexpr ((MK_ABLATE & 8) != 0) {  // hand-off cost only: forget the queued entries
+                    if (q_count >= MK_ISSUE_AT) {
+                        q_head = (q_head + q_count) & (kRingEntries - 1);
+                        q_count = 0;
+                    }
+                } else if (!pend_on && q_count >= MK_ISSUE_AT) {
+                    issue_probe(q_count < 64 ? q_count : 64);
+                }
                 pk_prev = p3;
             }
         }

@@ -2,6 +2,7 @@
 GPU path vs the oracle, covering the generic (runtime-q) kernel variants, every stride the
 geometry rule can pick, odd pattern lengths, mixed alphabets, -I, -r/-c pattern lists, forced
 BNDMq / Aho-Corasick emission orders and the global-filter mode."""
+import os
 import random
 
 import pytest
@@ -45,9 +46,10 @@ def _case(rnd):
     return raw, recs
 
 
-@pytest.mark.parametrize("seed", range(8))
+# longer campaigns: MERKURIO_FUZZ_SEEDS=200 MERKURIO_FUZZ_BASE=5000 python -m pytest tests/test_gpu_fuzz.py -m gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MERKURIO_FUZZ_SEEDS", "8"))))
 def test_fuzz_vs_oracle(mk, seed, monkeypatch):
-    rnd = random.Random(1000 + seed)
+    rnd = random.Random(int(os.environ.get("MERKURIO_FUZZ_BASE", "1000")) + seed)
     for it in range(60):
         raw, recs = _case(rnd)
         kw = dict(reverse_complement=rnd.random() < 0.3, canonical=False, lowercase=False, uppercase=rnd.random() < 0.1)

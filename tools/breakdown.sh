@@ -5,6 +5,8 @@ for r in 1 2; do
 unset MERKURIO_LIB_PATH
 run "full, 1% reads hit      "
 run "full, no planted hits   " --plant-every 0
+export MERKURIO_LIB_PATH=merkurio_amd/lib/libmerkurio_hip_abl8.so
+run "ring only (ABLATE=8)    " --plant-every 0
 export MERKURIO_LIB_PATH=merkurio_amd/lib/libmerkurio_hip_abl1.so
 run "filter only (ABLATE=1)  "
 export MERKURIO_LIB_PATH=merkurio_amd/lib/libmerkurio_hip_abl7.so

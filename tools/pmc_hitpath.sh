@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_hitpath
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for pe in 100 1; do
+for pe in ${PES:-100 1}; do
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
   i=$((i+1))
@@ -16,7 +16,7 @@ python3 - <<PY
 import csv, glob, os
 from collections import defaultdict
 out = "$OUT"
-for pe in (100, 1):
+for pe in [int(x) for x in "${PES:-100 1}".split()]:
     print("== plant_every=%d (per-launch averages, mk_scan kernels)" % pe)
     for f in sorted(glob.glob(os.path.join(out, "pe%d_pmc*" % pe, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(list)
