@@ -74,7 +74,7 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 //   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only,
 //   8 = filter positives are queued in the LDS ring but never probed (level 1 -> 2 hand-off cost),
 //   16 = level 3 dropped (q-gram hits are queued, never resolved), 32 = level 3 without its stores / atomics,
-//   64 = q-gram hits are not even queued
+//   64 = q-gram hits are not even queued, 128 = no per-pattern counter atomics, 256 = no record-flag stores
 #ifndef MK_ABLATE
 #define MK_ABLATE 0
 #endif
@@ -169,9 +169,9 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
         n_true++;
         return false;
     }
-    reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
+    if constexpr ((MK_ABLATE & 256) == 0) reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
     n_true++;
-    if (P.counters) {
+    if (P.counters && (MK_ABLATE & 128) == 0) {
         if (P.n_pat <= kLdsPatCounters) {
             // few patterns: their counters share a cache line or two, and a million global atomics
             // on one line serialise in one L2 channel (+0.5 ms at 13 patterns).  Count in LDS,
@@ -595,6 +595,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 // compiler sinks the packs below the loads and keeps the raw data alive with 16
                 // v_mov per group
                 asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+                // (re-issuing the stream loads first is 2-3 % slower: tools/ab3.sh, r01)
                 if (pend_on) consume_probe();  // its loads are older than the stream loads just waited for
                 load_group(r0, r1, r2, r3);
 #if MK_LOOPV == 1
