@@ -82,12 +82,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal hook: MERKURIO_BENCH_BACKEND=gloo runs several ranks on fewer GPUs (rank -> device
+    # round-robin); the measured configuration is one rank per GPU over nccl (= RCCL)
+    backend = os.environ.get("MERKURIO_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- pattern set (identical on every rank) and matcher
     raw = make_patterns(args.patterns, args.k)
@@ -95,7 +102,7 @@ def main():
     assert len(patterns) == args.patterns
     if args.rc:
         patterns = mk.parse_pattern_list(kmer_seq=patterns, reverse_complement=True)
-    m = mk.Matcher(patterns, device=local_rank)
+    m = mk.Matcher(patterns, device=dev_index)
     assert m.use_ac == mk.recommend_aho_corasick(patterns)
     lib = mk.load()
 
@@ -128,7 +135,10 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
