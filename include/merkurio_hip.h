@@ -172,7 +172,7 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
  * The call enqueues on `stream` (a hipStream_t, NULL = default stream): clear of
  * d_rec_flags[0..n_rec) and of *d_n_hits, then the scan kernel.  d_hits may be NULL in
  * MK_MODE_ANY.  Hits are written UNORDERED (order them with mk_order_hits after copying
- * back); *d_n_hits counts every occurrence even beyond hits_cap.
+ * back); in MK_MODE_HITS *d_n_hits counts every occurrence even beyond hits_cap (0 in MK_MODE_ANY).
  * d_counters (may be NULL): uint64[n_pat + MK_NUM_SUMMARY] accumulated (+=) by the scan:
  *   [0, n_pat)            occurrences per pattern (the AC meaning of pattern_hit_counts,
  *                         src/cmd_extract.rs:353)

@@ -586,8 +586,19 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint4 r0, r1, r2, r3;
         load_group(r0, r1, r2, r3);
         uint32_t pk_prev = 0;
+        // Queued filter positives carry only the low 32 bits of their position, restored relative to
+        // the wave's current position: none may stay queued while the wave advances 4 GiB.  A wave's
+        // tiles are n_waves * 31 KiB apart, so every `age_limit` tiles (1 GiB of advance) whatever
+        // is queued is pushed on to level 2 (sparse candidates never reach the ring's fill
+        // threshold by themselves: 1 pattern on 15 GB lost two hits in three before this).
+        const uint32_t age_limit = (uint32_t)std::max<uint64_t>(1, (1ull << 30) / (n_waves * kTileBytes));
+        uint32_t tiles_since_push = 0;
         for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
             const uint64_t base = tile * kTileBytes;
+            if (++tiles_since_push >= age_limit) {
+                tiles_since_push = 0;
+                if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
+            }
 #pragma unroll 1
             for (int g = 0; g < (kTileChunks + 1) / 4; ++g) {
                 const uint32_t p0 = pack16(r0), p1 = pack16(r1), p2 = pack16(r2), p3 = pack16(r3);

@@ -185,3 +185,50 @@ def test_headline_full_size_properties(mk):
         assert np.array_equal(flags_np != 0, keep != 0)
         sel = (hits["rec"] >= rec0) & (hits["rec"] < rec0 + M)
         assert int(sel.sum()) == c["hits"][0]
+
+
+@pytest.mark.parametrize("n_pat,every", [(1, 1000), (1, 50), (13, 100000)])
+def test_sparse_candidates_full_size(mk, n_pat, every):
+    """few patterns on a 15 GB batch: filter positives are so rare that a wave's ring never fills
+    by itself, and a queued position (32 bits) must not outlive 4 GiB of the wave's advance.
+    Shards below 4 GiB cannot have the problem: the whole batch must equal their concatenation.
+    (Regression: 1 pattern, 1 read in 1000 planted lost two hits in three.)"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    lib = mk.load()
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(n_pat, 31, 16))
+    m = mk.Matcher(patterns)
+    n_rec, L, seed = 100_000_000, 150, 0xBEEF + n_pat
+    st = torch.cuda.current_stream().cuda_stream
+    d_seq = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    assert lib.mk_synth_reads_device(m.handle, seed, n_rec, L, every, d_seq.data_ptr(), d_off.data_ptr(), st) == 0
+    npat = len(patterns)
+
+    def scan(seq_t, off_t, n):
+        flags = torch.empty((n + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        nh = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(npat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        rc = lib.mk_scan_device(m.handle, seq_t.data_ptr(), n * L, off_t.data_ptr(), n, mk.MK_MODE_ANY, flags.data_ptr(),
+                                None, 0, nh.data_ptr(), cnt.data_ptr(), st)
+        assert rc == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        return flags[:n], int(nh.item()), cnt.cpu().numpy()
+
+    f_all, nh_all, c_all = scan(d_seq, d_off, n_rec)
+    shard = 12_500_000  # 1.875 GB of text, a multiple of 8 records (16-byte aligned start)
+    parts, nh_sum, c_sum = [], 0, np.zeros_like(c_all)
+    for b in range(0, n_rec, shard):
+        off_s = (d_off[b:b + shard + 1] - d_off[b]).contiguous()
+        f, nh, c = scan(d_seq[b * L:], off_s, shard)
+        parts.append(f)
+        nh_sum += nh
+        c_sum += c
+    assert nh_all == nh_sum == 0  # *d_n_hits is the tuple count of MK_MODE_HITS
+    assert np.array_equal(c_all[:npat], c_sum[:npat])
+    for k in (mk.MK_SUM_HITS, mk.MK_SUM_RECORDS_HIT, mk.MK_SUM_RECORDS, mk.MK_SUM_BASES):
+        assert c_all[npat + k] == c_sum[npat + k]
+    assert c_all[npat + mk.MK_SUM_HITS] == int(c_all[:npat].sum())
+    assert torch.equal(torch.cat(parts), f_all)
+    n_flag = int(f_all.sum(dtype=torch.int64).item())
+    assert n_rec // every * 0.9 - 10 < n_flag < n_rec // every * 1.1 + 10
