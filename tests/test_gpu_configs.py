@@ -232,3 +232,109 @@ def test_sparse_candidates_full_size(mk, n_pat, every):
     assert torch.equal(torch.cat(parts), f_all)
     n_flag = int(f_all.sum(dtype=torch.int64).item())
     assert n_rec // every * 0.9 - 10 < n_flag < n_rec // every * 1.1 + 10
+
+
+def test_ragged_records_full_size(mk):
+    """14.4 GB of text cut into 100 M records of eight different lengths: the record lookup of a
+    verified hit starts from an interpolated index that is off by a few records here, so the
+    gallop / bisect path runs at full scale.  Whole batch == concatenation of 1.8 GB shards, and the
+    oracle agrees on the first records."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    lib = mk.load()
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(2000, 31, 26))
+    m = mk.Matcher(patterns)
+    npat = len(patterns)
+    cycle = [100, 151, 200, 149, 120, 180, 150, 102]  # 1152 bytes = 72 x 16
+    n_cyc = 12_500_000
+    n_rec, n_bytes = 8 * n_cyc, 1152 * n_cyc
+    st = torch.cuda.current_stream().cuda_stream
+    d_seq = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+    d_off_u = torch.empty(n_bytes // 150 + 1, dtype=torch.int64, device=dev)
+    # uniform 150-byte synthetic reads with planted k-mers, then re-cut at the ragged offsets
+    assert lib.mk_synth_reads_device(m.handle, 0xFACE, n_bytes // 150, 150, 20, d_seq.data_ptr(), d_off_u.data_ptr(), st) == 0
+    del d_off_u
+    lens = torch.tensor(cycle, dtype=torch.int64, device=dev).repeat(n_cyc)
+    d_off = torch.zeros(n_rec + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=d_off[1:])
+    del lens
+    assert int(d_off[-1].item()) == n_bytes
+
+    def scan(seq_t, off_t, n, nb):
+        flags = torch.empty((n + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        nh = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(npat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        rc = lib.mk_scan_device(m.handle, seq_t.data_ptr(), nb, off_t.data_ptr(), n, mk.MK_MODE_ANY, flags.data_ptr(),
+                                None, 0, nh.data_ptr(), cnt.data_ptr(), st)
+        assert rc == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        return flags[:n], cnt.cpu().numpy()
+
+    f_all, c_all = scan(d_seq, d_off, n_rec, n_bytes)
+    parts, c_sum = [], np.zeros_like(c_all)
+    shard_c = n_cyc // 8  # cycles per shard
+    for k in range(8):
+        r0, b0 = k * shard_c * 8, k * shard_c * 1152
+        off_s = (d_off[r0:r0 + shard_c * 8 + 1] - b0).contiguous()
+        f, c = scan(d_seq[b0:], off_s, shard_c * 8, shard_c * 1152)
+        parts.append(f)
+        c_sum += c
+    assert torch.equal(torch.cat(parts), f_all)
+    assert np.array_equal(c_all[:npat], c_sum[:npat])
+    for k in (mk.MK_SUM_HITS, mk.MK_SUM_RECORDS_HIT, mk.MK_SUM_RECORDS, mk.MK_SUM_BASES):
+        assert c_all[npat + k] == c_sum[npat + k]
+    assert c_all[npat + mk.MK_SUM_RECORDS_HIT] == int(f_all.sum(dtype=torch.int64).item()) > n_rec // 40
+    # oracle on the first 160 k records
+    M = 160_000
+    off = d_off[:M + 1].cpu().numpy().astype(np.uint64)
+    seq = d_seq[:int(off[-1])].cpu().numpy()
+    om = ob.Matcher(patterns, True, 0, False)
+    keep, _ = ob.extract_single_packed(om, seq, off, logging=False, invert=False)
+    assert np.array_equal(f_all[:M].cpu().numpy() != 0, keep != 0)
+
+
+def test_config5_full_size_shard_additivity(mk):
+    """BASELINE config 5 at a full per-GPU shard: 500 k 21-mers (global-memory filter) over
+    50 M x 250 bp = 12.5 GB.  Whole batch == concatenation of four 3.1 GB shards; hits mode agrees
+    with flags mode."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    lib = mk.load()
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(500_000, 21, 5))
+    m = mk.Matcher(patterns)
+    assert m.filter_mode()["in_lds"] is False
+    npat = len(patterns)
+    n_rec, L = 50_000_000, 250
+    st = torch.cuda.current_stream().cuda_stream
+    d_seq = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    assert lib.mk_synth_reads_device(m.handle, 0x5EED, n_rec, L, 100, d_seq.data_ptr(), d_off.data_ptr(), st) == 0
+
+    def scan(seq_t, off_t, n, mode=None, cap=0):
+        mode = mk.MK_MODE_ANY if mode is None else mode
+        flags = torch.empty((n + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        hits = torch.empty(max(cap, 1) * 2, dtype=torch.int64, device=dev)
+        nh = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(npat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        rc = lib.mk_scan_device(m.handle, seq_t.data_ptr(), n * L, off_t.data_ptr(), n, mode, flags.data_ptr(),
+                                hits.data_ptr(), cap, nh.data_ptr(), cnt.data_ptr(), st)
+        assert rc == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        return flags[:n], int(nh.item()), cnt.cpu().numpy()
+
+    f_all, _, c_all = scan(d_seq, d_off, n_rec)
+    f_hit, nh, c_hit = scan(d_seq, d_off, n_rec, mk.MK_MODE_HITS, 2_000_000)
+    assert torch.equal(f_all, f_hit) and np.array_equal(c_all, c_hit) and nh == c_hit[npat + mk.MK_SUM_HITS]
+    shard = 12_500_000  # x 250 B: a multiple of 16 bytes
+    parts, c_sum = [], np.zeros_like(c_all)
+    for b in range(0, n_rec, shard):
+        off_s = (d_off[b:b + shard + 1] - d_off[b]).contiguous()
+        f, _, c = scan(d_seq[b * L:], off_s, shard)
+        parts.append(f)
+        c_sum += c
+    assert torch.equal(torch.cat(parts), f_all)
+    assert np.array_equal(c_all[:npat], c_sum[:npat])
+    for k in (mk.MK_SUM_HITS, mk.MK_SUM_RECORDS_HIT, mk.MK_SUM_RECORDS, mk.MK_SUM_BASES):
+        assert c_all[npat + k] == c_sum[npat + k]
+    n_flag = int(f_all.sum(dtype=torch.int64).item())
+    assert n_rec // 100 * 0.9 < n_flag < n_rec // 100 * 1.2
