@@ -417,7 +417,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // ---- level 1 for one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
     // packed chunk that follows in the text (halo source for the last lanes).  Returns the
     // lane's candidate mask (bit j = sample j passed the filter).  Straight-line code.
-    auto halo = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &w1, uint32_t &w2) {
+    // Every reference-capturing lambda below is always_inline: past some size the inliner leaves
+    // one of them as a real function, its captures (and the kernel arguments) then live in scratch
+    // memory and the LDS ring is reached through flat instructions -- a 3x slower kernel.
+    auto halo = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &w1, uint32_t &w2) __attribute__((always_inline)) {
         // lane i needs the packed dwords of lanes i+1 and i+2; DPP wave_shl:1 moves a whole
         // wave by one lane in one VALU op, lane 63 keeps `old` = the next chunk's lane
         w1 = 0;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
         }
     };
-    auto filter_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &h0, uint32_t &h1) -> uint32_t {
+    auto filter_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &h0, uint32_t &h1) __attribute__((always_inline)) -> uint32_t {
         const uint32_t w0 = pk_cur;
         uint32_t w1, w2;
         halo(pk_cur, pk_nxt, w1, w2);
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     uint64_t pend_t = 0;
     uint4 pend_v0 = make_uint4(0, 0, 0, 0), pend_v1 = pend_v0;
     uint64_t newest_end = 0;  // wave-uniform: every queued position is < newest_end (and > newest_end - 4 GiB)
-    auto take_from_ring = [&](uint32_t n, bool &active, uint32_t &b, uint32_t &fp, uint64_t &t) {
+    auto take_from_ring = [&](uint32_t n, bool &active, uint32_t &b, uint32_t &fp, uint64_t &t) __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
@@ -487,59 +490,74 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         q_head = (q_head + n) & (kRingEntries - 1);
         q_count -= n;
     };
-    auto drain_ring = [&](uint32_t n) {  // synchronous
+    auto drain_ring = [&](uint32_t n) __attribute__((always_inline)) {  // synchronous
         bool active;
         uint32_t b, fp;
         uint64_t t;
         take_from_ring(n, active, b, fp, t);
         probe_chain<EMIT>(P, active, b, fp, t, lane, hr, n_true, lds_pat_cnt);
     };
-    auto issue_probe = [&](uint32_t n) {  // asynchronous: loads only
+    auto issue_probe = [&](uint32_t n) __attribute__((always_inline)) {  // asynchronous: loads only
         take_from_ring(n, pend_active, pend_b, pend_fp, pend_t);
         load_bucket(P, pend_active, pend_b, pend_v0, pend_v1);
         pend_on = true;
     };
-    auto consume_probe = [&]() {
+    auto consume_probe = [&]() __attribute__((always_inline)) {
         const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, n_true, lds_pat_cnt);
         if (__ballot(more))  // some home bucket was full: finish those chains synchronously
             probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, n_true, lds_pat_cnt);
         pend_on = false;
     };
 
-    // ---- level 1 -> 2 hand-off (rare): filter positives of one chunk -> per-wave LDS ring
-    // (ballot/popcount compaction); 64 at a time they are probed against the exact table, so
-    // the L2 round trip is paid once per 64 candidates, not per chunk
-    auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t cand, uint64_t cpos, uint32_t h0, uint32_t h1) {
+    // ---- level 1 -> 2 hand-off: filter positives -> per-wave LDS ring (ballot/popcount
+    // compaction); 64 at a time they are probed against the exact table, so the L2 round trip is
+    // paid once per 64 candidates, not per chunk.  With ~2 positives per 1 KiB chunk almost every
+    // chunk has one somewhere in the wave, and a compaction round per chunk costs as much as
+    // half the filter itself; so a positive first parks in its lane's register slot, and the
+    // slots are compacted into the ring only when some lane needs its slot a second time
+    // (every ~5 chunks: a birthday collision among 64 lanes).
+    uint32_t slot_h = 0, slot_t = 0;
+    bool slot_full = false;
+    auto flush_slots = [&]() __attribute__((always_inline)) {
+        const uint64_t full = __ballot(slot_full);
+        if (!full) return;
+        if (q_count > 64) drain_ring(64);  // an append round adds <= 64 entries to the 128-entry ring
+        if (slot_full) {
+            const uint32_t below =
+                __builtin_amdgcn_mbcnt_hi((uint32_t)(full >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)full, 0u));
+            CandEntry e;
+            e.h = slot_h;
+            e.t_lo = slot_t;
+            ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
+        }
+        q_count += (uint32_t)__popcll(full);
+        n_cand += (uint32_t)__popcll(full);
+        slot_full = false;
+    };
+    auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t cand, uint64_t cpos, uint32_t h0, uint32_t h1) __attribute__((always_inline)) {
         const uint32_t w0 = pk_cur;
         uint32_t w1 = 0, w2 = 0;
         if constexpr (NS > 2) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below
-        newest_end = cpos + kChunkBytes;
+        newest_end = cpos + kChunkBytes;  // parked and queued positions are all below it
         const uint32_t t_base = (uint32_t)cpos + lane * 16;
-        uint64_t any = __ballot(cand != 0);
-        while (any) {  // wave-uniform
-            if (q_count > 64) drain_ring(64);  // an append round adds <= 64 entries to the 128-entry ring
+        do {  // wave-uniform; one iteration unless a lane has several positives in this chunk
+            if (__ballot(cand != 0 && slot_full)) flush_slots();
             if (cand != 0) {
                 const uint32_t j = (uint32_t)__ffs(cand) - 1u;
                 cand &= cand - 1;
-                CandEntry e;
                 if constexpr (NS <= 2) {
-                    e.h = j ? h1 : h0;
+                    slot_h = j ? h1 : h0;
                 } else {  // same value as sample_hash / filter.hpp's bloom_hash of the masked key
                     const uint32_t sh = 2u * j * S;
                     const uint32_t klo = __builtin_amdgcn_alignbit(w1, w0, sh) & mask_lo;  // sh == 0 -> w0
                     const uint32_t khi = __builtin_amdgcn_alignbit(w2, w1, sh) & mask_hi;
                     const uint32_t t = __builtin_amdgcn_alignbit(khi, klo, 24);
-                    e.h = __umul24(klo, 0x9E3779u) + __umul24(t, 0x85EBCBu) + (t & 0xFF000000u);
+                    slot_h = __umul24(klo, 0x9E3779u) + __umul24(t, 0x85EBCBu) + (t & 0xFF000000u);
                 }
-                e.t_lo = t_base + j * S;
-                const uint32_t below =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
+                slot_t = t_base + j * S;
+                slot_full = true;
             }
-            q_count += (uint32_t)__popcll(any);
-            n_cand += (uint32_t)__popcll(any);
-            any = __ballot(cand != 0);
-        }
+        } while (__ballot(cand != 0));
     };
 
     // ---- main phase: tiles whose 32 chunk loads (31 scanned + halo) lie inside the text.
@@ -565,7 +583,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         };
         // four loads off one address register (immediate offsets); the tile wrap is checked
         // once per group so that the group stays one basic block
-        auto load_group = [&](uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+        auto load_group = [&](uint4 &a, uint4 &b, uint4 &c, uint4 &d) __attribute__((always_inline)) {
             a = nt_load(ld_ptr);
             b = nt_load(ld_ptr + kChunkBytes);
             c = nt_load(ld_ptr + 2 * kChunkBytes);
@@ -589,14 +607,15 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         // Queued filter positives carry only the low 32 bits of their position, restored relative to
         // the wave's current position: none may stay queued while the wave advances 4 GiB.  A wave's
         // tiles are n_waves * 31 KiB apart, so every `age_limit` tiles (1 GiB of advance) whatever
-        // is queued is pushed on to level 2 (sparse candidates never reach the ring's fill
-        // threshold by themselves: 1 pattern on 15 GB lost two hits in three before this).
+        // is parked or queued is pushed on to level 2 (sparse candidates never reach the ring's
+        // fill threshold by themselves: 1 pattern on 15 GB lost two hits in three before this).
         const uint32_t age_limit = (uint32_t)std::max<uint64_t>(1, (1ull << 30) / (n_waves * kTileBytes));
         uint32_t tiles_since_push = 0;
         for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
             const uint64_t base = tile * kTileBytes;
             if (++tiles_since_push >= age_limit) {
                 tiles_since_push = 0;
+                flush_slots();
                 if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
             }
 #pragma unroll 1
@@ -676,7 +695,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         }
     }
 
-    // drain what is left in this wave's rings
+    // drain what is left in this wave's slots and rings
+    flush_slots();
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
     if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, lds_pat_cnt);
     if constexpr (EMIT) flush_stage(P, hr, lane);
