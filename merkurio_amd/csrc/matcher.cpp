@@ -276,7 +276,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_wq, (void *)m->d_stage})
+                    (void *)m->d_stage})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -345,13 +345,6 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t waves_per_block = kBlockThreads / 64;
     uint64_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
-    // q-gram-hit rings: 128 entries per scan wave (allocated once for the largest grid)
-    if (!m->d_wq) {
-        const size_t need = (size_t)m->num_cus * waves_per_block * 128 * sizeof(HitCand);
-        MK_HIP(hipMalloc((void **)&m->d_wq, need));
-        m->d_wq_bytes = need;
-    }
-    p.wq = m->d_wq;
     if (mode == MK_MODE_HITS && !m->d_stage) {  // staging of verified occurrences, kHitStage per scan wave
         MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * waves_per_block * kHitStage * sizeof(mk_hit)));
     }

@@ -37,9 +37,6 @@ struct mk_matcher {
     mk_hit *d_hits = nullptr;
     size_t d_hits_cap = 0;
     unsigned long long *d_nhits = nullptr;
-    // per-scan-wave rings of q-gram hits awaiting verification (128 entries each)
-    mk::HitCand *d_wq = nullptr;
-    size_t d_wq_bytes = 0;
     mk_hit *d_stage = nullptr;  // EMIT kernels: per-wave staging of hit tuples
     const char *kernel_name = "";
     int last_grid = 0;

@@ -8,14 +8,6 @@
 
 namespace mk {
 
-// one exact q-gram table hit waiting for full verification: pattern `pat` would start at
-// absolute text position p
-struct alignas(16) HitCand {
-    uint64_t p;
-    uint32_t pat;
-    uint32_t pad;
-};
-
 constexpr uint32_t kHitStage = 1024;  // tuples a wave stages before it reserves output slots
 
 struct ScanParams {
@@ -38,8 +30,6 @@ struct ScanParams {
     uint32_t case_insensitive;
     uint32_t uniform_len;  // > 0: every pattern has this length (pattern i starts at i * uniform_len)
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
-    // per-scan-wave rings of q-gram hits awaiting resolve_one (global memory, 128 entries each)
-    HitCand *wq;
     // per-scan-wave staging of verified occurrences (EMIT kernels; kHitStage tuples each)
     mk_hit *stage;
     // outputs

@@ -67,7 +67,9 @@ struct alignas(8) CandEntry {
 };
 constexpr uint32_t kRingEntries = 128;  // per wave; <= 64 pending before an append round of <= 64
 constexpr uint32_t kLdsPatCounters = 64;  // pattern sets up to this size count their hits in LDS
-constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) + kLdsPatCounters * 8;  // 144.5 KiB
+constexpr uint32_t kHitSlots = 64;  // per wave: verified-q-gram hits waiting for level 3 (one per lane)
+constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) + kLdsPatCounters * 8 +
+                               (kBlockThreads / 64) * kHitSlots * 8;  // 152.5 KiB
 static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
 // compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
@@ -189,15 +191,18 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     return true;
 }
 
-// ---- per-wave ring of q-gram hits (global memory, L2-resident: 128 x 16 B per wave) --------
-// True q-gram hits are rare; resolving them the moment they are found would run the ~5
-// dependent memory round trips of resolve_one with one or two active lanes.  They are
-// queued instead and resolved 64 at a time (one per lane).
-constexpr uint32_t kHitRing = 128;
+// ---- per-wave buffer of q-gram hits (LDS, 64 x 8 B) ---------------------------------------------
+// True q-gram hits are rare; resolving them the moment they are found would run the dependent
+// memory round trips of resolve_one with one or two active lanes.  They are collected instead
+// and resolved up to 64 at a time (one per lane).  The buffer lives in LDS: a global-memory
+// ring cost one store per hit whose acknowledgement the wave's next s_waitcnt vmcnt(0) had to
+// wait for (loads and stores share the counter on gfx9) -- 0.1 ms per million hits on the
+// slower boxes of the pool -- plus two L2 round trips per drain to read the ring back.
+// An entry is {low 32 bits of the occurrence's text position, pattern}; the high bits are
+// restored relative to the wave's newest queued position like a CandEntry's.
 struct HitRing {
-    HitCand *q;      // this wave's ring
-    uint32_t head;   // wave-uniform
-    uint32_t count;  // wave-uniform
+    uint2 *q;        // this wave's buffer (LDS)
+    uint32_t count;  // wave-uniform, <= kHitSlots
     // EMIT: verified occurrences of this wave, staged in global memory and moved to the output
     // array kHitStage - 64 or more at a time.  The output cursor is ONE address: an atomic on it
     // costs ~10 ns whoever issues it, so reserving 64 slots per atomic caps the kernel at ~6 G
@@ -228,19 +233,22 @@ __device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, ui
 }
 
 template <bool EMIT>
-__device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint32_t n, uint32_t lane, uint32_t &n_true,
+__device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint64_t newest_end, uint32_t lane, uint32_t &n_true,
                                            unsigned long long *lds_pat_cnt) {
-    // entries were stored by other lanes of this wave: same CU, same L1; order the accesses
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t n = hr.count;
+    // entries were written by other lanes of this wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint2 e = hr.q[lane & (kHitSlots - 1)];
+    __builtin_amdgcn_wave_barrier();
     bool hit = false;
     mk_hit out;
     if (lane < n) {
-        const HitCand h = hr.q[(hr.head + lane) & (kHitRing - 1)];
-        hit = resolve_one<EMIT>(P, h.pat, h.p, n_true, lds_pat_cnt, out);
+        uint64_t p = (newest_end & 0xFFFFFFFF00000000ull) | e.x;
+        if (p >= newest_end) p -= 1ull << 32;
+        hit = resolve_one<EMIT>(P, e.y, p, n_true, lds_pat_cnt, out);
     }
-    hr.head = (hr.head + n) & (kHitRing - 1);
-    hr.count -= n;
+    hr.count = 0;
     if constexpr (EMIT) {
         const uint64_t mm = __ballot(hit);
         if (mm) {
@@ -261,7 +269,8 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
 // hit ring; returns whether this lane must look at the next bucket (its bucket was full).
 template <bool EMIT>
 __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint64_t t, uint4 v0, uint4 v1,
-                                            uint32_t lane, HitRing &hr, uint32_t &n_true, unsigned long long *lds_pat_cnt) {
+                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true,
+                                            unsigned long long *lds_pat_cnt) {
     const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
     const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
 #pragma unroll
@@ -270,17 +279,14 @@ __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, ui
         const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
         const uint64_t mm = (MK_ABLATE & 64) ? 0ull : __ballot(match);
         if (mm) {  // uniform, rare
+            const uint32_t cnt = (uint32_t)__popcll(mm);
+            if (hr.count + cnt > kHitSlots) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);  // make room
             if (match) {
                 const uint32_t below =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                HitCand h;
-                h.p = t - e_off;
-                h.pat = e_pat;
-                h.pad = 0;
-                hr.q[(hr.head + hr.count + below) & (kHitRing - 1)] = h;
+                hr.q[hr.count + below] = make_uint2((uint32_t)(t - e_off), e_pat);
             }
-            hr.count += (uint32_t)__popcll(mm);  // < 64 before, <= 127 now
-            if (hr.count >= 64) drain_hits<EMIT>(P, hr, 64, lane, n_true, lds_pat_cnt);
+            hr.count += cnt;
         }
     }
     return active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
@@ -300,11 +306,12 @@ __device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, ui
 // bucket is full), each iteration one memory round trip
 template <bool EMIT>
 __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint64_t t,
-                                            uint32_t lane, HitRing &hr, uint32_t &n_true, unsigned long long *lds_pat_cnt) {
+                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true,
+                                            unsigned long long *lds_pat_cnt) {
     while (__ballot(active)) {
         uint4 v0, v1;
         load_bucket(P, active, b, v0, v1);
-        active = probe_round<EMIT>(P, active, fp, t, v0, v1, lane, hr, n_true, lds_pat_cnt);
+        active = probe_round<EMIT>(P, active, fp, t, v0, v1, lane, hr, newest_end, n_true, lds_pat_cnt);
         b = (b + 1) & P.table_mask;
     }
 }
@@ -405,8 +412,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     CandEntry *ring = reinterpret_cast<CandEntry *>(bloom + kBloomWords) + wave_in_block * kRingEntries;
     uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
     HitRing hr;  // this wave's q-gram-hit ring
-    hr.q = P.wq + wave_id * (uint64_t)kHitRing;
-    hr.head = 0;
+    hr.q = reinterpret_cast<uint2 *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2 + kLdsPatCounters * 2) +
+           wave_in_block * kHitSlots;
     hr.count = 0;
     hr.stage = EMIT ? P.stage + wave_id * (uint64_t)kHitStage : nullptr;
     hr.staged = 0;
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint32_t b, fp;
         uint64_t t;
         take_from_ring(n, active, b, fp, t);
-        probe_chain<EMIT>(P, active, b, fp, t, lane, hr, n_true, lds_pat_cnt);
+        probe_chain<EMIT>(P, active, b, fp, t, lane, hr, newest_end, n_true, lds_pat_cnt);
     };
     auto issue_probe = [&](uint32_t n) __attribute__((always_inline)) {  // asynchronous: loads only
         take_from_ring(n, pend_active, pend_b, pend_fp, pend_t);
@@ -503,9 +510,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         pend_on = true;
     };
     auto consume_probe = [&]() __attribute__((always_inline)) {
-        const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, n_true, lds_pat_cnt);
+        const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true, lds_pat_cnt);
         if (__ballot(more))  // some home bucket was full: finish those chains synchronously
-            probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, n_true, lds_pat_cnt);
+            probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, newest_end, n_true, lds_pat_cnt);
         pend_on = false;
     };
 
@@ -616,6 +623,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             if (++tiles_since_push >= age_limit) {
                 tiles_since_push = 0;
                 flush_slots();
+                if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);  // 32-bit positions too
                 if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
             }
 #pragma unroll 1
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // drain what is left in this wave's slots and rings
     flush_slots();
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
-    if (hr.count) drain_hits<EMIT>(P, hr, hr.count, lane, n_true, lds_pat_cnt);
+    if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);
     if constexpr (EMIT) flush_stage(P, hr, lane);
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
