@@ -60,7 +60,9 @@ typedef struct mk_matcher mk_matcher;
 
 /* one occurrence: pattern `pat` (index into the sorted unique pattern list) starts at byte
  * `pos` (0-based) of record `rec`.  == (mat.pattern().as_usize(), mat.start()) of
- * src/cmd_extract.rs:341-342 and the `o` of BNDMq::find_iter (src/cmd_extract.rs:367). */
+ * src/cmd_extract.rs:341-342 and the `o` of BNDMq::find_iter (src/cmd_extract.rs:367).
+ * Limits of this build: a single record shorter than 4 GiB (`pos` is 32 bits; a batch may hold
+ * any number of bytes and records), at most 2^28 - 1 patterns. */
 typedef struct {
     uint64_t rec;
     uint32_t pat;
