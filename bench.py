@@ -4,61 +4,101 @@
 One "step" = one pass of the hot path (mk_scan_device, any-hit flags = `merkurio extract`
 without logging) over one device-resident batch of synthetic reads.  Workload at N=1: the
 configuration BASELINE.json's metric is quoted on: 100 M x 150 bp reads, 10 k 31-mers
-(Aho-Corasick by the reference's selection rule).  N>1: one process per GPU, every rank scans
-its own 100 M-read shard (weak scaling, no data-path collective); the only collective is the
-RCCL all-reduce of the hit-count / summary vector at the end of the job.
+(Aho-Corasick by the reference's selection rule).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--records R] [--read-len L]
-                    [--patterns P] [--k K] [--no-cpu-baseline]
+N>1: one process per GPU, records sharded in contiguous ranges (pairs never split), no
+data-path collective; the only collective is the RCCL all-reduce of the hit-count / summary
+vector at the end of the job (mk_comm_reduce_counters of the C ABI).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM) and
-`cpu_baseline` objects.
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--scaling weak|strong] [--total-records R] [--paired]
+                    [--records R] [--read-len L] [--patterns P] [--k K] [--mode any|hits] ...
+
+  --scaling weak    (default) every rank scans --records reads: the job grows with N
+  --scaling strong  the job is --total-records reads (or pairs with --paired) divided over the
+                    ranks: BASELINE config 3 = --scaling strong --paired --total-records 50000000,
+                    config 5 = --scaling strong --total-records 100000000 --read-len 250
+                    --patterns 500000 --k 21
+
+`python bench.py --gpus N` starts its own N ranks (torch.distributed.run as a child process,
+before this process has touched a GPU); under an external launcher (WORLD_SIZE == N already)
+it runs as one rank.  With fewer GPUs than ranks (a 1-GPU box) it runs in REHEARSAL mode:
+ranks share devices round-robin, process group on gloo, counter reduction through
+torch.distributed -- functional check only, marked "rehearsal": true in the output.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM) and,
+at N=1, `cpu_baseline` objects.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+KERNEL_SOURCES = ["merkurio_amd/csrc/scan_kernel_impl.hpp", "merkurio_amd/csrc/filter.hpp"]
+
+
+def kernel_source_hash():
+    """sha256 over the files that define the scan kernel: a PMC traffic figure is only valid for
+    the kernel body it was measured on"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(kernel, n_rec, read_len, n_pat):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this
-    exact workload (profiles/traffic_rNN.json: rocprofv3 FETCH_SIZE/WRITE_SIZE passes, gfx950
-    correction applied); None if no such profile is committed."""
+    exact workload AND this exact kernel source (profiles/traffic_rNN.json: rocprofv3
+    FETCH_SIZE/WRITE_SIZE passes, gfx950 correction applied).  -> (bytes | None, source note)"""
     import glob
-    best = None
+    cur = kernel_source_hash()
+    best, stale = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
         try:
             j = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if (j.get("kernel"), j.get("records_per_gpu"), j.get("read_len"), j.get("patterns")) == \
+        if (j.get("kernel"), j.get("records_per_gpu"), j.get("read_len"), j.get("patterns")) != \
                 (kernel, n_rec, read_len, n_pat):
+            continue
+        if j.get("kernel_source_sha16") == cur:
             best = (j["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
-    return best
+        else:
+            stale = os.path.relpath(f, ROOT)
+    if best:
+        return best
+    if stale:
+        return None, f"refused: {stale} was measured on a different kernel source (now {cur})"
+    return None, None
 
 
 def make_patterns(n, k, seed=0x4D65724B):
+    import numpy as np
     rng = np.random.default_rng(seed)
     codes = rng.integers(0, 4, size=(int(n * 1.01) + 8, k), dtype=np.uint8)
     arr = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
     return [arr[i].tobytes() for i in range(arr.shape[0])]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--records", type=int, default=100_000_000, help="weak scaling: reads (or pairs) per GPU")
+    ap.add_argument("--total-records", type=int, default=0, help="strong scaling: reads (or pairs) of the whole job")
+    ap.add_argument("--paired", action="store_true", help="paired-end: two mate batches per step, pairs never split")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--patterns", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=31)
@@ -70,31 +110,62 @@ def main():
     ap.add_argument("--no-counters", action="store_true", help="diagnostic: scan without the device counter vector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
-    args = ap.parse_args()
+    # filter-geometry tuning hooks (mk_matcher_options; results never depend on them)
+    ap.add_argument("--force-stride", type=int, default=0)
+    ap.add_argument("--force-global-filter", action="store_true")
+    ap.add_argument("--gbloom-log2-blocks", type=int, default=0)
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """--gpus N without an external launcher: start N ranks as a child job and relay its output.
+    Nothing in this (parent) process has touched HIP or torch.cuda."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env != args.gpus:
+        if "RANK" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world_env}")
+        raise SystemExit(spawn_ranks(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from merkurio_amd import native as mk
     from merkurio_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    # rehearsal hook: MERKURIO_BENCH_BACKEND=gloo runs several ranks on fewer GPUs (rank -> device
-    # round-robin); the measured configuration is one rank per GPU over nccl (= RCCL)
-    backend = os.environ.get("MERKURIO_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    world = world_env if args.gpus > 1 else 1
+    rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the scan path has no CPU fallback)")
+    rehearsal = world > n_dev  # fewer GPUs than ranks: functional rehearsal, ranks share devices
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
+    use_dist = world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
 
     # ---- pattern set (identical on every rank) and matcher
     raw = make_patterns(args.patterns, args.k)
@@ -102,23 +173,43 @@ def main():
     assert len(patterns) == args.patterns
     if args.rc:
         patterns = mk.parse_pattern_list(kmer_seq=patterns, reverse_complement=True)
-    m = mk.Matcher(patterns, device=dev_index)
+    options = None
+    if args.force_stride or args.force_global_filter or args.gbloom_log2_blocks:
+        options = dict(force_stride=args.force_stride, force_global_filter=args.force_global_filter,
+                       gbloom_log2_blocks=args.gbloom_log2_blocks)
+    m = mk.Matcher(patterns, device=dev_index, options=options)
     assert m.use_ac == mk.recommend_aho_corasick(patterns)
     lib = mk.load()
 
-    # ---- device-resident synthetic batch (records shard = rank)
-    n_rec, L = args.records, args.read_len
+    # ---- this rank's shard of the job: contiguous range of records (pairs), in units of 16 so
+    # that every shard starts on a block of the counter-based generator
+    L = args.read_len
+    if args.scaling == "strong":
+        total = (args.total_records or args.records) // 16 * 16
+        lo, hi = [16 * b for b in sharding.shard_bounds(total // 16, world)[rank]]
+    else:
+        total = args.records * world
+        lo, hi = rank * args.records, (rank + 1) * args.records
+        if (lo * L) % 32:
+            raise SystemExit("weak scaling with N > 1 needs --records * --read-len divisible by 32")
+    n_rec = hi - lo
     n_bytes = n_rec * L
-    seed = 0x4D65724B7572696F + rank
-    d_seq = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
-    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
-    d_flags = torch.empty((n_rec + 7) // 4 * 4, dtype=torch.uint8, device=dev)
-    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
-    d_cnt = torch.zeros(len(patterns) + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+    n_mates = 2 if args.paired else 1
+    seed = 0x4D65724B7572696F
     stream = torch.cuda.current_stream()
     st = stream.cuda_stream
-    rc = lib.mk_synth_reads_device(m.handle, seed, n_rec, L, args.plant_every, d_seq.data_ptr(), d_off.data_ptr(), st)
-    assert rc == 0, lib.mk_last_error()
+    mates = []
+    for f in range(n_mates):
+        d_seq = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+        d_flags = torch.empty((n_rec + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        rc = lib.mk_synth_reads_device_range(m.handle, seed + f, lo, n_rec, L, args.plant_every, d_seq.data_ptr(),
+                                             d_off.data_ptr(), st)
+        assert rc == 0, lib.mk_last_error()
+        mates.append((d_seq, d_off, d_flags))
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_cnt = torch.zeros(len(patterns) + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+    d_keep = torch.empty_like(mates[0][2]) if args.paired else None
     torch.cuda.synchronize()
 
     emit = args.mode == "hits"
@@ -126,35 +217,75 @@ def main():
     d_hits = torch.empty(2 * hits_cap, dtype=torch.int64, device=dev) if emit else None
 
     def step():
-        rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec,
-                                mk.MK_MODE_HITS if emit else mk.MK_MODE_ANY, d_flags.data_ptr(),
-                                d_hits.data_ptr() if emit else None, hits_cap, d_nh.data_ptr(),
-                                None if args.no_counters else d_cnt.data_ptr(), st)
-        if rc != 0:
-            raise RuntimeError(lib.mk_last_error().decode())
+        for d_seq, d_off, d_flags in mates:
+            rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec,
+                                    mk.MK_MODE_HITS if emit else mk.MK_MODE_ANY, d_flags.data_ptr(),
+                                    d_hits.data_ptr() if emit else None, hits_cap, d_nh.data_ptr(),
+                                    None if args.no_counters else d_cnt.data_ptr(), st)
+            if rc != 0:
+                raise RuntimeError(lib.mk_last_error().decode())
+        if args.paired:  # a pair is kept if either mate hits (src/cmd_extract.rs:600-606)
+            torch.bitwise_or(mates[0][2], mates[1][2], out=d_keep)
 
     def barrier():
         if use_dist:
-            if backend == "nccl":
-                dist.barrier(device_ids=[dev_index])
-            else:
+            if rehearsal:
                 dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev_index])
         torch.cuda.synchronize()
+
+    # ---- the job's only collective, through the C ABI (RCCL); torch.distributed carries the id
+    reduce_via = "none (1 GPU)"
+    if use_dist and not rehearsal:
+        # every rank first checks that it can bind RCCL through the library (a probe id), and all
+        # ranks agree before any of them enters the collective init: none may wait for a peer
+        # that has already given up
+        buf = np.zeros(mk.MK_COMM_ID_BYTES, dtype=np.uint8)
+        ok = torch.tensor([1 if lib.mk_comm_unique_id(buf.ctypes.data) == 0 else 0], dtype=torch.int32, device=dev)
+        why = "" if int(ok.item()) else lib.mk_last_error().decode()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            idt = torch.from_numpy(buf).to(dev)  # rank 0's id is the job's id
+            dist.broadcast(idt, src=0)
+            idb = idt.cpu().numpy().copy()
+            ok = torch.tensor([1 if lib.mk_comm_init(m.handle, idb.ctypes.data, rank, world) == 0 else 0],
+                              dtype=torch.int32, device=dev)
+            why = "" if int(ok.item()) else lib.mk_last_error().decode()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            reduce_via = "mk_comm_reduce_counters (RCCL ncclAllReduce, C ABI)"
+        else:  # same sum either way; say which path ran and why
+            reduce_via = f"torch.distributed all_reduce over RCCL (C-ABI communicator unavailable on some rank: {why})"
+    elif use_dist:
+        reduce_via = "torch.distributed all_reduce over gloo (rehearsal)"
+
+    def reduce_counters():
+        if not use_dist:
+            return
+        if reduce_via.startswith("mk_comm"):
+            mk._check(lib.mk_comm_reduce_counters(m.handle, d_cnt.data_ptr(), d_cnt.numel(), st))
+        elif rehearsal:
+            t = d_cnt.cpu()
+            sharding.all_reduce_counters(t)
+            d_cnt.copy_(t)
+        else:
+            sharding.all_reduce_counters(d_cnt)
 
     for _ in range(args.warmup):
         step()
     barrier()
     d_cnt.zero_()
-    m.enable_timing(args.steps)
+    m.enable_timing(args.steps * n_mates)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sharding.all_reduce_counters(d_cnt)  # the job's only collective: hit-count / summary vector (RCCL over xGMI)
+    reduce_counters()  # hit-count / summary vector (RCCL over xGMI), once per job
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms = m.kernel_times_ms()
@@ -162,12 +293,14 @@ def main():
     summ = cnt[len(patterns):]
 
     if rank == 0:
-        total_bases = world * n_bytes * args.steps
+        total_bases = total * n_mates * L * args.steps
         value = total_bases / dt / 1e9
         k_avg_ms = float(np.mean(kernel_ms))
-        algo_bytes = n_bytes * 1 + n_rec * 9  # 1 B/base + u64 offset + 1 B flag per record
+        algo_bytes = n_bytes * 1 + n_rec * 9  # 1 B/base + u64 offset + 1 B flag per record, per launch
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
+        job_bytes = (total * n_mates) * (L + 9) * args.steps
         info = dict(m.filter_info(), **m.filter_mode())
+        what = "pairs" if args.paired else "reads"
         out = {
             "metric": "Gbases/s scanned (150bp FASTQ, 10k 31-mers); % HBM roofline at 1/2/4/8 GPUs",
             "value": round(value, 3),
@@ -177,15 +310,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"extract ({'all hit tuples' if emit else 'any-hit flags'}): {n_rec} x {L} bp synthetic reads per GPU, "
+                "workload": f"extract{' -2 (paired)' if args.paired else ''} ({'all hit tuples' if emit else 'any-hit flags'}): "
+                            f"{total} x {L} bp synthetic {what} in the job, {n_rec} per GPU on rank 0, "
                             f"{len(patterns)} {args.k}-mers, Aho-Corasick semantics, 1/{args.plant_every} reads planted",
-                "records_per_gpu": n_rec, "read_len": L, "patterns": len(patterns), "k": args.k,
-                "sharding": f"records x{world}", "kernel": m.kernel_name, "filter": info,
+                "records_total": total, "records_per_gpu": n_rec, "paired": args.paired, "read_len": L,
+                "patterns": len(patterns), "k": args.k,
+                "sharding": f"contiguous record ranges x{world}" + (", pairs unsplit" if args.paired else ""),
+                "counter_reduction": reduce_via, "kernel": m.kernel_name, "filter": info,
             },
             "roofline": {
                 "bound": "hbm",
@@ -199,19 +335,24 @@ def main():
                 "kernel_ms_median": round(float(np.median(kernel_ms)), 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "launches_per_step": n_mates,
+                # whole job against N x peak (wall time, all ranks): the multi-GPU roofline figure
+                "job_frac_of_n_x_peak": round(job_bytes / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
             },
             "summary": {"hits": int(summ[mk.MK_SUM_HITS]), "records_hit": int(summ[mk.MK_SUM_RECORDS_HIT]),
                         "records": int(summ[mk.MK_SUM_RECORDS]), "bases": int(summ[mk.MK_SUM_BASES]),
                         "filter_candidates": int(summ[mk.MK_SUM_CANDIDATES])},
         }
-        tr = measured_traffic(m.kernel_name, n_rec, L, len(patterns))
-        if tr:
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, d_flags,
+        if rehearsal:
+            out["rehearsal"] = True
+            out["rehearsal_note"] = f"{world} ranks share {n_dev} GPU(s): functional check, not a scaling measurement"
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, len(patterns))
+        if world == 1 and not args.no_cpu_baseline and not args.paired:
+            out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, mates[0][2],
                                                args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
+        barrier()
         dist.destroy_process_group()
 
 
@@ -229,7 +370,7 @@ def host_cores():
                 n = min(n, max(1, int(quota) // int(period)))
         except (OSError, ValueError):
             pass
-    return min(n, int(os.environ.get("MERKURIO_BENCH_CPU_THREADS", "16")))  # a 1-GPU box's CPU share is 16
+    return min(n, 16)  # a 1-GPU box's CPU share is 16
 
 
 def cpu_baseline(mk, m, patterns, seed, n_rec, L, plant_every, d_flags, target_s):
@@ -237,6 +378,7 @@ def cpu_baseline(mk, m, patterns, seed, n_rec, L, plant_every, d_flags, target_s
     Aho-Corasick DFA, first-hit break per record (src/cmd_extract.rs:332-335), 1 thread --
     the reference matcher is single-threaded.  Timed on a bounded sample (the first M reads
     of rank 0's shard); the GPU flags for the same reads are checked against it."""
+    import numpy as np
     import oracle_binding as ob
     lib = mk.load()
     om = ob.Matcher(patterns, True, 0, False)

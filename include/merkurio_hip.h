@@ -12,10 +12,14 @@
  * Conventions
  *  - plain pointers and sizes only; no C++/torch types cross the boundary;
  *  - every function returns 0 (MK_OK) or a negative MK_E_* code; mk_last_error() gives the
- *    text for the calling thread; nothing throws across the ABI;
+ *    text for the calling thread; nothing throws across the ABI (host allocation failures and
+ *    hipErrorOutOfMemory come back as MK_E_NOMEM);
  *  - there is NO CPU fallback: without a usable HIP device creation fails with MK_E_HIP;
- *  - a matcher handle is bound to one HIP device; scans on a handle are serialised;
- *    distinct handles (one per GPU / per process) are independent;
+ *  - a matcher handle is bound to one HIP device and supports ONE scan in flight at a time
+ *    (its tuple staging buffer, timing events and launch bookkeeping are per handle): enqueue
+ *    the next scan of a handle on the same stream, or after the previous one has completed;
+ *    distinct handles (one per GPU / per process / per stream) are independent;
+ *  - nothing here reads environment variables: tuning goes through mk_matcher_options;
  *  - the caller owns every buffer it passes; the library copies patterns at create time.
  */
 #ifndef MERKURIO_HIP_H
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 1
+#define MK_ABI_VERSION 2
 
 /* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
 #define MK_OK 0
@@ -42,6 +46,7 @@ extern "C" {
 #define MK_E_CAPACITY (-8)      /* output buffer too small; required size is reported */
 #define MK_E_INVALID_ARG (-9)
 #define MK_E_UNSUPPORTED (-10)
+#define MK_E_RCCL (-11) /* RCCL missing or a collective failed (counter reduction only) */
 
 /* algorithm selector: what the reference's `-a` / `-q` / auto rule decides
  * (src/cmd_extract.rs:166-171, src/helpers.rs:203-211).  The device scan is the same for
@@ -136,6 +141,16 @@ void mk_free(void *p);
  * ---------------------------------------------------------------------------------- */
 int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
                       uint32_t flags, int32_t device, mk_matcher **out);
+/* Same, with explicit tuning / test options (NULL = defaults = mk_matcher_create).  Options never
+ * change results, only the filter geometry the scan kernel runs with. */
+typedef struct {
+    uint32_t struct_size;         /* = sizeof(mk_matcher_options); lets the struct grow compatibly */
+    uint32_t force_stride;        /* 0 = geometry rule; else sampling stride 1, 2, 4, 8 or 16 */
+    uint32_t force_global_filter; /* 1 = level-1 filter in global memory even for small sets */
+    uint32_t gbloom_log2_blocks;  /* 0 = rule; else log2 of the number of 64-bit blocks of a global filter */
+} mk_matcher_options;
+int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
+                         uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out);
 void mk_matcher_destroy(mk_matcher *m);
 /* MK_ALGO_AC or MK_ALGO_BNDMQ after the auto rule was applied */
 uint32_t mk_matcher_algo(const mk_matcher *m);
@@ -250,6 +265,34 @@ int mk_synth_reads_device(mk_matcher *m, uint64_t seed, uint64_t n_rec, uint32_t
                           void *d_seq, void *d_seq_off, void *stream);
 int mk_synth_reads_host(const mk_matcher *m, uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len,
                         uint32_t plant_every, uint8_t *seq, uint64_t *seq_off);
+/* records [rec0, rec0 + n_rec) of the same synthetic job (a rank's shard of a strong-scaled run):
+ * d_seq_off is relative to the shard; rec0 * read_len must be a multiple of 32 */
+int mk_synth_reads_device_range(mk_matcher *m, uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len,
+                                uint32_t plant_every, void *d_seq, void *d_seq_off, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU: the counter reduction (the path's only collective)
+ * Records shard across GPUs with no data-path exchange; at the end of a job the per-GPU
+ * vectors uint64[n_pat + MK_NUM_SUMMARY] (pattern_hit_counts | the scalars of
+ * src/cmd_extract.rs:285-290, src/cmd_tag.rs:360-364) are summed with RCCL ncclAllReduce
+ * over xGMI.  librccl is bound at run time; without it these calls return MK_E_RCCL.
+ *
+ * One process, one handle per GPU:  mk_reduce_counters(handles, n, vectors, len, host_sum)
+ * sums d_counters[0..n) element-wise IN PLACE (every vector holds the sum on return) and
+ * copies it to host_sum (may be NULL).  d_counters[i] is a device pointer on handles[i]'s
+ * device.  Handles that share a device are added on that device first; the all-reduce runs
+ * over the distinct devices.  Blocking: waits for all work enqueued on those devices.
+ *
+ * One process per GPU:  rank 0 calls mk_comm_unique_id and hands the id bytes to the other
+ * ranks (file, MPI, torch.distributed, ...); every rank calls mk_comm_init (collective), then
+ * mk_comm_reduce_counters enqueues the in-place all-reduce on `stream`.
+ * ---------------------------------------------------------------------------------- */
+#define MK_COMM_ID_BYTES 128
+int mk_reduce_counters(mk_matcher *const *per_gpu, int n, void *const *d_counters, size_t len, uint64_t *host_sum);
+int mk_comm_unique_id(uint8_t id[MK_COMM_ID_BYTES]);
+int mk_comm_init(mk_matcher *m, const uint8_t id[MK_COMM_ID_BYTES], int rank, int n_ranks);
+int mk_comm_reduce_counters(mk_matcher *m, void *d_counters, size_t len, void *stream);
+int mk_comm_destroy(mk_matcher *m);
 
 #ifdef __cplusplus
 }

@@ -1,13 +1,19 @@
 """Builds libmerkurio_hip.so (hand-written gfx950 kernels + C-ABI host code) in-tree with hipcc.
 
-    python -m merkurio_amd.build [--force]
+    python -m merkurio_amd.build [--force] [--tag NAME --flags "-DMK_ABLATE=1 ..."]
 
 hipcc cross-compiles for gfx950 without a GPU; the built .so travels to the GPU box with the
-repository snapshot (it is git-ignored, not gpurun-ignored).
+repository snapshot (it is git-ignored, not gpurun-ignored).  The scan kernel has ~60 template
+variants; they are compiled as independent translation units (scan_variants.hip with
+-DMK_TU=n) in parallel and linked into one library.
+
+--tag NAME builds merkurio_amd/lib/libmerkurio_hip_NAME.so with extra flags (A/B and ablation
+builds for the scripts under tools/; select one at run time with MERKURIO_LIB_PATH).
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -15,11 +21,13 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmerkurio_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "merkurio")
 
-LIB_SOURCES = ["scan_kernel.hip", "matcher.cpp", "host_patterns.cpp", "host_loops.cpp"]
+N_VARIANT_TUS = 6
+HOST_SOURCES = ["matcher.cpp", "host_patterns.cpp", "host_loops.cpp", "reduce.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 # profiling builds: MERKURIO_HIPCC_FLAGS="-DMK_ABLATE=1" python -m merkurio_amd.build --force
 FLAGS += os.environ.get("MERKURIO_HIPCC_FLAGS", "").split()
+JOBS = int(os.environ.get("MERKURIO_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))
 
 
 def _stale(target, deps):
@@ -29,10 +37,49 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "merkurio_hip.h"))
+    return hs
+
+
+def _units():
+    """(object name, source file, extra flags) of every translation unit of the library"""
+    units = [("scan_tu%d.o" % n, "scan_variants.hip", ["-DMK_TU=%d" % n]) for n in range(N_VARIANT_TUS)]
+    units.append(("scan_kernel.o", "scan_kernel.hip", []))
+    units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    return units
+
+
 def _deps():
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "merkurio_hip.h"))
-    return deps
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + _headers()
+
+
+def _compile_lib(out_path, extra_flags, obj_dir, force, verbose):
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = _headers()
+    jobs = []
+    objs = []
+    for obj, src, fl in _units():
+        o = os.path.join(obj_dir, obj)
+        s = os.path.join(CSRC, src)
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([HIPCC, *FLAGS, *extra_flags, *fl, "-c", "-o", o, s])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max(1, JOBS)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(out_path, objs):
+        tmp = out_path + ".tmp.%d" % os.getpid()
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", tmp, *objs, "-ldl", "-lpthread"])
+        os.replace(tmp, out_path)
+    return out_path
 
 
 def build_lib(force=False, verbose=False):
@@ -45,13 +92,14 @@ def build_lib(force=False, verbose=False):
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or _stale(LIB_PATH, _deps()):  # still stale once we hold the lock
-            tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-            cmd = [HIPCC, *FLAGS, "-shared", "-o", tmp] + [os.path.join(CSRC, s) for s in LIB_SOURCES]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            os.replace(tmp, LIB_PATH)
+            _compile_lib(LIB_PATH, [], os.path.join(LIB_DIR, "obj"), force, verbose)
     return LIB_PATH
+
+
+def build_tagged(tag, flags, force=False, verbose=False, only_scan=True):
+    """A/B or ablation build: libmerkurio_hip_<tag>.so compiled with extra `flags`."""
+    out = os.path.join(LIB_DIR, "libmerkurio_hip_%s.so" % tag)
+    return _compile_lib(out, list(flags), os.path.join(LIB_DIR, "obj_" + tag), force, verbose)
 
 
 def build_cli(force=False, verbose=False):
@@ -63,11 +111,24 @@ def build_cli(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, "cli", f) for f in os.listdir(os.path.join(CSRC, "cli"))] + [LIB_PATH]
     if not force and not _stale(CLI_PATH, deps):
         return CLI_PATH
-    cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-o", CLI_PATH, *srcs, "-L" + LIB_DIR,
-           "-lmerkurio_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    obj_dir = os.path.join(LIB_DIR, "obj_cli")
+    os.makedirs(obj_dir, exist_ok=True)
+    cli_hdrs = [os.path.join(CSRC, "cli", f) for f in os.listdir(os.path.join(CSRC, "cli")) if f.endswith(".hpp")] + _headers()
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(obj_dir, os.path.basename(s).replace(".cpp", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + cli_hdrs):
+            jobs.append([HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-c", "-o", o, s])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max(1, JOBS)) as ex:
+        list(ex.map(run, jobs))
+    run([HIPCC, "-o", CLI_PATH, *objs, "-L" + LIB_DIR, "-lmerkurio_hip", "-lz", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return CLI_PATH
 
 
@@ -78,4 +139,9 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--tag" in sys.argv:
+        tag = sys.argv[sys.argv.index("--tag") + 1]
+        fl = sys.argv[sys.argv.index("--flags") + 1].split() if "--flags" in sys.argv else []
+        print(build_tagged(tag, fl, force="--force" in sys.argv, verbose=True))
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

@@ -10,6 +10,8 @@
 #include <cstring>
 #include <ctime>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../../include/merkurio_hip.h"
 #include "io.hpp"
 
@@ -113,7 +115,52 @@ static void open_loggers(const CommonArgs &a, Loggers &lg) {
     lg.active = a.out_log || a.json_log;
 }
 
-static mk_matcher *make_matcher(const CommonArgs &a, const Patterns &p, bool *use_ac) {
+// ---- --gpus N: one matcher handle + one host thread per device, contiguous record ranges ---------
+// [lo, hi) of shard d of n units over `parts` shards, sizes differing by at most one (the same
+// rule as merkurio_amd/sharding.py): concatenating shard outputs in device order reproduces the
+// single-device output order (pairs are units, never split: src/cmd_extract.rs:463-468)
+static std::pair<size_t, size_t> shard_range(size_t n, size_t parts, size_t d) {
+    const size_t base = n / parts, rem = n % parts;
+    const size_t lo = d * base + std::min(d, rem);
+    return {lo, lo + base + (d < rem ? 1 : 0)};
+}
+
+// the scalars of src/cmd_extract.rs:285-290 / src/cmd_tag.rs:360-364 and pattern_hit_counts of every
+// device, summed by the library's RCCL all-reduce (mk_reduce_counters): the job's only collective
+static void reduce_device_counters(const std::vector<mk_matcher *> &ms, const std::vector<int> &devs,
+                                   const std::vector<mk_counters> &cs, const std::vector<std::vector<uint32_t>> &counts,
+                                   mk_counters &c, std::vector<uint32_t> &total_counts) {
+    const size_t n_pat = total_counts.size(), len = n_pat + 8;
+    std::vector<void *> dptr(ms.size(), nullptr);
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) bail(std::string(what) + ": " + hipGetErrorString(e));
+    };
+    for (size_t d = 0; d < ms.size(); ++d) {
+        std::vector<uint64_t> v(len, 0);
+        for (size_t k = 0; k < n_pat; ++k) v[k] = counts[d][k];
+        v[n_pat + 0] = cs[d].nb_records_tot; v[n_pat + 1] = cs[d].nb_bases;
+        v[n_pat + 2] = cs[d].nb_hits_tot[0]; v[n_pat + 3] = cs[d].nb_hits_tot[1];
+        v[n_pat + 4] = cs[d].nb_records_hit[0]; v[n_pat + 5] = cs[d].nb_records_hit[1];
+        v[n_pat + 6] = cs[d].nb_records_extracted;
+        hip_ok(hipSetDevice(devs[d]), "hipSetDevice");
+        hip_ok(hipMalloc(&dptr[d], len * sizeof(uint64_t)), "hipMalloc(counter vector)");
+        hip_ok(hipMemcpy(dptr[d], v.data(), len * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy(counter vector)");
+    }
+    std::vector<uint64_t> sum(len, 0);
+    const int rc = mk_reduce_counters(ms.data(), (int)ms.size(), dptr.data(), len, sum.data());
+    for (size_t d = 0; d < ms.size(); ++d) {
+        (void)hipSetDevice(devs[d]);
+        (void)hipFree(dptr[d]);
+    }
+    mk_check(rc, "Error reducing the per-GPU counters");
+    for (size_t k = 0; k < n_pat; ++k) total_counts[k] = (uint32_t)sum[k];
+    c.nb_records_tot = sum[n_pat + 0]; c.nb_bases = sum[n_pat + 1];
+    c.nb_hits_tot[0] = sum[n_pat + 2]; c.nb_hits_tot[1] = sum[n_pat + 3];
+    c.nb_records_hit[0] = sum[n_pat + 4]; c.nb_records_hit[1] = sum[n_pat + 5];
+    c.nb_records_extracted = sum[n_pat + 6];
+}
+
+static mk_matcher *make_matcher(const CommonArgs &a, const Patterns &p, bool *use_ac, int device = -1) {
     // src/cmd_extract.rs:166-171: -I forces AC; otherwise auto unless -q / -a were given
     bool ac = a.aho_corasick;
     if (a.case_insensitive)
@@ -126,9 +173,33 @@ static mk_matcher *make_matcher(const CommonArgs &a, const Patterns &p, bool *us
     mk_matcher *m = nullptr;
     mk_check(mk_matcher_create(p.bytes.data(), p.off.data(), (uint32_t)p.list.size(), ac ? MK_ALGO_AC : MK_ALGO_BNDMQ,
                                a.q_size ? (uint32_t)*a.q_size : 0, a.case_insensitive ? MK_FLAG_ASCII_CASE_INSENSITIVE : 0,
-                               a.device, &m),
+                               device < 0 ? a.device : device, &m),
              "Error");
     return m;
+}
+
+// --gpus N: the N handles live on devices (--device + d) mod the number of visible GPUs, so that the
+// multi-device path can be rehearsed on a box with fewer GPUs (several handles then share a device)
+static std::vector<int> device_list(const CommonArgs &a) {
+    const int avail = std::max(1, mk_device_count());
+    std::vector<int> devs;
+    for (int d = 0; d < std::max(1, a.gpus); ++d) devs.push_back(a.gpus > 1 ? (a.device + d) % avail : a.device);
+    return devs;
+}
+
+static std::vector<mk_matcher *> make_matchers(const CommonArgs &a, const Patterns &p, const std::vector<int> &devs, bool *use_ac) {
+    std::vector<mk_matcher *> ms(devs.size(), nullptr);
+    try {
+        run_threads(devs.size(), [&](size_t d) {
+            bool ac = false;
+            ms[d] = make_matcher(a, p, &ac, devs[d]);
+            if (d == 0) *use_ac = ac;
+        });
+    } catch (...) {
+        for (mk_matcher *m : ms) mk_matcher_destroy(m);
+        throw;
+    }
+    return ms;
 }
 
 static void write_summary(TextLogger &t, const Patterns &p, const std::vector<uint32_t> &counts, const mk_counters &c,
@@ -195,7 +266,8 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     PhaseTimer tm;
     bool use_ac = false;
     // HIP initialisation + pattern-set compilation (0.1-0.3 s) runs beside the input parsing
-    std::future<mk_matcher *> fm = std::async(std::launch::async, [&] { return make_matcher(a, pats, &use_ac); });
+    const std::vector<int> devs = device_list(a);
+    std::future<std::vector<mk_matcher *>> fm = std::async(std::launch::async, [&] { return make_matchers(a, pats, devs, &use_ac); });
 
     FastxFile f1, f2;
     const bool paired = (bool)a.in_fastq_2;
@@ -213,7 +285,8 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         throw;
     }
     tm.mark("read + parse input");
-    mk_matcher *m = fm.get();
+    const std::vector<mk_matcher *> ms = fm.get();
+    mk_matcher *m = ms[0];
     tm.mark("matcher create (HIP init), remainder");
     // writers: src/cmd_extract.rs:297-318, :420-460
     Sink w1, w2;
@@ -237,80 +310,140 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     std::vector<uint32_t> counts(pats.list.size(), 0);
     const size_t n = f1.recs.size();
     const uint64_t batch_bytes = (uint64_t)a.batch_mb << 20;
-    // double-buffered batches: while batch k is on the GPU and its records are written out, a
-    // second thread gathers the sequences of batch k + 1
-    struct Batch {
-        size_t b0 = 0, b1 = 0;
-        std::vector<uint8_t> s1, s2;
-        std::vector<uint64_t> o1, o2;
-    } bufs[2];
-    std::vector<uint8_t> keep;
-    std::vector<mk_row> rows(4096);
-    auto fill = [&](Batch &b, size_t from) {
-        size_t i = from;
-        uint64_t bytes = 0;
-        while (i < n && (bytes < batch_bytes || i == from)) {
-            bytes += f1.raw_len(i) + (paired ? f2.raw_len(i) : 0);
-            ++i;
+    // what a batch's results turn into: log rows (reference emission order) and the kept records
+    auto emit_rows = [&](size_t b0, const mk_row *rows, uint64_t n_rows) {
+        for (uint64_t k = 0; k < n_rows; ++k) {
+            const mk_row &r = rows[k];
+            const FastxFile &ff = r.file ? f2 : f1;
+            const std::string id = ff.id(b0 + r.rec);
+            lg.text.row(r.file ? name2 : name1, id, pats.list[r.pat], r.pos);
+            if (lg.has_json) lg.json.row(r.file ? name2 : name1, id, pats.list[r.pat], r.pos);
         }
-        b.b0 = from;
-        b.b1 = i;
-        f1.gather(from, i, b.s1, b.o1);
-        if (paired) f2.gather(from, i, b.s2, b.o2);
     };
-    int cur = 0;
-    if (n) fill(bufs[0], 0);
-    tm.mark("batch: gather sequences (first)");
-    while (n && bufs[cur].b0 < n) {
-        Batch &B = bufs[cur];
-        const size_t b0 = B.b0, i = B.b1;
-        std::vector<uint8_t> &s1 = B.s1, &s2 = B.s2;
-        std::vector<uint64_t> &o1 = B.o1, &o2 = B.o2;
-        std::future<void> next;
-        Batch &N = bufs[cur ^ 1];
-        N.b0 = n;  // "no further batch" unless filled below
-        if (i < n) next = std::async(std::launch::async, [&, i] { fill(N, i); });
-        const uint64_t nb = i - b0;
-        keep.assign(nb, 0);
-        uint64_t n_rows = 0;
-        for (;;) {
-            mk_counters cb;
-            memset(&cb, 0, sizeof(cb));
-            std::vector<uint32_t> cnt_b(counts.size(), 0);
-            int rc = paired ? mk_extract_paired(m, s1.data(), o1.data(), nb, s2.data(), o2.data(), nb, lg.active, a.invert_match,
-                                                keep.data(), rows.data(), rows.size(), &n_rows, &cb, cnt_b.data())
-                            : mk_extract_single(m, s1.data(), o1.data(), nb, lg.active, a.invert_match, keep.data(), rows.data(),
-                                                rows.size(), &n_rows, &cb, cnt_b.data());
-            if (rc == MK_E_CAPACITY && n_rows > rows.size()) {
-                rows.resize(n_rows);
-                continue;
+    auto emit_records = [&](size_t b0, const uint8_t *keep, uint64_t nb) {
+        if (a.suppress_output) return;
+        for (uint64_t k = 0; k < nb; ++k)
+            if (keep[k]) {
+                f1.write(b0 + k, w1);
+                if (paired) f2.write(b0 + k, w2);
             }
-            mk_check(rc, "Error during matching");
-            c.nb_records_tot += cb.nb_records_tot; c.nb_bases += cb.nb_bases;
-            c.nb_hits_tot[0] += cb.nb_hits_tot[0]; c.nb_hits_tot[1] += cb.nb_hits_tot[1];
-            c.nb_records_hit[0] += cb.nb_records_hit[0]; c.nb_records_hit[1] += cb.nb_records_hit[1];
-            c.nb_records_extracted += cb.nb_records_extracted;
-            for (size_t k = 0; k < counts.size(); ++k) counts[k] += cnt_b[k];
-            break;
-        }
-        tm.mark("batch: H2D + scan + D2H");
-        if (lg.active)
-            for (uint64_t k = 0; k < n_rows; ++k) {
-                const mk_row &r = rows[k];
-                const FastxFile &ff = r.file ? f2 : f1;
-                const std::string id = ff.id(b0 + r.rec);
-                lg.text.row(r.file ? name2 : name1, id, pats.list[r.pat], r.pos);
-                if (lg.has_json) lg.json.row(r.file ? name2 : name1, id, pats.list[r.pat], r.pos);
+    };
+    // Scans records [r0, r1) on matcher `mm` in double-buffered batches: while batch k is on the GPU
+    // and its results are consumed, a second thread gathers the sequences of batch k + 1.
+    // on_batch(first record, #records, keep, rows, #rows) is called in record order.
+    auto scan_range = [&](mk_matcher *mm, size_t r0, size_t r1, mk_counters &cc, std::vector<uint32_t> &cnts, auto on_batch) {
+        struct Batch {
+            size_t b0 = 0, b1 = 0;
+            std::vector<uint8_t> s1, s2;
+            std::vector<uint64_t> o1, o2;
+        } bufs[2];
+        std::vector<uint8_t> keep;
+        std::vector<mk_row> rows(4096);
+        auto fill = [&](Batch &b, size_t from) {
+            size_t i = from;
+            uint64_t bytes = 0;
+            while (i < r1 && (bytes < batch_bytes || i == from)) {
+                bytes += f1.raw_len(i) + (paired ? f2.raw_len(i) : 0);
+                ++i;
             }
-        if (!a.suppress_output)
-            for (uint64_t k = 0; k < nb; ++k)
-                if (keep[k]) {
-                    f1.write(b0 + k, w1);
-                    if (paired) f2.write(b0 + k, w2);
+            b.b0 = from;
+            b.b1 = i;
+            f1.gather(from, i, b.s1, b.o1);
+            if (paired) f2.gather(from, i, b.s2, b.o2);
+        };
+        int cur = 0;
+        bufs[0].b0 = r1;
+        if (r0 < r1) fill(bufs[0], r0);
+        while (bufs[cur].b0 < r1) {
+            Batch &B = bufs[cur];
+            const size_t b0 = B.b0, i = B.b1;
+            std::future<void> next;
+            Batch &N = bufs[cur ^ 1];
+            N.b0 = r1;  // "no further batch" unless filled below
+            if (i < r1) next = std::async(std::launch::async, [&, i] { fill(N, i); });
+            const uint64_t nb = i - b0;
+            keep.assign(nb, 0);
+            uint64_t n_rows = 0;
+            try {
+                for (;;) {
+                    mk_counters cb;
+                    memset(&cb, 0, sizeof(cb));
+                    std::vector<uint32_t> cnt_b(cnts.size(), 0);
+                    int rc = paired ? mk_extract_paired(mm, B.s1.data(), B.o1.data(), nb, B.s2.data(), B.o2.data(), nb, lg.active,
+                                                        a.invert_match, keep.data(), rows.data(), rows.size(), &n_rows, &cb, cnt_b.data())
+                                    : mk_extract_single(mm, B.s1.data(), B.o1.data(), nb, lg.active, a.invert_match, keep.data(),
+                                                        rows.data(), rows.size(), &n_rows, &cb, cnt_b.data());
+                    if (rc == MK_E_CAPACITY && n_rows > rows.size()) {
+                        rows.resize(n_rows);
+                        continue;
+                    }
+                    mk_check(rc, "Error during matching");
+                    cc.nb_records_tot += cb.nb_records_tot; cc.nb_bases += cb.nb_bases;
+                    cc.nb_hits_tot[0] += cb.nb_hits_tot[0]; cc.nb_hits_tot[1] += cb.nb_hits_tot[1];
+                    cc.nb_records_hit[0] += cb.nb_records_hit[0]; cc.nb_records_hit[1] += cb.nb_records_hit[1];
+                    cc.nb_records_extracted += cb.nb_records_extracted;
+                    for (size_t k = 0; k < cnts.size(); ++k) cnts[k] += cnt_b[k];
+                    break;
                 }
-        if (next.valid()) next.get();
-        tm.mark("batch: rows + records out, wait for next gather");
-        cur ^= 1;
+                on_batch(b0, nb, keep.data(), rows.data(), lg.active ? n_rows : 0);
+            } catch (...) {
+                if (next.valid()) next.wait();  // the gather thread still writes into this frame
+                throw;
+            }
+            if (next.valid()) next.get();
+            cur ^= 1;
+        }
+    };
+    if (ms.size() == 1) {
+        scan_range(m, 0, n, c, counts, [&](size_t b0, uint64_t nb, const uint8_t *keep, const mk_row *rows, uint64_t n_rows) {
+            tm.mark("batch: gather + H2D + scan + D2H");
+            emit_rows(b0, rows, n_rows);
+            emit_records(b0, keep, nb);
+            tm.mark("batch: rows + records out");
+        });
+    } else {
+        // --gpus N: device d scans the contiguous record (pair) range shard_range(n, N, d) on its own
+        // host thread; results are buffered per device and emitted in device order, which is record order
+        struct Shard {
+            size_t r0 = 0, r1 = 0;
+            mk_counters c;
+            std::vector<uint32_t> counts;
+            std::vector<uint8_t> keep;
+            std::vector<mk_row> rows;  // rec = index inside the shard
+        };
+        std::vector<Shard> shards(ms.size());
+        for (size_t d = 0; d < ms.size(); ++d) {
+            auto [lo, hi] = shard_range(n, ms.size(), d);
+            shards[d].r0 = lo;
+            shards[d].r1 = hi;
+            memset(&shards[d].c, 0, sizeof(mk_counters));
+            shards[d].counts.assign(counts.size(), 0);
+            shards[d].keep.assign(hi - lo, 0);
+        }
+        run_threads(ms.size(), [&](size_t d) {
+            Shard &S = shards[d];
+            scan_range(ms[d], S.r0, S.r1, S.c, S.counts, [&](size_t b0, uint64_t nb, const uint8_t *keep, const mk_row *rows, uint64_t n_rows) {
+                memcpy(S.keep.data() + (b0 - S.r0), keep, nb);
+                for (uint64_t k = 0; k < n_rows; ++k) {
+                    mk_row r = rows[k];
+                    r.rec += b0 - S.r0;
+                    S.rows.push_back(r);
+                }
+            });
+        });
+        tm.mark("scan on all devices");
+        for (auto &S : shards) {
+            emit_rows(S.r0, S.rows.data(), S.rows.size());
+            emit_records(S.r0, S.keep.data(), S.r1 - S.r0);
+        }
+        std::vector<mk_counters> cs;
+        std::vector<std::vector<uint32_t>> cts;
+        for (auto &S : shards) {
+            cs.push_back(S.c);
+            cts.push_back(S.counts);
+        }
+        reduce_device_counters(ms, devs, cs, cts, c, counts);
+        tm.mark("rows + records out, counter reduction");
     }
     w1.flush();
     w2.flush();
@@ -353,7 +486,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         pe.set("number_of_extracted_records", Json::integer((long long)c.nb_records_extracted));
         lg.json.finalize(meta, cj, sum, &pe);
     }
-    mk_matcher_destroy(m);
+    for (mk_matcher *x : ms) mk_matcher_destroy(x);
     return 0;
 }
 
@@ -380,7 +513,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     if (lg.active) write_log_header(lg.text, "tag", argv, &a.tag, pats.list.size(), a.invert_match);
     bool use_ac = false;
     PhaseTimer tm;
-    std::future<mk_matcher *> fm = std::async(std::launch::async, [&] { return make_matcher(a, pats, &use_ac); });
+    const std::vector<int> devs = device_list(a);
+    std::future<std::vector<mk_matcher *>> fm = std::async(std::launch::async, [&] { return make_matchers(a, pats, devs, &use_ac); });
 
     SamFile sam;
     try {
@@ -390,7 +524,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         throw;
     }
     tm.mark("parse");
-    mk_matcher *m = fm.get();
+    const std::vector<mk_matcher *> ms = fm.get();
+    mk_matcher *m = ms[0];
     tm.mark("matcher (HIP init), remainder");
     if (out_ext != "sam" && out_ext != "bam" && out_ext != "STDOUT") bail("Output file must be a BAM or SAM file.");
     Sink w;
@@ -411,103 +546,160 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     }
 
     const size_t n = sam.recs.size();
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> off;
-    sam.gather(seq, off);
-    tm.mark("gather sequences");
     mk_counters c;
     memset(&c, 0, sizeof(c));
     std::vector<uint32_t> counts(pats.list.size(), 0);
-    std::vector<uint8_t> keep(std::max<size_t>(n, 1), 0);
-    std::vector<mk_row> rows(4096);
-    std::vector<uint64_t> foff(n + 1, 0);
-    std::vector<uint32_t> fpat(1024);
-    uint64_t n_rows = 0;
-    for (;;) {
-        memset(&c, 0, sizeof(c));
-        std::fill(counts.begin(), counts.end(), 0);
-        int rc = mk_tag_records(m, seq.data(), off.data(), n, lg.active, a.filter_matching, a.invert_match, keep.data(), rows.data(),
-                                rows.size(), &n_rows, &c, counts.data(), foff.data(), fpat.data(), fpat.size());
-        if (rc == MK_E_CAPACITY && (n_rows > rows.size() || foff[n] > fpat.size())) {
-            rows.resize(std::max<uint64_t>(rows.size(), n_rows));
-            fpat.resize(std::max<uint64_t>(fpat.size(), foff[n]));
-            continue;
-        }
-        mk_check(rc, "Error during matching");
-        break;
-    }
-    tm.mark("scan");
-    if (lg.active)
-        for (uint64_t k = 0; k < n_rows; ++k) {
-            const mk_row &r = rows[k];
-            const std::string name = sam.name(r.rec);
-            lg.text.row(in_name, name, pats.list[r.pat], r.pos);
-            if (lg.has_json) lg.json.row(in_name, name, pats.list[r.pat], r.pos);
-        }
-    // tag + write kept records (src/cmd_tag.rs:457-497): tag values and output encoding are built
-    // on every host thread, a slab of records at a time, and written in record order
-    std::vector<size_t> kept;
-    kept.reserve(n);
-    for (size_t k = 0; k < n; ++k)
-        if (keep[k]) kept.push_back(k);
-    const size_t kSlab = 1 << 17;
-    for (size_t c0 = 0; c0 < kept.size() && !a.suppress_output; c0 += kSlab) {
-        const size_t c1 = std::min(kept.size(), c0 + kSlab);
-        const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (c1 - c0) / 4096 + 1));
-        std::vector<std::vector<uint8_t>> bin(to_bam ? T : 0);
-        std::vector<std::string> txt(to_bam ? 0 : T);
-        run_threads(T, [&](size_t t) {
-            std::vector<char> val(4096);
-            std::string line;
-            for (size_t i = c0 + (c1 - c0) * t / T; i < c0 + (c1 - c0) * (t + 1) / T; ++i) {
-                const size_t k = kept[i];
-                std::string existing;
-                const int has = sam.find_tag(k, a.tag, &existing);
-                if (has == 2) bail("Invalid tag value format. Expected string value.");
-                size_t need = 0;
-                for (;;) {
-                    int rc = mk_tag_value(m, fpat.data() + foff[k], foff[k + 1] - foff[k], has == 1 ? existing.c_str() : nullptr,
-                                          val.data(), val.size(), &need);
-                    if (rc == MK_E_CAPACITY) {
-                        val.resize(need + 1);
-                        continue;
-                    }
-                    mk_check(rc, "Error building tag value");
-                    break;
-                }
-                if (to_bam && sam.is_bam) {
-                    BamWriter::append_tagged_raw(sam.raw(k), sam.raw_len(k), a.tag, val.data(), need, bin[t]);
-                } else if (to_bam) {
-                    line.clear();
-                    sam.append_line(k, line);
-                    line += '\t';
-                    line += a.tag;
-                    line += ":Z:";
-                    line.append(val.data(), need);
-                    bw.encode_record(line, bin[t]);
-                } else {
-                    std::string &o = txt[t];
-                    sam.append_line(k, o);
-                    o += '\t';
-                    o += a.tag;
-                    o += ":Z:";
-                    o.append(val.data(), need);
-                    o += '\n';
-                }
+    const uint64_t batch_bytes = (uint64_t)a.batch_mb << 20;
+    // One batch = a slab of records whose sequences fill --batch-mb: gather (upper-case / un-nibble)
+    // -> mk_tag_records -> log rows -> tag + encode the kept records.  Only the input buffer and its
+    // record index are whole-file; device buffers, hit rows and matched-pattern sets are per batch.
+    // The results of a batch: its log rows and the encoded output of its kept records, in record order.
+    struct BatchOut {
+        std::vector<mk_row> rows;  // rec = global record index
+        std::vector<std::vector<uint8_t>> bin;  // BAM output: per-thread encoded records, in order
+        std::vector<std::string> txt;           // SAM output
+    };
+    auto emit = [&](const BatchOut &o) {
+        if (lg.active)
+            for (const mk_row &r : o.rows) {
+                const std::string name = sam.name(r.rec);
+                lg.text.row(in_name, name, pats.list[r.pat], r.pos);
+                if (lg.has_json) lg.json.row(in_name, name, pats.list[r.pat], r.pos);
             }
+        for (auto &b : o.bin) bw.put_encoded(b);
+        for (auto &t : o.txt) w.write(t);
+    };
+    auto scan_range = [&](mk_matcher *mm, size_t r0, size_t r1, mk_counters &cc, std::vector<uint32_t> &cnts, size_t enc_threads,
+                          auto on_batch) {
+        std::vector<uint8_t> seq, keep;
+        std::vector<uint64_t> off, foff;
+        std::vector<uint32_t> fpat(1024);
+        std::vector<mk_row> rows(4096);
+        for (size_t b0 = r0; b0 < r1;) {
+            size_t b1 = b0;
+            uint64_t bytes = 0;
+            while (b1 < r1 && (bytes < batch_bytes || b1 == b0)) bytes += sam.recs[b1++].l_seq;
+            const size_t nb = b1 - b0;
+            sam.gather(b0, b1, seq, off);
+            keep.assign(nb, 0);
+            foff.assign(nb + 1, 0);
+            uint64_t n_rows = 0;
+            for (;;) {
+                mk_counters cb;
+                memset(&cb, 0, sizeof(cb));
+                std::vector<uint32_t> cnt_b(cnts.size(), 0);
+                int rc = mk_tag_records(mm, seq.data(), off.data(), nb, lg.active, a.filter_matching, a.invert_match, keep.data(),
+                                        rows.data(), rows.size(), &n_rows, &cb, cnt_b.data(), foff.data(), fpat.data(), fpat.size());
+                if (rc == MK_E_CAPACITY && (n_rows > rows.size() || foff[nb] > fpat.size())) {
+                    rows.resize(std::max<uint64_t>(rows.size(), n_rows));
+                    fpat.resize(std::max<uint64_t>(fpat.size(), foff[nb]));
+                    continue;
+                }
+                mk_check(rc, "Error during matching");
+                cc.nb_records_tot += cb.nb_records_tot; cc.nb_bases += cb.nb_bases;
+                cc.nb_hits_tot[0] += cb.nb_hits_tot[0]; cc.nb_records_hit[0] += cb.nb_records_hit[0];
+                cc.nb_records_extracted += cb.nb_records_extracted;
+                for (size_t k = 0; k < cnts.size(); ++k) cnts[k] += cnt_b[k];
+                break;
+            }
+            BatchOut out;
+            if (lg.active) {
+                out.rows.assign(rows.begin(), rows.begin() + n_rows);
+                for (auto &r : out.rows) r.rec += b0;
+            }
+            // tag + encode the kept records (src/cmd_tag.rs:457-497) on the host threads, in record order
+            std::vector<size_t> kept;
+            for (size_t k = 0; k < nb; ++k)
+                if (keep[k]) kept.push_back(k);
+            if (a.suppress_output) {  // the reference still validates existing tags of kept records
+                for (size_t k : kept) {
+                    std::string existing;
+                    if (sam.find_tag(b0 + k, a.tag, &existing) == 2) bail("Invalid tag value format. Expected string value.");
+                }
+            } else {
+                const size_t T = std::max<size_t>(1, std::min<size_t>(enc_threads, kept.size() / 4096 + 1));
+                out.bin.resize(to_bam ? T : 0);
+                out.txt.resize(to_bam ? 0 : T);
+                run_threads(T, [&](size_t t) {
+                    std::vector<char> val(4096);
+                    std::string line;
+                    for (size_t i = kept.size() * t / T; i < kept.size() * (t + 1) / T; ++i) {
+                        const size_t k = kept[i], g = b0 + k;
+                        std::string existing;
+                        const int has = sam.find_tag(g, a.tag, &existing);
+                        if (has == 2) bail("Invalid tag value format. Expected string value.");
+                        size_t need = 0;
+                        for (;;) {
+                            int rc = mk_tag_value(mm, fpat.data() + foff[k], foff[k + 1] - foff[k], has == 1 ? existing.c_str() : nullptr,
+                                                  val.data(), val.size(), &need);
+                            if (rc == MK_E_CAPACITY) {
+                                val.resize(need + 1);
+                                continue;
+                            }
+                            mk_check(rc, "Error building tag value");
+                            break;
+                        }
+                        if (to_bam && sam.is_bam) {
+                            BamWriter::append_tagged_raw(sam.raw(g), sam.raw_len(g), a.tag, val.data(), need, out.bin[t]);
+                        } else if (to_bam) {
+                            line.clear();
+                            sam.append_line(g, line);
+                            line += '\t';
+                            line += a.tag;
+                            line += ":Z:";
+                            line.append(val.data(), need);
+                            bw.encode_record(line, out.bin[t]);
+                        } else {
+                            std::string &o = out.txt[t];
+                            sam.append_line(g, o);
+                            o += '\t';
+                            o += a.tag;
+                            o += ":Z:";
+                            o.append(val.data(), need);
+                            o += '\n';
+                        }
+                    }
+                });
+            }
+            on_batch(std::move(out));
+            b0 = b1;
+        }
+    };
+    if (ms.size() == 1) {
+        scan_range(m, 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
+            emit(o);
+            tm.mark("batch: gather + scan + tag + write");
         });
-        for (size_t t = 0; t < T; ++t) {
-            if (to_bam)
-                bw.put_encoded(bin[t]);
-            else
-                w.write(txt[t]);
+    } else {
+        // --gpus N: contiguous record ranges per device, one host thread each; batch results are kept
+        // per device and emitted in device order = record order; counters reduced with RCCL
+        struct Shard {
+            mk_counters c;
+            std::vector<uint32_t> counts;
+            std::vector<BatchOut> outs;
+        };
+        std::vector<Shard> shards(ms.size());
+        for (auto &S : shards) {
+            memset(&S.c, 0, sizeof(mk_counters));
+            S.counts.assign(counts.size(), 0);
         }
+        run_threads(ms.size(), [&](size_t d) {
+            auto [lo, hi] = shard_range(n, ms.size(), d);
+            scan_range(ms[d], lo, hi, shards[d].c, shards[d].counts, std::max<size_t>(1, io_threads() / ms.size()),
+                       [&](BatchOut &&o) { shards[d].outs.push_back(std::move(o)); });
+        });
+        tm.mark("scan + tag on all devices");
+        for (auto &S : shards)
+            for (auto &o : S.outs) emit(o);
+        std::vector<mk_counters> cs;
+        std::vector<std::vector<uint32_t>> cts;
+        for (auto &S : shards) {
+            cs.push_back(S.c);
+            cts.push_back(S.counts);
+        }
+        reduce_device_counters(ms, devs, cs, cts, c, counts);
+        tm.mark("write, counter reduction");
     }
-    if (a.suppress_output)  // the reference still validates existing tags of kept records
-        for (size_t k : kept) {
-            std::string existing;
-            if (sam.find_tag(k, a.tag, &existing) == 2) bail("Invalid tag value format. Expected string value.");
-        }
     w.flush();
     bw.close();
     tm.mark("write");
@@ -541,7 +733,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         sum.set("number_of_distinct_records_with_a_hit", Json::integer((long long)c.nb_records_hit[0]));
         lg.json.finalize(meta, cj, sum, nullptr);
     }
-    mk_matcher_destroy(m);
+    for (mk_matcher *x : ms) mk_matcher_destroy(x);
     return 0;
 }
 

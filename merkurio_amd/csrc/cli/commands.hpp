@@ -25,6 +25,7 @@ struct CommonArgs {
     bool aho_corasick = false;             // -a
     // opt-in extras of this build (defaults reproduce the reference behaviour)
     int device = 0;       // --device
+    int gpus = 1;         // --gpus N: records sharded over N devices, outputs in device order, counters reduced with RCCL
     int batch_mb = 128;  // --batch-mb: sequence bytes per GPU batch (tools/batch_mb.sh: 128-256 MB is fastest end to end)
 };
 

@@ -146,12 +146,13 @@ std::vector<char> read_file_maybe_gz(const std::string &path) {
     unsigned char magic[6] = {0};
     size_t got = fread(magic, 1, sizeof(magic), f);
     fclose(f);
-    if (got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')
-        bail("bzip2 input is not supported by this build (gzip and plain text are): " + path);
-    if (got >= 6 && magic[0] == 0xFD && !memcmp(magic + 1, "7zXZ", 4))
-        bail("xz input is not supported by this build (gzip and plain text are): " + path);
-    if (got >= 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD)
-        bail("zstd input is not supported by this build (gzip and plain text are): " + path);
+    if ((got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') ||
+        (got >= 6 && magic[0] == 0xFD && !memcmp(magic + 1, "7zXZ", 4)) ||
+        (got >= 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD)) {
+        FileBytes fb;  // bzip2 / xz / zstd: FileBytes::load inflates by magic
+        fb.load(path);
+        return std::vector<char>(fb.p, fb.p + fb.n);
+    }
     {  // BGZF (BAM, bgzip'ed FASTQ): independent <= 64 KiB members, inflated on every host thread
         std::vector<char> out;
         if (inflate_bgzf_parallel(path, out)) return out;
@@ -202,12 +203,16 @@ void FileBytes::load(const std::string &path) {
             map_len = (uint64_t)st.st_size;
             p = (const char *)m;
             n = map_len;
-            // reject the compressed formats this build cannot read
-            if (n >= 3 && !memcmp(p, "BZh", 3)) bail("bzip2 input is not supported by this build (gzip and plain text are): " + path);
-            if (n >= 6 && (unsigned char)p[0] == 0xFD && !memcmp(p + 1, "7zXZ", 4))
-                bail("xz input is not supported by this build (gzip and plain text are): " + path);
-            if (n >= 4 && !memcmp(p, "\x28\xB5\x2F\xFD", 4))
-                bail("zstd input is not supported by this build (gzip and plain text are): " + path);
+            // bzip2 / xz / zstd (needletail's `compression` feature, Cargo.toml:26): inflated by magic
+            std::vector<char> out;
+            if (inflate_by_magic(path, (const unsigned char *)p, (size_t)n, out)) {
+                munmap(map, map_len);
+                map = nullptr;
+                map_len = 0;
+                owned = std::move(out);
+                p = owned.data();
+                n = owned.size();
+            }
             return;
         }
     }
@@ -367,16 +372,23 @@ void FastxFile::gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vec
 }
 
 void FastxFile::write(size_t i, Sink &w) const {
+    // needletail's SequenceRecord::write(writer, None) ends every line with the record's own line
+    // ending, detected on its header line: CRLF input stays CRLF (the wrapped lines inside a FASTA
+    // raw_seq keep theirs anyway)
     const Rec &r = recs[i];
+    const bool crlf = r.id_e < file.n && data[r.id_e] == '\r';
+    const char *nl = crlf ? "\r\n" : "\n";
+    const size_t nl_len = crlf ? 2 : 1;
     w.write(fastq ? "@" : ">", 1);
     w.write(data + r.id_b, r.id_e - r.id_b);
-    w.write("\n", 1);
+    w.write(nl, nl_len);
     w.write(data + r.raw_b, r.raw_e - r.raw_b);
-    w.write("\n", 1);
+    w.write(nl, nl_len);
     if (fastq) {
-        w.write("+\n", 2);
+        w.write("+", 1);
+        w.write(nl, nl_len);
         w.write(data + r.qual_b, r.qual_e - r.qual_b);
-        w.write("\n", 1);
+        w.write(nl, nl_len);
     }
 }
 
@@ -619,18 +631,18 @@ void SamFile::parse(const std::string &path) {
     io_mark("record index");
 }
 
-void SamFile::gather(std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const {
-    const size_t n = recs.size();
+void SamFile::gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const {
+    const size_t n = b1 - b0;
     off.resize(n + 1);
     off[0] = 0;
-    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + recs[i].l_seq;
+    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + recs[b0 + i].l_seq;
     seq.resize(off[n] + 1);
     const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), n / 65536 + 1));
     run_threads(T, [&](size_t t) {
         for (size_t i = n * t / T; i < n * (t + 1) / T; ++i) {
             uint8_t *o = seq.data() + off[i];
-            const uint32_t l = recs[i].l_seq;
-            const uint8_t *src = (const uint8_t *)data + recs[i].seq_off;
+            const uint32_t l = recs[b0 + i].l_seq;
+            const uint8_t *src = (const uint8_t *)data + recs[b0 + i].seq_off;
             if (is_bam) {
                 for (uint32_t k = 0; k < l; ++k) o[k] = (uint8_t)kBamSeq[(src[k >> 1] >> ((~k & 1) << 2)) & 15];
             } else {  // the matcher sees upper-case text (bam crate: sequences are stored packed, case is lost)

@@ -37,9 +37,12 @@ void run_threads(size_t T, F fn) {
         if (!e.empty()) bail(e);
 }
 
-// whole file into memory; transparently inflates gzip (magic 1f 8b); BGZF members in parallel.  bz2 / xz / zstd
-// inputs are recognised and rejected with a clear message (no such libraries in this build).
+// whole file into memory; transparently inflates gzip (magic 1f 8b; BGZF members in parallel) and,
+// like needletail's `compression` feature, bzip2 / xz / zstd (decompress.cpp)
 std::vector<char> read_file_maybe_gz(const std::string &path);
+// bzip2 / xz / zstd by magic bytes through the system's runtime libraries (bound with dlopen):
+// false = none of the three; raises cli::Error on corrupt input or a missing library
+bool inflate_by_magic(const std::string &path, const unsigned char *data, size_t n, std::vector<char> &out);
 
 // ---- FASTA / FASTQ ------------------------------------------------------------------------------
 // a whole input file in memory: mmap for plain files, an inflated copy for gzip
@@ -102,8 +105,8 @@ struct SamFile {
     std::vector<Rec> recs;
     void parse(const std::string &path);  // by extension: "sam" / "bam" (src/cmd_tag.rs:503-615)
     std::string name(size_t i) const { return std::string(data + recs[i].off + (is_bam ? 36 : 0), recs[i].name_len); }
-    // SEQ of every record as the matcher sees it (upper-case ASCII), concatenated (+1 pad byte)
-    void gather(std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const;
+    // SEQ of records [b0, b1) as the matcher sees it (upper-case ASCII), concatenated (+1 pad byte)
+    void gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const;
     // record i as one SAM text line (no line end) appended to out
     void append_line(size_t i, std::string &out) const;
     // BAM input: raw record bytes after the block_size field

@@ -19,7 +19,7 @@ struct Spec {
 const Spec kCommon[] = {{'s', "kmer-seq", 2},      {'f', "kmer-file", 1},    {'r', "reverse-complement", 0}, {'c', "canonical", 0},
                         {'l', "out-log", 3},       {'j', "json-log", 3},     {'S', "suppress-output", 0},    {'v', "invert-match", 0},
                         {'I', "case-insensitive", 0}, {'L', "lowercase", 0}, {'U', "uppercase", 0},          {'q', "q-size", 1},
-                        {'a', "aho-corasick", 0},  {0, "device", 1},         {0, "batch-mb", 1}};
+                        {'a', "aho-corasick", 0},  {0, "device", 1},         {0, "batch-mb", 1},           {0, "gpus", 1}};
 const Spec kExtract[] = {{'i', "in-fastx", 1}, {'1', "in-fastx", 1}, {'2', "in-fastq-2", 1}, {'o', "out-fastx", 1}};
 const Spec kTag[] = {{'i', "in-file", 1}, {'o', "out-file", 1}, {'t', "tag", 1}, {'p', "threads", 1}, {'m', "filter-matching", 0}};
 
@@ -44,13 +44,14 @@ void print_help(const char *sub) {
              "  -v, --invert-match           select non-matching records\n  -I, --case-insensitive       (always Aho-Corasick)\n"
              "  -L, --lowercase | -U, --uppercase   convert the patterns\n  -q, --q-size <Q>             force BNDMq with this q\n"
              "  -a, --aho-corasick           force Aho-Corasick\n      --device <N>             HIP device ordinal [0]\n"
+             "      --gpus <N>               shard the records over N GPUs (device, device+1, ...) [1]\n"
              "      --batch-mb <MB>          sequence bytes per GPU batch [128]");
     } else {
         puts("Usage: merkurio tag [OPTIONS] --in-file <IN_FILE> <--kmer-seq <KMER_SEQ>...|--kmer-file <KMER_FILE>>\n\n"
              "  -i, --in-file <PATH>         SAM/BAM input\n  -o, --out-file <PATH>        SAM output (stdout if absent)\n"
              "  -s, --kmer-seq <SEQ>... | -f, --kmer-file <PATH>\n  -t, --tag <TAG>              two-character tag [km]\n"
              "  -m, --filter-matching        keep only records with a hit\n  -v, --invert-match           keep only records without a hit\n"
-             "  -p, --threads <N>            accepted for compatibility\n  -r -c -l -j -S -I -L -U -q -a --device  as for extract");
+             "  -p, --threads <N>            accepted for compatibility\n  -r -c -l -j -S -I -L -U -q -a --device --gpus --batch-mb  as for extract");
     }
 }
 
@@ -67,38 +68,11 @@ Parsed parse(const std::vector<std::string> &args, const Spec *extra, size_t n_e
     std::vector<Spec> specs(kCommon, kCommon + sizeof(kCommon) / sizeof(Spec));
     specs.insert(specs.end(), extra, extra + n_extra);
     Parsed p;
-    size_t i = 0;
+    size_t i = 0;  // next argument to look at
     auto is_opt = [](const std::string &s) { return s.size() >= 2 && s[0] == '-' && !(s[1] >= '0' && s[1] <= '9' && s != "-1" && s != "-2"); };
-    while (i < args.size()) {
-        const std::string &a = args[i];
-        if (a == "-h" || a == "--help") {
-            print_help(sub);
-            exit(0);
-        }
-        const Spec *sp = nullptr;
-        std::string inline_val;
-        bool has_inline = false;
-        if (a.rfind("--", 0) == 0) {
-            std::string name = a.substr(2);
-            size_t eq = name.find('=');
-            if (eq != std::string::npos) {
-                inline_val = name.substr(eq + 1);
-                name = name.substr(0, eq);
-                has_inline = true;
-            }
-            for (auto &s : specs)
-                if (name == s.long_name) sp = &s;
-        } else if (a.size() >= 2 && a[0] == '-') {
-            for (auto &s : specs)
-                if (s.short_name && a[1] == s.short_name) sp = &s;
-            if (sp && a.size() > 2) {  // -q5 / -ofile
-                if (sp->kind == 0) usage_error("unexpected value for '-" + std::string(1, a[1]) + "'");
-                inline_val = a.substr(a[2] == '=' ? 3 : 2);
-                has_inline = true;
-            }
-        }
-        if (!sp) usage_error("unexpected argument '" + a + "' found");
-        ++i;
+    // records one occurrence of option `sp`; value-taking options consume `inline_val` (-q5, --q-size=5)
+    // or the following argument(s)
+    auto commit = [&](const Spec *sp, bool has_inline, const std::string &inline_val) {
         std::vector<std::string> vals;
         if (has_inline) {
             vals.push_back(inline_val);
@@ -114,14 +88,59 @@ Parsed parse(const std::vector<std::string> &args, const Spec *extra, size_t n_e
             else
                 vals.push_back("STDOUT");
         }
-        bool merged = false;
         for (auto &o : p.opts)
             if (o.first == sp->long_name) {
                 if (sp->kind != 2) usage_error(std::string("the argument '--") + sp->long_name + "' cannot be used multiple times");
                 o.second.insert(o.second.end(), vals.begin(), vals.end());
-                merged = true;
+                return;
             }
-        if (!merged) p.opts.emplace_back(sp->long_name, vals);
+        p.opts.emplace_back(sp->long_name, vals);
+    };
+    while (i < args.size()) {
+        const std::string a = args[i];
+        if (a == "-h" || a == "--help") {
+            print_help(sub);
+            exit(0);
+        }
+        ++i;
+        if (a.rfind("--", 0) == 0) {
+            std::string name = a.substr(2), inline_val;
+            bool has_inline = false;
+            size_t eq = name.find('=');
+            if (eq != std::string::npos) {
+                inline_val = name.substr(eq + 1);
+                name = name.substr(0, eq);
+                has_inline = true;
+            }
+            const Spec *sp = nullptr;
+            for (auto &s : specs)
+                if (name == s.long_name) sp = &s;
+            if (!sp) usage_error("unexpected argument '" + a + "' found");
+            if (has_inline && sp->kind == 0) usage_error("unexpected value '" + inline_val + "' for '--" + name + "' found; no more were expected");
+            commit(sp, has_inline, inline_val);
+        } else if (a.size() >= 2 && a[0] == '-') {
+            // clap-style cluster of short options: -rl, -vI, -rq5, -Sl log.txt; the first option
+            // that takes a value ends the cluster (the rest of the word, if any, is its value)
+            size_t k = 1;
+            while (k < a.size()) {
+                const Spec *sp = nullptr;
+                for (auto &s : specs)
+                    if (s.short_name && a[k] == s.short_name) sp = &s;
+                if (!sp) usage_error(k == 1 ? "unexpected argument '" + a + "' found" : "unexpected argument '-" + std::string(1, a[k]) + "' found");
+                ++k;
+                if (sp->kind == 0) {
+                    commit(sp, false, "");
+                    continue;
+                }
+                if (k < a.size())
+                    commit(sp, true, a.substr(a[k] == '=' ? k + 1 : k));
+                else
+                    commit(sp, false, "");
+                break;
+            }
+        } else {
+            usage_error("unexpected argument '" + a + "' found");
+        }
     }
     return p;
 }
@@ -149,6 +168,7 @@ void fill_common(const Parsed &p, CommonArgs &c, bool has_out) {
     if (auto v = p.get("q-size")) c.q_size = to_num((*v)[0], "--q-size <Q_SIZE>");
     c.aho_corasick = flag("aho-corasick");
     if (auto v = p.get("device")) c.device = (int)to_num((*v)[0], "--device");
+    if (auto v = p.get("gpus")) c.gpus = (int)std::max<size_t>(1, to_num((*v)[0], "--gpus"));
     if (auto v = p.get("batch-mb")) c.batch_mb = (int)std::max<size_t>(1, to_num((*v)[0], "--batch-mb"));
     // clap ArgGroups (src/cmd_extract.rs:33-62, src/cmd_tag.rs:29-66)
     if (c.kmer_seq.empty() == !c.kmer_file) {

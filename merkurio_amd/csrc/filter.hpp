@@ -44,11 +44,15 @@ struct alignas(8) TableEntry {
     uint32_t fp;       // = bloom_hash(key)
     uint32_t pat_off;  // kEmptyPat = empty slot
 };
-constexpr uint32_t kMaxPatterns = (1u << 28) - 1;
+constexpr uint32_t kMaxPatterns = (1u << 27) - 2;
 // The table is an array of 32-byte buckets of 4 entries, filled front to back; a lookup reads
 // one whole bucket (2 x global_load_dwordx4, one memory round trip) and moves on to the next
-// bucket only if this one is full.
+// bucket only if this one has OVERFLOWED while the table was built (some key that hashes here or
+// before was pushed past it): bit 31 of the pat_off word of the bucket's entry 0.  "Bucket full"
+// alone would send 3.6 % of the lookups -- 9 of 10 wave-wide probe rounds -- into a second,
+// synchronous round trip at load 0.3; the overflow flag does so for 0.8 %.
 constexpr uint32_t kBucketEntries = 4;
+constexpr uint32_t kBucketOverflow = 0x80000000u;
 MK_HD uint32_t table_bucket(uint32_t h, uint32_t bucket_mask) { return ((h * 0x9E3779B1u) >> 6) & bucket_mask; }
 
 MK_HD uint32_t code2(uint8_t c) { return (c >> 1) & 3u; }
@@ -79,6 +83,34 @@ MK_HD uint32_t bloom_bit_c(uint32_t h) { return (h >> 17) & 31u; }
 // correlate with the block index.
 MK_HD uint32_t gbloom_block(uint32_t h, uint32_t block_mask) { return (h >> 5) & block_mask; }
 MK_HD uint32_t gbloom_bits(uint32_t h) { return h * 0x9E3779B1u; }  // a,b,c = top three 5-bit groups
+
+// ---- context fingerprints (global-filter kernels with a compile-time q: gf_has_ctx) ---------------
+// With hundreds of thousands of patterns the sampled q-grams get short (500 k 21-mers: q = 14) and
+// 1.5 % of all text samples are REAL q-gram matches of some pattern: each would cost level 3 a byte
+// compare, i.e. three random HBM reads.  A pattern occurrence that puts its offset-o q-gram on the
+// sample at t also fixes the o text bases before t and the S-1-o bases after the q-gram (every pattern
+// has at least q + S - 1 bases).  The candidate carries up to 7 + 7 of them, 2-bit packed (ctx:
+// bits [0,14) = bases t-7..t-1, bits [14,28) = bases t+q..t+q+6), and the level-2 fingerprint of
+// entry (pattern, o) is the q-gram hash mixed with the pattern's own bases under the mask of o.
+// For 21-mers at S = 8 the fingerprint covers the whole pattern: level 3 sees real occurrences only.
+MK_HD bool gf_has_ctx(uint32_t S, uint32_t q) { return (S == 8 && q == 14) || (S == 4 && q == 18) || (S == 8 && q == 24); }
+MK_HD uint32_t ctx_mask(uint32_t o, uint32_t S) {
+    const uint32_t npre = o < 7 ? o : 7;
+    const uint32_t rem = S - 1 - o;
+    const uint32_t nsuf = rem < 7 ? rem : 7;
+    return ((0x3FFFu << (14 - 2 * npre)) & 0x3FFFu) | (((1u << (2 * nsuf)) - 1u) << 14);
+}
+MK_HD uint32_t ctx_fp(uint32_t h, uint32_t ctx_masked) { return h ^ (ctx_masked * 0x85EBCA6Bu); }
+// the context word of pattern p (its bytes) for the q-gram at offset o: the same layout as the text side
+MK_HD uint32_t ctx_of_pattern(const uint8_t *p, uint32_t o, uint32_t q, uint32_t S) {
+    const uint32_t npre = o < 7 ? o : 7;
+    const uint32_t rem = S - 1 - o;
+    const uint32_t nsuf = rem < 7 ? rem : 7;
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < npre; ++i) c |= code2(p[o - npre + i]) << (14 - 2 * npre + 2 * i);
+    for (uint32_t i = 0; i < nsuf; ++i) c |= code2(p[o + q + i]) << (14 + 2 * i);
+    return c;
+}
 
 MK_HD uint8_t fold_ascii(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c | 0x20) : c; }
 

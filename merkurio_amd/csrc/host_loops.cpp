@@ -76,6 +76,7 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
                       mk_counters *c, uint32_t *counts) {
     if (!m || !keep || !c || (logging && !counts)) return fail(MK_E_INVALID_ARG, "null argument");
     if (n_rows) *n_rows = 0;
+    MK_ABI_BEGIN
     std::vector<uint8_t> flags;
     std::vector<mk_hit> hits;
     int rc = scan_all(m, seq, off, n_rec, logging ? MK_MODE_HITS : MK_MODE_ANY, flags, hits);
@@ -97,6 +98,7 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
     if (logging && rows && sink.n > rows_cap)
         return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
     return MK_OK;
+    MK_ABI_END
 }
 
 int mk_extract_paired(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, uint64_t n_rec1,
@@ -109,6 +111,7 @@ int mk_extract_paired(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, 
         return fail(MK_E_PAIR_MISMATCH,
                     "The two input files have a different number of records. Please provide valid paired-end read files.");
     const uint64_t n_rec = n_rec1;
+    MK_ABI_BEGIN
     std::vector<uint8_t> f1, f2;
     std::vector<mk_hit> h1, h2;
     const uint32_t mode = logging ? MK_MODE_HITS : MK_MODE_ANY;
@@ -159,6 +162,7 @@ int mk_extract_paired(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, 
     if (logging && rows && sink.n > rows_cap)
         return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
     return MK_OK;
+    MK_ABI_END
 }
 
 int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint64_t n_rec, int logging,
@@ -166,6 +170,7 @@ int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint6
                    mk_counters *c, uint32_t *counts, uint64_t *found_off, uint32_t *found_pat, uint64_t found_cap) {
     if (!m || !keep || !c || !found_off || (logging && !counts)) return fail(MK_E_INVALID_ARG, "null argument");
     if (n_rows) *n_rows = 0;
+    MK_ABI_BEGIN
     std::vector<uint8_t> flags;
     std::vector<mk_hit> hits;
     // the tag loop always needs the matched-pattern SET (src/cmd_tag.rs:392-442)
@@ -204,11 +209,13 @@ int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint6
     if (logging && rows && sink.n > rows_cap)
         return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
     return MK_OK;
+    MK_ABI_END
 }
 
 int mk_tag_value(const mk_matcher *m, const uint32_t *found_pat, uint64_t n_found, const char *existing, char *out,
                  size_t cap, size_t *out_len) {
     if (!m || (!found_pat && n_found)) return fail(MK_E_INVALID_ARG, "null argument");
+    MK_ABI_BEGIN
     std::vector<std::string> items;
     for (uint64_t i = 0; i < n_found; ++i) {
         const uint32_t p = found_pat[i];
@@ -235,6 +242,7 @@ int mk_tag_value(const mk_matcher *m, const uint32_t *found_pat, uint64_t n_foun
     if (!out || cap < joined.size() + 1) return fail(MK_E_CAPACITY, "tag buffer too small: need %zu", joined.size() + 1);
     memcpy(out, joined.c_str(), joined.size() + 1);
     return MK_OK;
+    MK_ABI_END
 }
 
 }  // extern "C"

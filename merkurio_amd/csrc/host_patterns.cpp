@@ -102,6 +102,7 @@ int mk_generate_masks(const uint8_t *pattern, size_t m, uint64_t masks[256], uin
 int mk_read_kmers_from_text(const uint8_t *content, size_t len, uint8_t **out_bytes, uint32_t **out_off,
                             uint32_t *out_n) {
     if (!out_bytes || !out_off || !out_n) return mk::fail(MK_E_INVALID_ARG, "null output");
+    MK_ABI_BEGIN
     std::vector<std::string> v;
     size_t i = 0;
     while (i < len) {  // str::lines(): split on '\n', strip one trailing '\r'
@@ -120,6 +121,7 @@ int mk_read_kmers_from_text(const uint8_t *content, size_t len, uint8_t **out_by
     }
     if (v.empty()) return mk::fail(MK_E_NO_PATTERNS, "No k-mers found in the file.");
     return export_list(v, out_bytes, out_off, out_n);
+    MK_ABI_END
 }
 
 int mk_parse_pattern_list(const uint8_t *in_bytes, const uint32_t *in_off, uint32_t n_in, int reverse_complement,
@@ -127,6 +129,7 @@ int mk_parse_pattern_list(const uint8_t *in_bytes, const uint32_t *in_off, uint3
                           uint32_t *out_n) {
     if (!out_bytes || !out_off || !out_n || (n_in && (!in_off || !in_bytes)))
         return mk::fail(MK_E_INVALID_ARG, "null argument");
+    MK_ABI_BEGIN
     std::vector<std::string> v;
     v.reserve((size_t)n_in * (reverse_complement ? 2 : 1));
     for (uint32_t i = 0; i < n_in; ++i) v.emplace_back((const char *)in_bytes + in_off[i], in_off[i + 1] - in_off[i]);
@@ -158,6 +161,7 @@ int mk_parse_pattern_list(const uint8_t *in_bytes, const uint32_t *in_off, uint3
     v.erase(std::unique(v.begin(), v.end()), v.end());
     if (v.empty()) return mk::fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
     return export_list(v, out_bytes, out_off, out_n);
+    MK_ABI_END
 }
 
 }  // extern "C"

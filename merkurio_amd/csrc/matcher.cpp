@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -18,22 +19,27 @@
 
 namespace mk {
 
-thread_local std::string g_last_error;
+// message of the calling thread's last failure: a fixed buffer, so that reporting an
+// out-of-memory condition never allocates
+thread_local char g_last_error[512] = "";
 
 int fail(int code, const char *fmt, ...) {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
 }
 
-#define MK_HIP(call)                                                                                  \
-    do {                                                                                              \
-        hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess) return fail(MK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+int hip_fail(hipError_t e, const char *what) {
+    (void)hipGetLastError();  // clear the sticky error
+    return fail(e == hipErrorOutOfMemory ? MK_E_NOMEM : MK_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+}
+
+#define MK_HIP(call)                                       \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);  \
     } while (0)
 
 // ---- filter geometry -----------------------------------------------------------------------
@@ -43,11 +49,10 @@ int fail(int code, const char *fmt, ...) {
 // 31-mers (profiles/r01_stride_sweep.txt): S=8 (80 k entries, 0.2 % of bases become
 // candidates) beats S=4 by 14 % and S=16 by 60 %.  Rule: largest S with <= 96 k entries and
 // q >= 14.
-static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t *S, uint32_t *gblocks) {
-    const char *force = getenv("MERKURIO_FORCE_STRIDE");  // tuning / test hook
-    const int forced = force ? atoi(force) : 0;
-    const char *fg = getenv("MERKURIO_FORCE_GLOBAL_FILTER");  // test hook
-    const bool force_global = fg && atoi(fg) != 0;
+static void choose_geometry(uint32_t lmin, uint64_t n_pat, const mk_matcher_options &opt, uint32_t *q, uint32_t *S,
+                            uint32_t *gblocks) {
+    const int forced = (int)opt.force_stride;  // tuning / test hooks: mk_matcher_create_ex only
+    const bool force_global = opt.force_global_filter != 0;
     *gblocks = 0;
     constexpr uint64_t kMaxLdsEntries = 98304;
     if (n_pat <= kMaxLdsEntries && !force_global) {  // LDS filter
@@ -100,7 +105,7 @@ static void choose_geometry(uint32_t lmin, uint64_t n_pat, uint32_t *q, uint32_t
     // stays resident in the 4 MiB XCD L2; 8 MiB (0.09 % pass) is 1.8x slower.  ~8 entries/block.
     uint64_t blocks = 1ull << 17;  // >= 1 MiB
     while (blocks < n_pat * *S / 8 && blocks < (1ull << 25)) blocks <<= 1;
-    if (const char *e = getenv("MERKURIO_GBLOOM_LOG2_BLOCKS")) blocks = 1ull << atoi(e);  // tuning hook
+    if (opt.gbloom_log2_blocks) blocks = 1ull << opt.gbloom_log2_blocks;  // tuning hook
     *gblocks = (uint32_t)blocks;
 }
 
@@ -129,7 +134,7 @@ static int ensure(void **p, size_t *cap, size_t need) {
 extern "C" {
 
 int mk_abi_version(void) { return MK_ABI_VERSION; }
-const char *mk_last_error(void) { return g_last_error.c_str(); }
+const char *mk_last_error(void) { return g_last_error; }
 
 int mk_device_count(void) {
     int n = 0;
@@ -141,8 +146,26 @@ void mk_free(void *p) { free(p); }
 
 int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
                       uint32_t flags, int32_t device, mk_matcher **out) {
+    return mk_matcher_create_ex(pat_bytes, pat_off, n_pat, algo, q, flags, device, nullptr, out);
+}
+
+int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
+                         uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out) {
     if (!out) return fail(MK_E_INVALID_ARG, "out is null");
     *out = nullptr;
+    mk_matcher_options opt;
+    memset(&opt, 0, sizeof(opt));
+    if (options) {  // a caller built against an older, shorter struct passes its own size
+        if (options->struct_size < sizeof(uint32_t) || options->struct_size > 4096)
+            return fail(MK_E_INVALID_ARG, "mk_matcher_options.struct_size %u is not plausible", options->struct_size);
+        memcpy(&opt, options, std::min<size_t>(options->struct_size, sizeof(opt)));
+        const uint32_t fs = opt.force_stride;
+        if (fs != 0 && fs != 1 && fs != 2 && fs != 4 && fs != 8 && fs != 16)
+            return fail(MK_E_INVALID_ARG, "force_stride %u: must be 0, 1, 2, 4, 8 or 16", fs);
+        if (opt.gbloom_log2_blocks != 0 && (opt.gbloom_log2_blocks < 10 || opt.gbloom_log2_blocks > 25))
+            return fail(MK_E_INVALID_ARG, "gbloom_log2_blocks %u out of range (10..25)", opt.gbloom_log2_blocks);
+    }
+    MK_ABI_BEGIN
     if (n_pat == 0 || !pat_off || !pat_bytes) return fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
     if (algo > MK_ALGO_BNDMQ) return fail(MK_E_INVALID_ARG, "unknown algo %u", algo);
     if (n_pat > kMaxPatterns) return fail(MK_E_UNSUPPORTED, "too many patterns (%u)", n_pat);
@@ -183,7 +206,11 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
     if (device < 0 || device >= ndev) return fail(MK_E_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
     MK_HIP(hipSetDevice(device));
 
-    mk_matcher *m = new mk_matcher();
+    struct Deleter {
+        void operator()(mk_matcher *p) const { mk_matcher_destroy(p); }
+    };
+    std::unique_ptr<mk_matcher, Deleter> owner(new mk_matcher());
+    mk_matcher *m = owner.get();
     m->device = device;
     m->algo = use;
     m->flags = flags;
@@ -196,16 +223,17 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
 
     m->uniform_len = (lmin == lmax) ? lmin : 0;
     // ---- compile the pattern set: Bloom filter + exact table
-    choose_geometry(lmin, n_pat, &m->q, &m->S, &m->gbloom_blocks);
+    choose_geometry(lmin, n_pat, opt, &m->q, &m->S, &m->gbloom_blocks);
+    if (opt.force_stride && m->S != opt.force_stride)
+        return fail(MK_E_INVALID_ARG, "force_stride %u is longer than the shortest pattern (%u)", opt.force_stride, lmin);
     const uint32_t q_f = m->q, S = m->S;
     m->entries = (uint64_t)n_pat * S;
+    // load <= 0.5 while the table shares L2 with the text stream; a global-filter set's table is
+    // HBM-resident anyway, and at load <= 0.25 a lookup all but never has to walk to a second bucket
     uint64_t slots = 64;
-    while (slots < 2 * m->entries) slots <<= 1;
-    if (slots > (1ull << 27)) {  // bucket index has 26 bits
-        const unsigned long long ne = m->entries;
-        delete m;
-        return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", ne);
-    }
+    while (slots < (m->gbloom_blocks ? 4 : 2) * m->entries) slots <<= 1;
+    if (slots > (1ull << 27))  // bucket index has 26 bits
+        return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", (unsigned long long)m->entries);
     m->table_slots = (uint32_t)slots;
     const uint32_t gmask = m->gbloom_blocks ? m->gbloom_blocks - 1 : 0;
     std::vector<uint32_t> bloom(m->gbloom_blocks ? (size_t)m->gbloom_blocks * 2 : (size_t)kBloomWords, 0);
@@ -215,11 +243,15 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
         e.pat_off = kEmptyPat;
     }
     const uint32_t bmask = m->table_slots / kBucketEntries - 1;  // bucket index mask
+    const bool gf_ctx = m->gbloom_blocks != 0 && gf_has_ctx(S, q_f);
     for (uint32_t pi = 0; pi < n_pat; ++pi) {
         const uint8_t *p = pat_bytes + pat_off[pi];
         for (uint32_t o = 0; o < S; ++o) {
             const uint64_t key = pack_qgram(p + o, q_f);
             const uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
+            // level-2 fingerprint: the filter hash, or (context kernels) that hash mixed with the
+            // pattern bases around the q-gram
+            const uint32_t fp = gf_ctx ? ctx_fp(h, ctx_of_pattern(p, o, q_f, S) & ctx_mask(o, S)) : h;
             if (m->gbloom_blocks) {
                 const size_t blk = (size_t)gbloom_block(h, gmask) * 2;
                 const uint32_t hb = gbloom_bits(h);
@@ -236,41 +268,38 @@ int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_
                 uint32_t k = 0;
                 while (k < kBucketEntries && e[k].pat_off != kEmptyPat) ++k;
                 if (k < kBucketEntries) {
-                    e[k].fp = h;
+                    e[k].fp = fp;
                     e[k].pat_off = (pi << 4) | o;
                     break;
                 }
+                e[0].pat_off |= kBucketOverflow;  // a lookup that reaches this bucket must look further
                 b = (b + 1) & bmask;
             }
         }
     }
-    auto bail = [&](int code) {
-        mk_matcher_destroy(m);
-        return code;
-    };
-#define MK_HIP_M(call)                                                                                     \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess) return bail(fail(MK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); \
-    } while (0)
-    MK_HIP_M(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    MK_HIP_M(hipMalloc((void **)&m->d_bloom, bloom.size() * sizeof(uint32_t)));
-    MK_HIP_M(hipMalloc((void **)&m->d_table, slots * sizeof(TableEntry)));
-    MK_HIP_M(hipMalloc((void **)&m->d_pat_bytes, m->pat_bytes.size() + 16));
-    MK_HIP_M(hipMalloc((void **)&m->d_pat_off, (n_pat + 1) * sizeof(uint32_t)));
-    MK_HIP_M(hipMalloc((void **)&m->d_nhits, sizeof(unsigned long long)));
-    MK_HIP_M(hipMemcpy(m->d_bloom, bloom.data(), bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    MK_HIP_M(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
-    MK_HIP_M(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
-    MK_HIP_M(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-#undef MK_HIP_M
-    *out = m;
+    // (a failing MK_HIP returns; `owner` then releases whatever was allocated so far)
+    MK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    MK_HIP(hipMalloc((void **)&m->d_bloom, bloom.size() * sizeof(uint32_t)));
+    MK_HIP(hipMalloc((void **)&m->d_table, slots * sizeof(TableEntry)));
+    MK_HIP(hipMalloc((void **)&m->d_pat_bytes, m->pat_bytes.size() + 16));
+    MK_HIP(hipMalloc((void **)&m->d_pat_off, (n_pat + 1) * sizeof(uint32_t)));
+    MK_HIP(hipMalloc((void **)&m->d_nhits, sizeof(unsigned long long)));
+    // staging of verified occurrences for the hit-tuple kernels, kHitStage tuples per scan wave.
+    // Allocated here, not by the first MK_MODE_HITS scan: mk_scan_device only enqueues.
+    MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * (kBlockThreads / 64) * kHitStage * sizeof(mk_hit)));
+    MK_HIP(hipMemcpy(m->d_bloom, bloom.data(), bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    *out = owner.release();
     return MK_OK;
+    MK_ABI_END
 }
 
 void mk_matcher_destroy(mk_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    if (m->comm) (void)mk_comm_destroy(m);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     for (auto e : m->ev_start) (void)hipEventDestroy(e);
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
@@ -345,9 +374,6 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t waves_per_block = kBlockThreads / 64;
     uint64_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
-    if (mode == MK_MODE_HITS && !m->d_stage) {  // staging of verified occurrences, kHitStage per scan wave
-        MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * waves_per_block * kHitStage * sizeof(mk_hit)));
-    }
     p.stage = m->d_stage;
     p.rec_per_byte = (double)n_rec / (double)n_bytes;
     const size_t slots = m->ev_start.size();
@@ -368,6 +394,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
 
 int mk_matcher_enable_timing(mk_matcher *m, uint32_t slots) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    MK_ABI_BEGIN
     MK_HIP(hipSetDevice(m->device));
     for (auto e : m->ev_start) (void)hipEventDestroy(e);
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
@@ -379,6 +406,7 @@ int mk_matcher_enable_timing(mk_matcher *m, uint32_t slots) {
         MK_HIP(hipEventCreate(&m->ev_stop[i]));
     }
     return MK_OK;
+    MK_ABI_END
 }
 
 int mk_matcher_kernel_times(mk_matcher *m, float *ms, uint32_t cap, uint32_t *n_out) {
@@ -441,6 +469,7 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
     const uint64_t base = seq_off[0];
     const uint64_t n_bytes = seq_off[n_rec] - base;
     if (n_bytes && !seq_bytes) return fail(MK_E_INVALID_ARG, "null sequence buffer");
+    MK_ABI_BEGIN
     MK_HIP(hipSetDevice(m->device));
     int rc;
     if ((rc = ensure((void **)&m->d_seq, &m->d_seq_cap, n_bytes + 64))) return rc;
@@ -479,13 +508,21 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
         }
     }
     return MK_OK;
+    MK_ABI_END
 }
 
 int mk_synth_reads_device(mk_matcher *m, uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every,
                           void *d_seq, void *d_seq_off, void *stream) {
+    return mk_synth_reads_device_range(m, seed, 0, n_rec, read_len, plant_every, d_seq, d_seq_off, stream);
+}
+
+int mk_synth_reads_device_range(mk_matcher *m, uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len,
+                                uint32_t plant_every, void *d_seq, void *d_seq_off, void *stream) {
     if (!m || !d_seq || !d_seq_off) return fail(MK_E_INVALID_ARG, "null argument");
+    if (((uint64_t)rec0 * read_len) % 32 != 0)
+        return fail(MK_E_INVALID_ARG, "rec0 * read_len must be a multiple of 32 (generator block)");
     MK_HIP(hipSetDevice(m->device));
-    launch_synth(seed, n_rec, read_len, plant_every, m->d_pat_bytes, m->d_pat_off, m->n_pat, (uint8_t *)d_seq,
+    launch_synth(seed, rec0, n_rec, read_len, plant_every, m->d_pat_bytes, m->d_pat_off, m->n_pat, (uint8_t *)d_seq,
                  (uint64_t *)d_seq_off, (hipStream_t)stream);
     MK_HIP(hipGetLastError());
     return MK_OK;

@@ -44,4 +44,7 @@ struct mk_matcher {
     // around the scan kernel): bench.py's roofline figure
     std::vector<hipEvent_t> ev_start, ev_stop;
     uint64_t timed_launches = 0;
+    // one-process-per-GPU counter reduction (reduce.cpp): this rank's RCCL communicator
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
 };

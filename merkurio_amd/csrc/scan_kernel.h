@@ -45,13 +45,17 @@ struct ScanParams {
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
                         hipStream_t stream);
 
+// host-side launcher of one kernel variant; defined (explicitly instantiated) in scan_variants.hip
+template <int S, int QC, bool EMIT, bool GF>
+void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream);
+
 // static LDS bytes of one scan workgroup (filter + candidate rings + pattern counters)
 uint32_t scan_lds_bytes();
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);
 
-void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
+void launch_synth(uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
                   const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream);
 
 }  // namespace mk

@@ -1,724 +1,11 @@
-// scan_kernel.hip -- hand-written gfx950 (CDNA4, wave64) multi-pattern scan kernel.
-//
-// Replaces, for a whole batch of records at once, the reference's per-record matcher calls:
-//   BNDMq::find_match / find_iter        src/pattern_matching.rs:82-209
-//   AhoCorasick::find_overlapping_iter   src/cmd_extract.rs:332,480,507; src/cmd_tag.rs:393-396
-// Result set = every (record, pattern, start) occurrence + per-record any-hit flags
-// (bit-exact vs the oracle); emission ORDER is restored on the host (matcher.cpp).
-//
-// Shape of the work (integer, HBM-streaming; no MFMA -- DESIGN.md §3/§4):
-//   * one persistent 1024-thread workgroup per CU (16 waves); level 1, the 128 KiB blocked
-//     q-gram Bloom filter of the pattern set, lives in LDS for the life of the workgroup
-//     (pattern sets too large for it use the same filter layout in global memory / L2: GF);
-//   * the concatenated text is cut into 31 KiB tiles dealt round-robin to the 4096 waves; a wave
-//     walks a tile in 1 KiB chunks: each lane issues ONE non-temporal global_load_dwordx4
-//     (64 lanes x 16 B, fully coalesced) per chunk, four chunks (one group) are in flight while
-//     the previous group is filtered;
-//   * a lane 2-bit-packs its 16 bytes into one dword (11 VALU ops), gets the 32-base halo from
-//     lanes +1/+2 by DPP wave_shl (no LDS traffic), forms the 16/S sampled q-gram keys with
-//     v_alignbit, hashes with two 24-bit multiplies and probes the filter with one ds_read_b64
-//     per sample;
-//   * filter positives are compacted (ballot + mbcnt) into a per-wave LDS ring; when the ring
-//     fills, 64 candidates at a time go through level 2 (bucketised exact table in L2, loads
-//     issued at the end of one group and consumed at the top of the next) and level 3
-//     (byte-exact compare, record lookup, boundary check) with all 64 lanes busy;
-//   * results: one byte store per hit record (flags), per-pattern counters (LDS for tiny sets,
-//     global atomics otherwise), optional (record, pattern, position) tuples staged through a
-//     per-wave ring so the output cursor sees one atomic per 64 hits.
+// scan_kernel.hip -- host-side dispatch over the gfx950 scan-kernel variants (the kernel itself is
+// scan_kernel_impl.hpp, instantiated by scan_variants.hip), the flag-count kernel and the
+// synthetic-workload kernels.
 #include <algorithm>
 
 #include "scan_kernel.h"
 
 namespace mk {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// 16 ASCII bytes -> 32 bits, base i at bits 2i..2i+1, code = (c >> 1) & 3.
-// Per dword: x = d & 0x06060606 holds the four codes at bits 1,9,17,25; x * (2^23+2^17+2^11+2^5)
-// lines them up in the TOP BYTE of the product (bits 24..31; the other partial products fall
-// on distinct 2-bit slots below bit 24, so nothing carries).  Three v_perm_b32 then gather the
-// four top bytes: 4 x (v_and + v_mul_lo) + 3 = 11 VALU ops per 16 bases.
-__device__ __forceinline__ uint32_t pack4_top(uint32_t d) { return (d & 0x06060606u) * 0x00820820u; }
-__device__ __forceinline__ uint32_t pack16(uint4 v) {
-    const uint32_t u0 = pack4_top(v.x), u1 = pack4_top(v.y), u2 = pack4_top(v.z), u3 = pack4_top(v.w);
-    // v_perm_b32(src0, src1, sel): bytes 0-3 of the 8-byte pool come from src1, 4-7 from src0
-    const uint32_t lo16 = __builtin_amdgcn_perm(u1, u0, 0x0c0c0703u);  // [u0.b3, u1.b3, 0, 0]
-    const uint32_t hi16 = __builtin_amdgcn_perm(u3, u2, 0x07030c0cu);  // [0, 0, u2.b3, u3.b3]
-    return lo16 | hi16;
-}
-
-// 16 bytes at text position pos (pos % 16 == 0); bytes at or beyond n read as 0
-__device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ seq, uint64_t pos, uint64_t n) {
-    if (pos + 16 <= n) return *reinterpret_cast<const uint4 *>(seq + pos);
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (pos < n) {
-        uint32_t rem = (uint32_t)(n - pos);
-        for (uint32_t i = 0; i < rem; ++i) w[i >> 2] |= (uint32_t)seq[pos + i] << (8 * (i & 3));
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// one filter positive waiting for level 2: the filter hash of its q-gram (level 2 is keyed by it)
-// and the low 32 bits of its text position (a wave's queued positions span far less than 4 GiB;
-// the high bits are restored from the wave's current position when the entry is taken)
-struct alignas(8) CandEntry {
-    uint32_t h;
-    uint32_t t_lo;
-};
-constexpr uint32_t kRingEntries = 128;  // per wave; <= 64 pending before an append round of <= 64
-constexpr uint32_t kLdsPatCounters = 64;  // pattern sets up to this size count their hits in LDS
-constexpr uint32_t kHitSlots = 64;  // per wave: verified-q-gram hits waiting for level 3 (one per lane)
-constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) + kLdsPatCounters * 8 +
-                               (kBlockThreads / 64) * kHitSlots * 8;  // 152.5 KiB
-static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
-
-// compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
-//   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only,
-//   8 = filter positives are queued in the LDS ring but never probed (level 1 -> 2 hand-off cost),
-//   16 = level 3 dropped (q-gram hits are queued, never resolved), 32 = level 3 without its stores / atomics,
-//   64 = q-gram hits are not even queued, 128 = no per-pattern counter atomics, 256 = no record-flag stores
-#ifndef MK_ABLATE
-#define MK_ABLATE 0
-#endif
-
-// ---- level 3: one q-gram hit (pattern `pat` would start at text position p) --------------
-// byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
-// check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
-// its tuple in `out`.
-template <bool EMIT>
-__device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt, mk_hit &out) {
-    // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
-    if constexpr ((MK_ABLATE & 16) != 0) return false;
-    const uint32_t a = P.uniform_len ? pat * P.uniform_len : P.pat_off[pat];
-    const uint32_t len = P.uniform_len ? P.uniform_len : P.pat_off[pat + 1] - a;
-    if (p + len > P.n_bytes) return false;
-    const uint8_t *__restrict__ tx = P.seq + p;
-    const uint8_t *__restrict__ pt = P.pat_bytes + a;
-    // Everything below that touches memory is independent of everything else, so it is issued
-    // together and costs ONE round trip: the record-offset pair at the interpolated record
-    // index (reads are mostly of similar length, so the guess is usually right) and the four
-    // 8-byte text / pattern loads of the comparison.
-    const uint64_t n = P.n_rec;
-    uint64_t lo = (uint64_t)((double)p * P.rec_per_byte);
-    if (lo >= n) lo = n - 1;
-    uint64_t rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];  // seq_off[0] == 0 is part of the ABI
-    if (P.case_insensitive) {
-        for (uint32_t i = 0; i < len; ++i)
-            if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return false;
-    } else {
-        // independent 8-byte (unaligned) loads, no early-exit chain; the clamped offsets of
-        // patterns up to 32 bytes (every k-mer) overlap harmlessly
-        uint64_t diff = 0;
-        if (len >= 8) {
-            const uint32_t last = len - 8;
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                const uint32_t o = 8 * i < last ? 8 * i : last;
-                uint64_t x, y;
-                __builtin_memcpy(&x, tx + o, 8);
-                __builtin_memcpy(&y, pt + o, 8);
-                diff |= x ^ y;
-            }
-            for (uint32_t o = 32; o < len; o += 8) {  // longer patterns
-                const uint32_t oo = o < last ? o : last;
-                uint64_t x, y;
-                __builtin_memcpy(&x, tx + oo, 8);
-                __builtin_memcpy(&y, pt + oo, 8);
-                diff |= x ^ y;
-            }
-        } else {
-            for (uint32_t i = 0; i < len; ++i) diff |= (uint64_t)(tx[i] ^ pt[i]);
-        }
-        if (diff) return false;
-    }
-    // record containing p: largest r with rec_off[r] <= p.  Wrong guess (ragged records):
-    // gallop from it to a bracket, then bisect.
-    if (!(rstart <= p && p < rend)) {
-        uint64_t hi;
-        if (rstart <= p) {
-            hi = lo + 1;
-            uint64_t step = 1;
-            while (hi < n && P.rec_off[hi] <= p) {
-                lo = hi;
-                step <<= 1;
-                hi = (n - hi > step) ? hi + step : n;
-            }
-        } else {
-            hi = lo;
-            uint64_t step = 1;
-            lo = lo - 1;  // lo > 0 here because rec_off[0] = 0 <= p
-            while (P.rec_off[lo] > p) {
-                hi = lo;
-                step <<= 1;
-                lo = lo > step ? lo - step : 0;
-            }
-        }
-        while (hi - lo > 1) {  // invariant: rec_off[lo] <= p < rec_off[hi]  (rec_off[n] = n_bytes)
-            const uint64_t mid = (lo + hi) >> 1;
-            if (P.rec_off[mid] <= p)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        rstart = P.rec_off[lo];
-        rend = P.rec_off[lo + 1];
-    }
-    if (p + len > rend) return false;  // occurrence would cross a record boundary
-    // ---- a true occurrence.  The flag is a plain byte store (idempotent; nothing waits for it);
-    // flagged records are counted afterwards by mk_count_flags_kernel when counters are wanted.
-    if constexpr ((MK_ABLATE & 32) != 0) {
-        n_true++;
-        return false;
-    }
-    if constexpr ((MK_ABLATE & 256) == 0) reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
-    n_true++;
-    if (P.counters && (MK_ABLATE & 128) == 0) {
-        if (P.n_pat <= kLdsPatCounters) {
-            // few patterns: their counters share a cache line or two, and a million global atomics
-            // on one line serialise in one L2 channel (+0.5 ms at 13 patterns).  Count in LDS,
-            // flush once per workgroup at kernel end.
-            atomicAdd(&lds_pat_cnt[pat], 1ull);
-        } else {
-            atomicAdd(&P.counters[pat], 1ull);
-        }
-    }
-    if (EMIT) {  // the caller stages the tuple (HitStage)
-        out.rec = lo;
-        out.pat = pat;
-        out.pos = (uint32_t)(p - rstart);
-    }
-    return true;
-}
-
-// ---- per-wave buffer of q-gram hits (LDS, 64 x 8 B) ---------------------------------------------
-// True q-gram hits are rare; resolving them the moment they are found would run the dependent
-// memory round trips of resolve_one with one or two active lanes.  They are collected instead
-// and resolved up to 64 at a time (one per lane).  The buffer lives in LDS: a global-memory
-// ring cost one store per hit whose acknowledgement the wave's next s_waitcnt vmcnt(0) had to
-// wait for (loads and stores share the counter on gfx9) -- 0.1 ms per million hits on the
-// slower boxes of the pool -- plus two L2 round trips per drain to read the ring back.
-// An entry is {low 32 bits of the occurrence's text position, pattern}; the high bits are
-// restored relative to the wave's newest queued position like a CandEntry's.
-struct HitRing {
-    uint2 *q;        // this wave's buffer (LDS)
-    uint32_t count;  // wave-uniform, <= kHitSlots
-    // EMIT: verified occurrences of this wave, staged in global memory and moved to the output
-    // array kHitStage - 64 or more at a time.  The output cursor is ONE address: an atomic on it
-    // costs ~10 ns whoever issues it, so reserving 64 slots per atomic caps the kernel at ~6 G
-    // occurrences/s (every read hitting: 20.8 ms per 100 M reads instead of 10.2 without tuples).
-    mk_hit *stage;
-    uint32_t staged;  // wave-uniform
-};
-
-// move this wave's staged tuples to the output array: one cursor atomic for all of them
-__device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, uint32_t lane) {
-    const uint32_t n = hr.staged;
-    if (n == 0) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(P.n_hits, (unsigned long long)n);
-    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    base = ((unsigned long long)bhi << 32) | blo;
-    // the entries were stored by other lanes of this wave (same CU, same L1)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint4 v = reinterpret_cast<const uint4 *>(hr.stage)[i];
-        if (base + i < P.hits_cap) reinterpret_cast<uint4 *>(P.hits)[base + i] = v;
-    }
-    // the next tuples staged must not overtake these reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    hr.staged = 0;
-}
-
-template <bool EMIT>
-__device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint64_t newest_end, uint32_t lane, uint32_t &n_true,
-                                           unsigned long long *lds_pat_cnt) {
-    const uint32_t n = hr.count;
-    // entries were written by other lanes of this wave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint2 e = hr.q[lane & (kHitSlots - 1)];
-    __builtin_amdgcn_wave_barrier();
-    bool hit = false;
-    mk_hit out;
-    if (lane < n) {
-        uint64_t p = (newest_end & 0xFFFFFFFF00000000ull) | e.x;
-        if (p >= newest_end) p -= 1ull << 32;
-        hit = resolve_one<EMIT>(P, e.y, p, n_true, lds_pat_cnt, out);
-    }
-    hr.count = 0;
-    if constexpr (EMIT) {
-        const uint64_t mm = __ballot(hit);
-        if (mm) {
-            if (hit) {
-                const uint32_t below =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                hr.stage[hr.staged + below] = out;
-            }
-            hr.staged += (uint32_t)__popcll(mm);
-            if (hr.staged > kHitStage - 64) flush_stage(P, hr, lane);  // no room for another full round
-        }
-    }
-}
-
-// ---- level 2: up to 64 filter positives (one per lane) against the exact q-gram table -----
-// One bucket (32 B, 4 entries) per lane and round.  probe_round() consumes a bucket that is
-// already in registers: fingerprint matches are compacted (ballot/popcount) into the wave's
-// hit ring; returns whether this lane must look at the next bucket (its bucket was full).
-template <bool EMIT>
-__device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint64_t t, uint4 v0, uint4 v1,
-                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt) {
-    const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
-    const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t e_off = epo[k] & 15u, e_pat = epo[k] >> 4;
-        const bool match = active && epo[k] != kEmptyPat && efp[k] == fp && t >= e_off;
-        const uint64_t mm = (MK_ABLATE & 64) ? 0ull : __ballot(match);
-        if (mm) {  // uniform, rare
-            const uint32_t cnt = (uint32_t)__popcll(mm);
-            if (hr.count + cnt > kHitSlots) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);  // make room
-            if (match) {
-                const uint32_t below =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                hr.q[hr.count + below] = make_uint2((uint32_t)(t - e_off), e_pat);
-            }
-            hr.count += cnt;
-        }
-    }
-    return active && epo[3] != kEmptyPat;  // bucket full: the key may live in the next one
-}
-
-__device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, uint32_t b, uint4 &v0, uint4 &v1) {
-    v0 = make_uint4(0, kEmptyPat, 0, kEmptyPat);
-    v1 = v0;
-    if (active) {
-        const uint4 *bp = reinterpret_cast<const uint4 *>(P.table + (size_t)b * kBucketEntries);
-        v0 = bp[0];
-        v1 = bp[1];
-    }
-}
-
-// synchronous probe: wave-uniform loop over the bucket chain (one iteration unless a home
-// bucket is full), each iteration one memory round trip
-template <bool EMIT>
-__device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint64_t t,
-                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt) {
-    while (__ballot(active)) {
-        uint4 v0, v1;
-        load_bucket(P, active, b, v0, v1);
-        active = probe_round<EMIT>(P, active, fp, t, v0, v1, lane, hr, newest_end, n_true, lds_pat_cnt);
-        b = (b + 1) & P.table_mask;
-    }
-}
-
-#ifndef MK_LOOPV
-#define MK_LOOPV 1  // 1: one looped copy of filter + hand-off per chunk (2 % faster at S=8, tools/loopv_ab.sh); 0: four straight-line filter passes per group
-#endif
-#ifndef MK_STREAM_NT
-#define MK_STREAM_NT 1  // 1: non-temporal stream loads; 0: plain loads (tools/hitpath_ab2.sh: 6 % slower on the headline workload, 12 % faster when every read hits)
-#endif
-#ifndef MK_ISSUE_AT
-#define MK_ISSUE_AT 56  // ring fill at which a group ends with an asynchronous level-2 probe
-#endif
-
-// Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
-// sizes that matter get their own kernels: no runtime masks, no unused halo words);
-// QC == 0: runtime q <= 16 (32-bit keys); QC == -1: runtime q in 17..32.
-template <int S, int QC>
-struct Geo {
-    static constexpr bool kFixed = QC > 0;
-    static constexpr int kNS = 16 / S;                                     // samples per lane per chunk
-    static constexpr int kSpan = kFixed ? (kNS - 1) * S + QC : 48;         // bases a lane looks at
-    static constexpr bool kNeedW1 = kSpan > 16, kNeedW2 = kSpan > 32;      // halo words
-};
-
-// bits [bit, bit+32) of the packed stream w0 | w1<<32 | w2<<64 (bit is a compile-time constant)
-__device__ __forceinline__ uint32_t stream32(uint32_t w0, uint32_t w1, uint32_t w2, int bit) {
-    const int k = bit >> 5, r = bit & 31;
-    const uint32_t a = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : 0u;
-    const uint32_t b = k == 0 ? w1 : k == 1 ? w2 : 0u;
-    return r ? __builtin_amdgcn_alignbit(b, a, r) : a;
-}
-
-// Bloom hash of the q-gram that starts `sh` bits into the lane's packed stream; equals
-// filter.hpp's bloom_hash(key) for the masked key.
-template <int S, int QC>
-__device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32_t w2, int sh, uint32_t mask_lo,
-                                                uint32_t mask_hi) {
-    constexpr uint32_t C1 = 0x9E3779u, C2 = 0x85EBCBu;
-    if constexpr (QC > 0) {
-        const uint32_t lo = stream32(w0, w1, w2, sh);
-        if constexpr (QC <= 12) {
-            return __umul24(lo & ((1u << (2 * QC)) - 1u), C1);
-        } else if constexpr (QC < 16) {
-            const uint32_t l = lo & ((1u << (2 * QC)) - 1u);
-            return __umul24(l, C1) + __umul24(l >> 24, C2);
-        } else if constexpr (QC == 16) {
-            return __umul24(lo, C1) + __umul24(lo >> 24, C2);
-        } else if constexpr (QC < 24) {  // key bits 24 .. 2q-1 live in t's low bits
-            const uint32_t t = stream32(w0, w1, w2, sh + 24) & ((1u << (2 * QC - 24)) - 1u);
-            return __umul24(lo, C1) + __umul24(t, C2);
-        } else if constexpr (QC == 24) {  // mul24 ignores t's top byte: no mask at all
-            const uint32_t t = stream32(w0, w1, w2, sh + 24);
-            return __umul24(lo, C1) + __umul24(t, C2);
-        } else {  // 25..32: key bits 48..55 are added in place, bits >= 56 ignored
-            const uint32_t t = stream32(w0, w1, w2, sh + 24);
-            constexpr uint32_t top = QC >= 28 ? 0xFF000000u : (((1u << (2 * QC - 48)) - 1u) << 24);
-            return __umul24(lo, C1) + __umul24(t, C2) + (t & top);
-        }
-    } else {
-        const uint32_t lo = stream32(w0, w1, w2, sh) & mask_lo;
-        const uint32_t hi = QC == 0 ? 0u : (stream32(w0, w1, w2, sh + 32) & mask_hi);
-        const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 24);
-        return __umul24(lo, C1) + __umul24(t, C2) + (t & 0xFF000000u);
-    }
-}
-
-// ---- main kernel -----------------------------------------------------------------------
-template <int S, int QC, bool EMIT, bool GF>
-__global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
-    using G = Geo<S, QC>;
-    __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
-    if (threadIdx.x < kLdsPatCounters)
-        reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2)[threadIdx.x] = 0;
-    if constexpr (GF) __syncthreads();
-    if constexpr (!GF) {  // stage the filter image of the pattern set in LDS
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
-        uint4 *dst = reinterpret_cast<uint4 *>(bloom);
-        for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
-        __syncthreads();
-    }
-    const uint2 *__restrict__ gbloom = reinterpret_cast<const uint2 *>(P.bloom);  // GF: filter blocks in global memory
-    const uint32_t gmask = P.gbloom_mask;
-
-    if (P.counters && blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS], (unsigned long long)P.n_rec);
-        atomicAdd(&P.counters[P.n_pat + MK_SUM_BASES], (unsigned long long)P.n_bytes);
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // SGPR
-    const uint64_t wave_id = (uint64_t)blockIdx.x * (kBlockThreads / 64) + wave_in_block;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (kBlockThreads / 64);
-    constexpr int NS = G::kNS;
-    constexpr uint64_t kTileBytes = (uint64_t)kTileChunks * kChunkBytes;
-    const uint32_t mask_lo = P.key_mask_lo, mask_hi = P.key_mask_hi;
-    const uint8_t *__restrict__ seq = P.seq;
-    const uint64_t n_bytes = P.n_bytes;
-    CandEntry *ring = reinterpret_cast<CandEntry *>(bloom + kBloomWords) + wave_in_block * kRingEntries;
-    uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
-    HitRing hr;  // this wave's q-gram-hit ring
-    hr.q = reinterpret_cast<uint2 *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2 + kLdsPatCounters * 2) +
-           wave_in_block * kHitSlots;
-    hr.count = 0;
-    hr.stage = EMIT ? P.stage + wave_id * (uint64_t)kHitStage : nullptr;
-    hr.staged = 0;
-    uint32_t n_true = 0;  // per lane: occurrences found
-    unsigned long long *lds_pat_cnt = reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2);
-    uint32_t abl_acc = 0;              // ablation builds only
-
-    // ---- level 1 for one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
-    // packed chunk that follows in the text (halo source for the last lanes).  Returns the
-    // lane's candidate mask (bit j = sample j passed the filter).  Straight-line code.
-    // Every reference-capturing lambda below is always_inline: past some size the inliner leaves
-    // one of them as a real function, its captures (and the kernel arguments) then live in scratch
-    // memory and the LDS ring is reached through flat instructions -- a 3x slower kernel.
-    auto halo = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &w1, uint32_t &w2) __attribute__((always_inline)) {
-        // lane i needs the packed dwords of lanes i+1 and i+2; DPP wave_shl:1 moves a whole
-        // wave by one lane in one VALU op, lane 63 keeps `old` = the next chunk's lane
-        w1 = 0;
-        w2 = 0;
-        if constexpr (G::kNeedW1) {
-            const uint32_t n0 = __builtin_amdgcn_readlane(pk_nxt, 0);
-            w1 = __builtin_amdgcn_update_dpp(n0, pk_cur, 0x130, 0xf, 0xf, false);
-        }
-        if constexpr (G::kNeedW2) {
-            const uint32_t n1 = __builtin_amdgcn_readlane(pk_nxt, 1);
-            w2 = __builtin_amdgcn_update_dpp(n1, w1, 0x130, 0xf, 0xf, false);
-        }
-    };
-    auto filter_chunk = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t &h0, uint32_t &h1) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t w0 = pk_cur;
-        uint32_t w1, w2;
-        halo(pk_cur, pk_nxt, w1, w2);
-        if constexpr ((MK_ABLATE & 4) != 0) return ((w0 ^ w1 ^ w2) == 0x12345678u) ? 1u : 0u;  // loads + pack only
-        uint32_t cand = 0;
-        const char *bloom_bytes = reinterpret_cast<const char *>(bloom);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            uint32_t h = sample_hash<S, QC>(w0, w1, w2, 2 * j * S, mask_lo, mask_hi);
-            if (j == 0) h0 = h;  // kept for the hand-off when a lane has at most two samples
-            if (j == 1) h1 = h;
-            uint2 blk;
-            if constexpr ((MK_ABLATE & 2) != 0) {
-                blk = make_uint2(h & 0x10101010u, h);
-            } else if constexpr (GF) {
-                blk = gbloom[gbloom_block(h, gmask)];  // random 8-byte read, L2 / Infinity Cache
-                h = gbloom_bits(h);
-            } else {
-                blk = *reinterpret_cast<const uint2 *>(bloom_bytes + bloom_block_byte(h));  // ds_read_b64
-            }
-            // all three filter bits set?  (shift counts use the low 5 bits of their register)
-            const uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
-            cand |= (m & 1u) << j;
-        }
-        if constexpr ((MK_ABLATE & 1) != 0) {  // keep the filter work alive, drop its result
-            abl_acc += cand;
-            cand = 0;
-        }
-        return cand;
-    };
-
-    // ---- level 2 drains.  Synchronous: take n (<= 64) candidates off the ring and walk their
-    // bucket chains.  Asynchronous (the normal case): issue the bucket loads now, keep them in
-    // registers, and consume them at the top of the next group -- by then the loads are older
-    // than the stream loads the wave has waited for anyway, so the probe's memory round trip
-    // overlaps a whole group of scanning instead of stalling the wave (and its prefetches).
-    bool pend_on = false;  // wave-uniform
-    bool pend_active = false;
-    uint32_t pend_fp = 0, pend_b = 0;
-    uint64_t pend_t = 0;
-    uint4 pend_v0 = make_uint4(0, 0, 0, 0), pend_v1 = pend_v0;
-    uint64_t newest_end = 0;  // wave-uniform: every queued position is < newest_end (and > newest_end - 4 GiB)
-    auto take_from_ring = [&](uint32_t n, bool &active, uint32_t &b, uint32_t &fp, uint64_t &t) __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const CandEntry e = ring[(q_head + lane) & (kRingEntries - 1)];
-        __builtin_amdgcn_wave_barrier();
-        active = lane < n;
-        b = table_bucket(e.h, P.table_mask);
-        fp = e.h;
-        t = (newest_end & 0xFFFFFFFF00000000ull) | e.t_lo;
-        if (t >= newest_end) t -= 1ull << 32;
-        q_head = (q_head + n) & (kRingEntries - 1);
-        q_count -= n;
-    };
-    auto drain_ring = [&](uint32_t n) __attribute__((always_inline)) {  // synchronous
-        bool active;
-        uint32_t b, fp;
-        uint64_t t;
-        take_from_ring(n, active, b, fp, t);
-        probe_chain<EMIT>(P, active, b, fp, t, lane, hr, newest_end, n_true, lds_pat_cnt);
-    };
-    auto issue_probe = [&](uint32_t n) __attribute__((always_inline)) {  // asynchronous: loads only
-        take_from_ring(n, pend_active, pend_b, pend_fp, pend_t);
-        load_bucket(P, pend_active, pend_b, pend_v0, pend_v1);
-        pend_on = true;
-    };
-    auto consume_probe = [&]() __attribute__((always_inline)) {
-        const bool more = probe_round<EMIT>(P, pend_active, pend_fp, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true, lds_pat_cnt);
-        if (__ballot(more))  // some home bucket was full: finish those chains synchronously
-            probe_chain<EMIT>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_t, lane, hr, newest_end, n_true, lds_pat_cnt);
-        pend_on = false;
-    };
-
-    // ---- level 1 -> 2 hand-off: filter positives -> per-wave LDS ring (ballot/popcount
-    // compaction); 64 at a time they are probed against the exact table, so the L2 round trip is
-    // paid once per 64 candidates, not per chunk.  With ~2 positives per 1 KiB chunk almost every
-    // chunk has one somewhere in the wave, and a compaction round per chunk costs as much as
-    // half the filter itself; so a positive first parks in its lane's register slot, and the
-    // slots are compacted into the ring only when some lane needs its slot a second time
-    // (every ~5 chunks: a birthday collision among 64 lanes).
-    uint32_t slot_h = 0, slot_t = 0;
-    bool slot_full = false;
-    auto flush_slots = [&]() __attribute__((always_inline)) {
-        const uint64_t full = __ballot(slot_full);
-        if (!full) return;
-        if (q_count > 64) drain_ring(64);  // an append round adds <= 64 entries to the 128-entry ring
-        if (slot_full) {
-            const uint32_t below =
-                __builtin_amdgcn_mbcnt_hi((uint32_t)(full >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)full, 0u));
-            CandEntry e;
-            e.h = slot_h;
-            e.t_lo = slot_t;
-            ring[(q_head + q_count + below) & (kRingEntries - 1)] = e;
-        }
-        q_count += (uint32_t)__popcll(full);
-        n_cand += (uint32_t)__popcll(full);
-        slot_full = false;
-    };
-    auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t cand, uint64_t cpos, uint32_t h0, uint32_t h1) __attribute__((always_inline)) {
-        const uint32_t w0 = pk_cur;
-        uint32_t w1 = 0, w2 = 0;
-        if constexpr (NS > 2) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below
-        newest_end = cpos + kChunkBytes;  // parked and queued positions are all below it
-        const uint32_t t_base = (uint32_t)cpos + lane * 16;
-        do {  // wave-uniform; one iteration unless a lane has several positives in this chunk
-            if (__ballot(cand != 0 && slot_full)) flush_slots();
-            if (cand != 0) {
-                const uint32_t j = (uint32_t)__ffs(cand) - 1u;
-                cand &= cand - 1;
-                if constexpr (NS <= 2) {
-                    slot_h = j ? h1 : h0;
-                } else {  // same value as sample_hash / filter.hpp's bloom_hash of the masked key
-                    const uint32_t sh = 2u * j * S;
-                    const uint32_t klo = __builtin_amdgcn_alignbit(w1, w0, sh) & mask_lo;  // sh == 0 -> w0
-                    const uint32_t khi = __builtin_amdgcn_alignbit(w2, w1, sh) & mask_hi;
-                    const uint32_t t = __builtin_amdgcn_alignbit(khi, klo, 24);
-                    slot_h = __umul24(klo, 0x9E3779u) + __umul24(t, 0x85EBCBu) + (t & 0xFF000000u);
-                }
-                slot_t = t_base + j * S;
-                slot_full = true;
-            }
-        } while (__ballot(cand != 0));
-    };
-
-    // ---- main phase: tiles whose 32 chunk loads (31 scanned + halo) lie inside the text.
-    // No bounds checks here; loads run one group (4 chunks = 4 KiB per wave, 64 KiB per CU)
-    // ahead of their use.
-    const uint64_t n_main_tiles = n_bytes >= kChunkBytes ? (n_bytes - kChunkBytes) / kTileBytes : 0;
-    if (wave_id < n_main_tiles) {
-        // loader cursor (wave-uniform): pointer to the next chunk to fetch.  Past this wave's
-        // last tile the pointer parks on the last main tile: the loads stay unconditional (a
-        // branch around a load would force s_waitcnt vmcnt(0) at the join), their data unused.
-        uint64_t ld_tile = wave_id;
-        uint32_t ld_g = 0;  // group index inside the tile (a tile is 8 groups of 4 chunk loads)
-        const uint64_t last_tile = n_main_tiles - 1;
-        const uint8_t *ld_ptr = seq + wave_id * kTileBytes + lane * 16;
-        auto nt_load = [](const uint8_t *p) -> uint4 {
-            // non-temporal: the text is read once; keep L2 for the exact table and the filter image
-#if MK_STREAM_NT
-            const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-#else
-            const u32x4 nv = *reinterpret_cast<const u32x4 *>(p);
-#endif
-            return make_uint4(nv.x, nv.y, nv.z, nv.w);
-        };
-        // four loads off one address register (immediate offsets); the tile wrap is checked
-        // once per group so that the group stays one basic block
-        auto load_group = [&](uint4 &a, uint4 &b, uint4 &c, uint4 &d) __attribute__((always_inline)) {
-            a = nt_load(ld_ptr);
-            b = nt_load(ld_ptr + kChunkBytes);
-            c = nt_load(ld_ptr + 2 * kChunkBytes);
-            d = nt_load(ld_ptr + 3 * kChunkBytes);
-            ld_ptr += 4 * kChunkBytes;
-            if (++ld_g == (uint32_t)(kTileChunks + 1) / 4) {  // next tile of this wave
-                ld_g = 0;
-                ld_tile += n_waves;
-                const uint64_t t = ld_tile < last_tile ? ld_tile : last_tile;
-                ld_ptr = seq + t * kTileBytes + lane * 16;
-            }
-        };
-        // Register pipeline, one group = 4 chunks deep.  A group (straight-line code, so the
-        // compiler's s_waitcnt vmcnt(N) stay counted): pack the four chunks loaded one group
-        // ago, re-issue the four loads, run level 1 on the four chunk pairs (pk_prev,p0) ..
-        // (p2,p3).  Only if some lane has a filter positive does the wave enter the (looped,
-        // single-copy) hand-off code.
-        uint4 r0, r1, r2, r3;
-        load_group(r0, r1, r2, r3);
-        uint32_t pk_prev = 0;
-        // Queued filter positives carry only the low 32 bits of their position, restored relative to
-        // the wave's current position: none may stay queued while the wave advances 4 GiB.  A wave's
-        // tiles are n_waves * 31 KiB apart, so every `age_limit` tiles (1 GiB of advance) whatever
-        // is parked or queued is pushed on to level 2 (sparse candidates never reach the ring's
-        // fill threshold by themselves: 1 pattern on 15 GB lost two hits in three before this).
-        const uint32_t age_limit = (uint32_t)std::max<uint64_t>(1, (1ull << 30) / (n_waves * kTileBytes));
-        uint32_t tiles_since_push = 0;
-        for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
-            const uint64_t base = tile * kTileBytes;
-            if (++tiles_since_push >= age_limit) {
-                tiles_since_push = 0;
-                flush_slots();
-                if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);  // 32-bit positions too
-                if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
-            }
-#pragma unroll 1
-            for (int g = 0; g < (kTileChunks + 1) / 4; ++g) {
-                const uint32_t p0 = pack16(r0), p1 = pack16(r1), p2 = pack16(r2), p3 = pack16(r3);
-                // pack BEFORE re-issuing the loads into the same registers: without this pin the
-                // compiler sinks the packs below the loads and keeps the raw data alive with 16
-                // v_mov per group
-                asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-                // (re-issuing the stream loads first is 2-3 % slower: tools/ab3.sh, r01)
-                if (pend_on) consume_probe();  // its loads are older than the stream loads just waited for
-                load_group(r0, r1, r2, r3);
-#if MK_LOOPV == 1
-                // one looped copy of filter + hand-off per chunk (rotating the packed registers)
-                {
-                    uint32_t q0 = p0, q1 = p1, q2 = p2;
-#pragma unroll 1
-                    for (int k = 0; k < 4; ++k) {
-                        const int ci = 4 * g + k - 1;
-                        if (ci >= 0) {
-                            uint32_t h0 = 0, h1 = 0;
-                            const uint32_t ck = filter_chunk(pk_prev, q0, h0, h1);
-                            if constexpr ((MK_ABLATE & 4) != 0) n_cand += ck;
-                            if (__ballot(ck != 0)) queue_candidates(pk_prev, q0, ck, base + (uint64_t)ci * kChunkBytes, h0, h1);
-                        }
-                        pk_prev = q0;
-                        q0 = q1;
-                        q1 = q2;
-                        q2 = p3;
-                    }
-                }
-#else
-                // chunk scanned by pair k is 4g + k - 1; the first pair of a tile straddles tiles
-                uint32_t ha[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0};
-                uint32_t c0 = filter_chunk(pk_prev, p0, ha[0], hb[0]);
-                if (g == 0) c0 = 0;
-                const uint32_t c1 = filter_chunk(p0, p1, ha[1], hb[1]);
-                const uint32_t c2 = filter_chunk(p1, p2, ha[2], hb[2]);
-                const uint32_t c3 = filter_chunk(p2, p3, ha[3], hb[3]);
-                if constexpr ((MK_ABLATE & 4) != 0) n_cand += c0 + c1 + c2 + c3;
-                if (__ballot((c0 | c1 | c2 | c3) != 0)) {  // rare at useful filter densities
-#pragma unroll 1
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t cur = k == 0 ? pk_prev : k == 1 ? p0 : k == 2 ? p1 : p2;
-                        const uint32_t nxt = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
-                        const uint32_t ck = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-                        const uint32_t hk0 = k == 0 ? ha[0] : k == 1 ? ha[1] : k == 2 ? ha[2] : ha[3];
-                        const uint32_t hk1 = k == 0 ? hb[0] : k == 1 ? hb[1] : k == 2 ? hb[2] : hb[3];
-                        if (__ballot(ck != 0))
-                            queue_candidates(cur, nxt, ck, base + (uint64_t)(4 * g + k - 1) * kChunkBytes, hk0, hk1);
-                    }
-                }
-#endif
-                if constexpr ((MK_ABLATE & 8) != 0) {  // hand-off cost only: forget the queued entries
-                    if (q_count >= MK_ISSUE_AT) {
-                        q_head = (q_head + q_count) & (kRingEntries - 1);
-                        q_count = 0;
-                    }
-                } else if (!pend_on && q_count >= MK_ISSUE_AT) {
-                    issue_probe(q_count < 64 ? q_count : 64);
-                }
-                pk_prev = p3;
-            }
-        }
-    }
-    if (pend_on) consume_probe();
-
-    // ---- tail phase: the < 32 KiB behind the last main tile, with guarded loads; one wave
-    if (wave_id == n_main_tiles % n_waves) {
-        for (uint64_t cpos = n_main_tiles * kTileBytes; cpos < n_bytes; cpos += kChunkBytes) {
-            const uint32_t pk_cur = pack16(load16(seq, cpos + lane * 16, n_bytes));
-            const uint32_t pk_nxt = pack16(load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
-            uint32_t h0 = 0, h1 = 0;
-            const uint32_t ck = filter_chunk(pk_cur, pk_nxt, h0, h1);
-            if constexpr ((MK_ABLATE & 4) != 0) n_cand += ck;
-            if (__ballot(ck != 0)) queue_candidates(pk_cur, pk_nxt, ck, cpos, h0, h1);
-        }
-    }
-
-    // drain what is left in this wave's slots and rings
-    flush_slots();
-    while (q_count) drain_ring(q_count < 64 ? q_count : 64);
-    if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);
-    if constexpr (EMIT) flush_stage(P, hr, lane);
-    if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
-    if (P.counters) {
-        if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
-        // uniform addresses: the compiler folds each of these into one atomic per wave
-        if (n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
-    }
-    if (P.counters && P.n_pat <= kLdsPatCounters) {  // flush the workgroup's per-pattern counts
-        __syncthreads();
-        if (threadIdx.x < P.n_pat && lds_pat_cnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x], lds_pat_cnt[threadIdx.x]);
-    }
-}
 
 // number of records with rec_flags != 0 -> counters[n_pat + MK_SUM_RECORDS_HIT]
 // (flag bytes are 0 or 1; 16-byte loads over the 16-byte aligned middle, bytes at both ends)
@@ -754,8 +41,6 @@ __global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint8_t *__re
     }
 }
 
-uint32_t scan_lds_bytes() { return kLdsBytes; }
-
 void launch_count_flags(const ScanParams &p, hipStream_t st) {
     const uint64_t n16 = p.n_rec / 16;
     const int blocks = (int)std::min<uint64_t>(1024, std::max<uint64_t>(1, (n16 + 1023) / 1024));
@@ -763,9 +48,21 @@ void launch_count_flags(const ScanParams &p, hipStream_t st) {
                        p.n_rec, p.counters + p.n_pat + MK_SUM_RECORDS_HIT);
 }
 
+// dst[i] += src[i]: counter vectors of two handles that share a device (mk_reduce_counters)
+__global__ void mk_add_u64_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, size_t len) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+void launch_add_u64(unsigned long long *dst, const unsigned long long *src, size_t len, hipStream_t stream) {
+    const int blocks = (int)std::min<size_t>(1024, (len + 255) / 256);
+    hipLaunchKernelGGL(mk_add_u64_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, src, len);
+}
+
+// the kernel variants are instantiated in groups by scan_variants.hip (one translation unit per
+// group, compiled in parallel); launch_variant<...> is the host-side launcher of one of them
 template <int S, int QC, bool EMIT, bool GF>
 static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
-    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT, GF>), dim3(grid), dim3(kBlockThreads), 0, st, p);
+    launch_variant<S, QC, EMIT, GF>(p, grid, st);
     return name;
 }
 
@@ -823,10 +120,12 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
 #undef MK_VARIANT
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
-__global__ void mk_synth_fill_kernel(uint64_t seed, uint64_t n_bytes, uint8_t *__restrict__ seq) {
+// byte0 = global position of seq[0] in the synthetic stream (a multiple of 32)
+__global__ void mk_synth_fill_kernel(uint64_t seed, uint64_t byte0, uint64_t n_bytes, uint8_t *__restrict__ seq) {
     const uint64_t n16 = (n_bytes + 15) / 16;
+    const uint64_t blk0 = byte0 >> 5;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t bits = synth_block(seed, i >> 1) >> (32 * (i & 1));
+        const uint64_t bits = synth_block(seed, blk0 + (i >> 1)) >> (32 * (i & 1));
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -844,15 +143,16 @@ __global__ void mk_synth_fill_kernel(uint64_t seed, uint64_t n_bytes, uint8_t *_
     }
 }
 
-__global__ void mk_synth_off_plant_kernel(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every,
+__global__ void mk_synth_off_plant_kernel(uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len, uint32_t plant_every,
                                           const uint8_t *__restrict__ pat_bytes, const uint32_t *__restrict__ pat_off,
                                           uint32_t n_pat, uint8_t *__restrict__ seq, uint64_t *__restrict__ seq_off) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
         seq_off[r] = r * read_len;
         if (r == n_rec || plant_every == 0) continue;
-        const uint64_t h = synth_rec_hash(seed, r);
+        const uint64_t gr = rec0 + r;  // global record index: a shard of a job equals that slice of the whole job
+        const uint64_t h = synth_rec_hash(seed, gr);
         if (h % plant_every != 0) continue;
-        const uint32_t pat = (uint32_t)((r * 2654435761ull) % n_pat);
+        const uint32_t pat = (uint32_t)((gr * 2654435761ull) % n_pat);
         const uint32_t a = pat_off[pat], len = pat_off[pat + 1] - a;
         if (len > read_len) continue;
         const uint32_t o = (uint32_t)((h >> 32) % (read_len - len + 1));
@@ -860,11 +160,11 @@ __global__ void mk_synth_off_plant_kernel(uint64_t seed, uint64_t n_rec, uint32_
     }
 }
 
-void launch_synth(uint64_t seed, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
+void launch_synth(uint64_t seed, uint64_t rec0, uint64_t n_rec, uint32_t read_len, uint32_t plant_every, const uint8_t *d_pat_bytes,
                   const uint32_t *d_pat_off, uint32_t n_pat, uint8_t *d_seq, uint64_t *d_seq_off, hipStream_t stream) {
     const uint64_t n_bytes = n_rec * read_len;
-    hipLaunchKernelGGL(mk_synth_fill_kernel, dim3(2048), dim3(256), 0, stream, seed, n_bytes, d_seq);
-    hipLaunchKernelGGL(mk_synth_off_plant_kernel, dim3(2048), dim3(256), 0, stream, seed, n_rec, read_len, plant_every,
+    hipLaunchKernelGGL(mk_synth_fill_kernel, dim3(2048), dim3(256), 0, stream, seed, rec0 * read_len, n_bytes, d_seq);
+    hipLaunchKernelGGL(mk_synth_off_plant_kernel, dim3(2048), dim3(256), 0, stream, seed, rec0, n_rec, read_len, plant_every,
                        d_pat_bytes, d_pat_off, n_pat, d_seq, d_seq_off);
 }
 

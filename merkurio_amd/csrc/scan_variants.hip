@@ -1,0 +1,60 @@
+// scan_variants.hip -- instantiates the scan kernel (scan_kernel_impl.hpp) for one GROUP of variants.
+// Compiled once per group with -DMK_TU=<n> (merkurio_amd/build.py runs the groups in parallel: the
+// ~60 variants take minutes in one translation unit).  S = sampling stride, QC = q-gram length
+// (> 0 fixed at compile time, 0 runtime q <= 16, -1 runtime q in 17..32), GF = filter in global memory.
+#include "scan_kernel_impl.hpp"
+
+#ifndef MK_TU
+#error "compile with -DMK_TU=0..6"
+#endif
+
+namespace mk {
+
+template <int S, int QC, bool EMIT, bool GF>
+void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT, GF>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, p);
+}
+
+#define MK_INST(S_, QC_, GF_)                                                             \
+    template void launch_variant<S_, QC_, false, GF_>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, GF_>(const ScanParams &, int, hipStream_t)
+
+#if MK_TU == 0  // LDS filter, q fixed at compile time: the 31-mer and 21-mer families
+uint32_t scan_lds_bytes() { return kLdsBytes; }
+MK_INST(16, 16, false);
+MK_INST(8, 24, false);
+MK_INST(4, 28, false);
+MK_INST(4, 18, false);
+#elif MK_TU == 1  // LDS filter, runtime q <= 16
+MK_INST(1, 0, false);
+MK_INST(2, 0, false);
+MK_INST(4, 0, false);
+MK_INST(8, 0, false);
+MK_INST(16, 0, false);
+#elif MK_TU == 2  // LDS filter, runtime q in 17..32
+MK_INST(1, -1, false);
+MK_INST(2, -1, false);
+MK_INST(4, -1, false);
+MK_INST(8, -1, false);
+MK_INST(16, -1, false);
+#elif MK_TU == 3  // global filter, q fixed
+MK_INST(8, 14, true);
+MK_INST(4, 18, true);
+MK_INST(8, 24, true);
+#elif MK_TU == 4  // global filter, runtime q <= 16
+MK_INST(1, 0, true);
+MK_INST(2, 0, true);
+MK_INST(4, 0, true);
+MK_INST(8, 0, true);
+MK_INST(16, 0, true);
+#elif MK_TU == 5  // global filter, runtime q in 17..32
+MK_INST(1, -1, true);
+MK_INST(2, -1, true);
+MK_INST(4, -1, true);
+MK_INST(8, -1, true);
+MK_INST(16, -1, true);
+#else
+#error "unknown MK_TU"
+#endif
+
+}  // namespace mk

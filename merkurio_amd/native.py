@@ -30,6 +30,8 @@ MK_E_HIP = -7
 MK_E_CAPACITY = -8
 MK_E_INVALID_ARG = -9
 MK_E_UNSUPPORTED = -10
+MK_E_RCCL = -11
+MK_COMM_ID_BYTES = 128
 
 MK_ALGO_AUTO, MK_ALGO_AC, MK_ALGO_BNDMQ = 0, 1, 2
 MK_FLAG_ASCII_CASE_INSENSITIVE = 1
@@ -43,11 +45,12 @@ ROW_DTYPE = np.dtype([("rec", "<u8"), ("pat", "<u4"), ("pos", "<u4"), ("file", "
 EXPORTS = [
     "mk_abi_version", "mk_last_error", "mk_device_count", "mk_read_kmers_from_text", "mk_parse_pattern_list",
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
-    "mk_free", "mk_matcher_create", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
+    "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
-    "mk_synth_reads_host",
+    "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_unique_id", "mk_comm_init",
+    "mk_comm_reduce_counters", "mk_comm_destroy",
 ]
 
 
@@ -65,6 +68,16 @@ class PatternError(MerkurioError):
     @property
     def kind(self):
         return self.KINDS.get(self.code, "?")
+
+
+class MatcherOptions(C.Structure):
+    """mk_matcher_options (include/merkurio_hip.h): tuning / test hooks of mk_matcher_create_ex"""
+    _fields_ = [("struct_size", C.c_uint32), ("force_stride", C.c_uint32), ("force_global_filter", C.c_uint32),
+                ("gbloom_log2_blocks", C.c_uint32)]
+
+    def __init__(self, force_stride=0, force_global_filter=False, gbloom_log2_blocks=0):
+        super().__init__(C.sizeof(MatcherOptions), int(force_stride), int(bool(force_global_filter)),
+                         int(gbloom_log2_blocks))
 
 
 class Counters(C.Structure):
@@ -133,6 +146,15 @@ def load(build_if_missing=True):
     L.mk_matcher_num_patterns.restype = C.c_uint32
     L.mk_matcher_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
                                     C.POINTER(C.c_void_p)]
+    L.mk_matcher_create_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
+                                       C.POINTER(MatcherOptions), C.POINTER(C.c_void_p)]
+    L.mk_synth_reads_device_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mk_reduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]
+    L.mk_comm_unique_id.argtypes = [C.c_void_p]
+    L.mk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.mk_comm_reduce_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.mk_comm_destroy.argtypes = [C.c_void_p]
     L.mk_scan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_uint64, C.POINTER(C.c_uint64)]
     L.mk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
@@ -280,13 +302,20 @@ class Matcher:
     """The matcher bundle the reference drivers hold (src/cmd_extract.rs:259): construction
     applies the reference's algorithm-selection rule; scans run on the GPU."""
 
-    def __init__(self, patterns, algo=MK_ALGO_AUTO, q=0, case_insensitive=False, device=0):
+    def __init__(self, patterns, algo=MK_ALGO_AUTO, q=0, case_insensitive=False, device=0, options=None):
+        """options: None or a MatcherOptions / dict(force_stride=..., force_global_filter=...,
+        gbloom_log2_blocks=...) -> mk_matcher_create_ex"""
         self.patterns = [p.encode() if isinstance(p, str) else bytes(p) for p in patterns]
         data, off = pack_list(self.patterns)
         self._h = C.c_void_p()
         flags = MK_FLAG_ASCII_CASE_INSENSITIVE if case_insensitive else 0
-        _check(load().mk_matcher_create(data.ctypes.data, off.ctypes.data, len(self.patterns), algo, q, flags, device,
-                                        C.byref(self._h)))
+        if options is None:
+            _check(load().mk_matcher_create(data.ctypes.data, off.ctypes.data, len(self.patterns), algo, q, flags,
+                                            device, C.byref(self._h)))
+        else:
+            opt = options if isinstance(options, MatcherOptions) else MatcherOptions(**options)
+            _check(load().mk_matcher_create_ex(data.ctypes.data, off.ctypes.data, len(self.patterns), algo, q, flags,
+                                               device, C.byref(opt), C.byref(self._h)))
         self.device = device
 
     def close(self):
@@ -439,6 +468,18 @@ class Matcher:
                 continue
             _check(rc)
             return out.value
+
+
+def reduce_counters(matchers, d_counter_ptrs, length):
+    """mk_reduce_counters: in-place RCCL all-reduce (sum) of one device counter vector per handle
+    (single process, one handle per GPU; handles sharing a device are pre-summed there).
+    d_counter_ptrs: device addresses (ints).  Returns the sum as a numpy uint64 array."""
+    n = len(matchers)
+    hs = (C.c_void_p * n)(*[m.handle for m in matchers])
+    ps = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_counter_ptrs])
+    out = np.zeros(length, dtype=np.uint64)
+    _check(load().mk_reduce_counters(hs, n, ps, length, out.ctypes.data))
+    return out
 
 
 # ------------------------------------------------------------------ reference-shaped single matchers

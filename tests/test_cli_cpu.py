@@ -61,3 +61,62 @@ def test_log_flag_conflicts(golden):
     assert code == 1 and b"No k-mers found" in err
     code, _, err = rc("extract", "-i", fa, "-f", "/nonexistent/kmers.txt", "-o", "x")
     assert code == 1 and b"File not found." in err
+
+
+def test_clustered_short_flags_parse_like_clap(golden):
+    """-rl, -vI, -Sl: combined short flags (clap accepts them; scripts written for the reference use them)"""
+    fa = os.path.join(golden, "fixtures/input/simple.fasta")
+    # parsing succeeds and the run gets as far as the semantic checks / the device
+    code, _, err = rc("extract", "-i", fa, "-s", "A", "-rl", "-j")
+    assert code == 1 and b"Cannot use both -l/--out-log and -j/--json-log" in err
+    code, _, err = rc("extract", "-i", fa, "-s", "A", "-rc")
+    assert code == 2 and b"--canonical" in err                               # the group check sees both flags
+    assert rc("extract", "-i", fa, "-s", "A", "-rq")[0] == 2                 # -q still needs its value
+    code, _, err = rc("extract", "-i", fa, "-s", "A", "-vIq5")
+    assert code in (0, 1) and b"unexpected" not in err                       # parsed (q takes '5'); past clap: runs or fails on the device
+    assert rc("extract", "-i", fa, "-s", "A", "-rx")[0] == 2                 # unknown flag inside a cluster
+
+
+def test_bz2_xz_zstd_decoders(tmp_path, golden):
+    """needletail reads .gz/.bz2/.xz (zstd with the same feature); the CLI binds libbz2 / liblzma /
+    libzstd at run time.  Harness around the CLI's decoder file: reference samples, multi-stream
+    bzip2, multi-MB inputs, truncated inputs are errors."""
+    import bz2
+    import ctypes
+    import lzma
+    exe = str(tmp_path / "dz")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "merkurio_amd/csrc/cli"), "-o", exe,
+                    os.path.join(ROOT, "tests/helpers/decompress_harness.cpp"),
+                    os.path.join(ROOT, "merkurio_amd/csrc/cli/decompress.cpp"), "-ldl"], check=True)
+
+    def fnv(b):
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%x" % h
+
+    plain = open(os.path.join(golden, "data/sample.fasta"), "rb").read()
+    big = plain * 300
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(big))
+    buf = ctypes.create_string_buffer(cap)
+    n_zs = z.ZSTD_compress(buf, cap, big, len(big), 3)
+    zs = buf.raw[:n_zs]
+    files = {"two.bz2": bz2.compress(big[:1000]) + bz2.compress(big[1000:]), "big.xz": lzma.compress(big), "big.zst": zs,
+             "trunc.bz2": bz2.compress(big)[:-40], "trunc.xz": lzma.compress(big)[:-40], "trunc.zst": zs[:-40]}
+    for name, data in files.items():
+        open(tmp_path / name, "wb").write(data)
+    args = [os.path.join(golden, "data/sample.fasta.bz2"), os.path.join(golden, "data/sample.fasta.xz")] + \
+           [str(tmp_path / n) for n in files]
+    out = subprocess.run([exe, *args], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == 8
+    for line in out[:2]:
+        assert f"1 {len(plain)} bytes hash {fnv(plain)}" in line, line
+    for line in out[2:5]:
+        assert f"1 {len(big)} bytes hash {fnv(big)}" in line, line
+    for line in out[5:]:
+        assert "error Error while decompressing" in line, line

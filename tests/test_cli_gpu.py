@@ -249,3 +249,132 @@ def test_cli_errors(golden, tmp_path):
     # -S with a log on stdout is fine, and -v is reported in the header line
     p = run(["extract", "-i", os.path.join(fx, "simple.fasta"), "-s", "ACG", "-S", "-l", "-v"])
     assert b"#Searching for 1 pattern (inverted matching)\n" in p.stdout and b"simple.fasta\tseq1\tACG\t0\n" in p.stdout
+
+
+def test_compressed_inputs_bz2_xz_zstd(golden, tmp_path):
+    """the reference reads .gz / .bz2 / .xz through needletail (Cargo.toml:26, helpers.rs:48-68,
+    tests/data/sample.fasta.{gz,bz2,xz}); zstd rides on the same feature.  Every compression of
+    the same file must extract byte-identically to the plain file, with the uncompressed type as
+    the output extension (identify_uncompressed_type)."""
+    import ctypes
+    data = os.path.join(golden, "data")
+    plain = open(os.path.join(data, "sample.fasta"), "rb").read()
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(plain))
+    buf = ctypes.create_string_buffer(cap)
+    n_zs = z.ZSTD_compress(buf, cap, plain, len(plain), 3)
+    (tmp_path / "sample.fasta.zst").write_bytes(buf.raw[:n_zs])
+    outs = {}
+    for name, src in (("plain", os.path.join(data, "sample.fasta")), ("gz", os.path.join(data, "sample.fasta.gz")),
+                      ("bz2", os.path.join(data, "sample.fasta.bz2")), ("xz", os.path.join(data, "sample.fasta.xz")),
+                      ("zst", str(tmp_path / "sample.fasta.zst"))):
+        o = tmp_path / f"o_{name}"
+        run(["extract", "-i", src, "-f", os.path.join(data, "kmers.txt"), "-o", str(o), "-l", str(tmp_path / f"{name}.log")])
+        rows = [ln.split(b"\t", 1)[1] for ln in log_body(tmp_path / f"{name}.log").split(b"\n") if ln and not ln.startswith(b"#")]
+        outs[name] = ((tmp_path / f"o_{name}.fasta").read_bytes(), rows)
+    assert len(outs["plain"][0]) > 0 and len(outs["plain"][1]) > 0
+    for name in ("gz", "bz2", "xz", "zst"):
+        assert outs[name] == outs["plain"], name
+    (tmp_path / "broken.fasta.bz2").write_bytes(open(os.path.join(data, "sample.fasta.bz2"), "rb").read()[:-20])
+    p = run(["extract", "-i", str(tmp_path / "broken.fasta.bz2"), "-s", "ACG"], check=False)
+    assert p.returncode == 1 and b"Error while decompressing" in p.stderr
+
+
+def test_gpus_2_equals_gpus_1(golden, tmp_path):
+    """--gpus N: contiguous record ranges on N handles (both on device 0 on a 1-GPU box), outputs in
+    device order, counters summed with mk_reduce_counters (RCCL): byte-equal to --gpus 1 for the paired
+    fixture and the workflow goldens, extract and tag, text + JSON logs."""
+    fx = os.path.join(golden, "fixtures")
+    wf = os.path.join(golden, "example-workflow")
+    cases = {
+        "paired": ["extract", "-i", os.path.join(fx, "input/paired-1.fastq"), "-2", os.path.join(fx, "input/paired-2.fastq"), "-s", "CTT"],
+        "workflow": ["extract", "-i", os.path.join(wf, "data/mutant_R1.subset.fastq.gz"), "-2",
+                     os.path.join(wf, "data/mutant_R2.subset.fastq.gz"), "-f", os.path.join(wf, "significant_kmers.txt"), "-r"],
+        "single-inv": ["extract", "-i", os.path.join(fx, "input/simple.fasta"), "-r", "-s", "ACG", "-v"],
+    }
+    for name, base in cases.items():
+        res = {}
+        for g in (1, 2, 3):
+            d = tmp_path / f"{name}_{g}"
+            d.mkdir()
+            run(base + ["-o", str(d / "out"), "-l", str(d / "x.log"), "-j", str(d / "x.json"), "--gpus", str(g), "--batch-mb", "1"])
+            files = sorted(f for f in os.listdir(d) if f.startswith("out"))
+            j = json.load(open(d / "x.json"))
+            res[g] = ([(f, (d / f).read_bytes()) for f in files], log_body(d / "x.log"), j["matching_records"], j["pattern_hit_counts"],
+                      j["summary_statistics"], j.get("paired_end_reads_statistics"))
+        assert res[1] == res[2] == res[3], name
+        assert len(res[1][0]) >= 1 and len(res[1][2]) > 0
+    # goldens still hold with two handles
+    d = tmp_path / "paired_2"
+    for k in (1, 2):
+        assert (d / f"out_{k}.fastq").read_bytes() == open(os.path.join(fx, f"extract/paired_{k}.extracted.fastq"), "rb").read()
+    assert log_body(d / "x.log") == log_body(os.path.join(fx, "extract/paired.log"))
+    # tag: workflow SAM (48 records, 24 hit) and the BAM fixture
+    tag_cases = {
+        "wf": ["tag", "-i", os.path.join(wf, "output/mutant_extracted.sorted.sam"), "-f", os.path.join(wf, "significant_kmers.txt"), "-r"],
+        "bam-m": ["tag", "-i", os.path.join(fx, "input/simple.bam"), "-s", "CTC", "-r", "-m"],
+    }
+    for name, base in tag_cases.items():
+        res = {}
+        for g in (1, 2):
+            d = tmp_path / f"tag_{name}_{g}"
+            d.mkdir()
+            run(base + ["-o", str(d / "o.sam"), "-l", str(d / "x.log"), "-j", str(d / "x.json"), "--gpus", str(g)])
+            j = json.load(open(d / "x.json"))
+            res[g] = (sam_without_own_pg(d / "o.sam"), open(d / "x.log", "rb").read().split(b"\n", 5)[5], j["matching_records"],
+                      j["pattern_hit_counts"], j["summary_statistics"])
+        assert res[1] == res[2], name
+    assert sam_without_own_pg(tmp_path / "tag_wf_2" / "o.sam") == \
+        sam_without_own_pg(os.path.join(wf, "output/mutant_extracted.sorted.tagged.sam"))
+
+
+def test_tag_is_batched(tmp_path):
+    """tag scans, tags and writes a slab of records at a time (--batch-mb): many small batches must
+    give the same bytes as one big batch, SAM and BAM output, with and without -m"""
+    import random
+    rnd = random.Random(5)
+    kmers = ["".join(rnd.choice("ACGT") for _ in range(31)) for _ in range(200)]
+    lines = []
+    for i in range(40000):
+        s = "".join(rnd.choice("ACGTacgt" if i % 50 == 0 else "ACGT") for _ in range(rnd.choice((50, 150))))
+        if i % 4 == 0:
+            k = rnd.choice(kmers)
+            o = rnd.randrange(len(s) - 31)
+            s = s[:o] + k + s[o + 31:]
+        extra = "\tkm:Z:OLD" if i % 1000 == 0 else ""
+        lines.append(f"r{i}\t4\t*\t0\t0\t*\t*\t0\t0\t{s}\t{'I' * len(s)}{extra}\n")
+    (tmp_path / "in.sam").write_text("@HD\tVN:1.6\n" + "".join(lines))
+    (tmp_path / "k.txt").write_text("\n".join(kmers) + "\n")
+    outs = {}
+    for mb in ("1", "512"):
+        for extra in ([], ["-m"]):
+            o = tmp_path / f"o_{mb}_{len(extra)}.sam"
+            run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(o), "-l", str(tmp_path / "x.log"),
+                 "--batch-mb", mb, *extra])
+            outs[(mb, len(extra))] = (sam_without_own_pg(o), open(tmp_path / "x.log", "rb").read().split(b"\n", 5)[5])
+    assert outs[("1", 0)] == outs[("512", 0)] and outs[("1", 1)] == outs[("512", 1)]
+    kept = [ln for ln in outs[("1", 1)][0] if ln and not ln.startswith(b"@")]
+    assert 9000 < len(kept) < 40000 and all(b"\tkm:Z:" in ln for ln in kept)
+    assert any(ln.endswith(b",OLD") or b",OLD," in ln or b"km:Z:OLD" in ln for ln in outs[("1", 0)][0])
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "a.bam"), "--batch-mb", "1"])
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "b.bam"), "--batch-mb", "512"])
+    import gzip
+    a, b = (gzip.decompress(open(tmp_path / f, "rb").read()).split(b"\tVN:1.0.0\n", 1)[1] for f in ("a.bam", "b.bam"))
+    assert a == b and len(a) > 40000 * 100  # everything after the @PG line: reference dictionary + records
+
+
+def test_crlf_records_keep_their_line_ending(tmp_path):
+    """needletail writes a record with the line ending it detected for that record
+    (record.write(&mut writer, None), src/cmd_extract.rs:403): CRLF in, CRLF out -- FASTA (wrapped) and FASTQ"""
+    fa = b">s1 first\r\nACGTACGTAC\r\nGGGTTTACGA\r\n>s2\r\nTTTTTTTTTT\r\n>s3 unix\nACGGGGTTTA\nCC\n"
+    (tmp_path / "crlf.fasta").write_bytes(fa)
+    run(["extract", "-i", str(tmp_path / "crlf.fasta"), "-s", "GGGTTTA", "-o", str(tmp_path / "o")])
+    assert (tmp_path / "o.fasta").read_bytes() == b">s1 first\r\nACGTACGTAC\r\nGGGTTTACGA\r\n>s3 unix\nACGGGGTTTA\nCC\n"
+    fq = b"@q1\r\nACGTGGGTTTA\r\n+\r\nIIIIIIIIIII\r\n@q2\r\nAAAAAAAAAAA\r\n+\r\nIIIIIIIIIII\r\n"
+    (tmp_path / "crlf.fastq").write_bytes(fq)
+    run(["extract", "-i", str(tmp_path / "crlf.fastq"), "-s", "GGGTTTA", "-o", str(tmp_path / "q")])
+    assert (tmp_path / "q.fastq").read_bytes() == b"@q1\r\nACGTGGGTTTA\r\n+\r\nIIIIIIIIIII\r\n"

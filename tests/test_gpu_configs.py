@@ -82,15 +82,13 @@ def test_config4_scaled_tag(mk):
 
 
 @pytest.mark.parametrize("stride", [None, 4])
-def test_config5_large_pattern_set(mk, stride, monkeypatch):
+def test_config5_large_pattern_set(mk, stride):
     """500 k 21-mers: the set no longer fits the LDS filter; the filter moves to global memory
     (stride 8, 14-base q-grams, 4 MiB: the largest L2-resident geometry; stride 4 is the
     18-base alternative).  Correctness must hold regardless"""
-    if stride:
-        monkeypatch.setenv("MERKURIO_FORCE_STRIDE", str(stride))
     patterns = mk.parse_pattern_list(kmer_seq=_kmers(500_000, 21, 5))
     recs = _reads(20_000, 250, 51, plant=patterns, every=10)
-    m = mk.Matcher(patterns)
+    m = mk.Matcher(patterns, options=dict(force_stride=stride) if stride else None)
     assert m.use_ac and m.filter_mode()["in_lds"] is False
     if stride is None:
         assert m.filter_info()["stride"] == 8 and m.filter_info()["q_gram"] == 14
@@ -102,16 +100,14 @@ def test_config5_large_pattern_set(mk, stride, monkeypatch):
 
 
 @pytest.mark.parametrize("stride", [1, 2, 4, 8, 16])
-def test_global_filter_variants(mk, stride, monkeypatch):
+def test_global_filter_variants(mk, stride):
     """every kernel variant of the global-memory filter mode (forced on a small set)"""
-    monkeypatch.setenv("MERKURIO_FORCE_GLOBAL_FILTER", "1")
-    monkeypatch.setenv("MERKURIO_FORCE_STRIDE", str(stride))
     for k, n in ((31, 3000), (21, 2000), (16 + stride - 1, 500)):
         if stride > k:
             continue
         patterns = mk.parse_pattern_list(kmer_seq=_kmers(n, k, 60 + stride))
         recs = _reads(4000, 150, 70 + stride, plant=patterns, every=7)
-        m = mk.Matcher(patterns)
+        m = mk.Matcher(patterns, options=dict(force_stride=stride, force_global_filter=True))
         assert m.filter_mode()["in_lds"] is False and m.filter_info()["stride"] == stride
         om = ob.Matcher(patterns, True, 0, False)
         assert m.extract_single(recs, logging=True) == ob.extract_single(om, recs, logging=True)

@@ -47,8 +47,8 @@ def _case(rnd):
 
 
 # longer campaigns: MERKURIO_FUZZ_SEEDS=200 MERKURIO_FUZZ_BASE=5000 python -m pytest tests/test_gpu_fuzz.py -m gpu
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MERKURIO_FUZZ_SEEDS", "8"))))
-def test_fuzz_vs_oracle(mk, seed, monkeypatch):
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MERKURIO_FUZZ_SEEDS", "32"))))
+def test_fuzz_vs_oracle(mk, seed):
     rnd = random.Random(int(os.environ.get("MERKURIO_FUZZ_BASE", "1000")) + seed)
     for it in range(60):
         raw, recs = _case(rnd)
@@ -65,11 +65,8 @@ def test_fuzz_vs_oracle(mk, seed, monkeypatch):
             algo = mk.MK_ALGO_AC
         elif choice < 0.4 and max_len <= 64 and not ci:
             algo, q = mk.MK_ALGO_BNDMQ, rnd.choice([0, 1])
-        if rnd.random() < 0.15:
-            monkeypatch.setenv("MERKURIO_FORCE_GLOBAL_FILTER", "1")
-        else:
-            monkeypatch.delenv("MERKURIO_FORCE_GLOBAL_FILTER", raising=False)
-        m = mk.Matcher(patterns, algo=algo, q=q, case_insensitive=ci)
+        options = dict(force_global_filter=True) if rnd.random() < 0.15 else None
+        m = mk.Matcher(patterns, algo=algo, q=q, case_insensitive=ci, options=options)
         use_ac = m.use_ac
         assert use_ac == (True if (ci or algo == mk.MK_ALGO_AC) else False if algo == mk.MK_ALGO_BNDMQ
                           else ob.select_aho_corasick(ci, False, False, patterns))
@@ -82,6 +79,10 @@ def test_fuzz_vs_oracle(mk, seed, monkeypatch):
         if len(recs) >= 2:
             h = len(recs) // 2
             assert m.extract_paired(recs[:h], recs[h:2 * h], logging=True) == ob.extract_paired(om, recs[:h], recs[h:2 * h], logging=True)
-        keep, rows, c, found = m.tag_records(recs, logging=logging, filter_matching=rnd.random() < 0.5)
-        keep_o, rows_o, c_o, found_o = ob.tag_records(om, recs, logging=logging, filter_matching=False)
-        assert rows == rows_o and found == [sorted(set(f)) for f in found_o]
+        # tag: the keep/drop rule (-m / -v, src/cmd_tag.rs:457-467) with the same flags on both sides
+        fm = rnd.random() < 0.5
+        inv = (not fm) and rnd.random() < 0.5
+        keep, rows, c, found = m.tag_records(recs, logging=logging, filter_matching=fm, invert=inv)
+        keep_o, rows_o, c_o, found_o = ob.tag_records(om, recs, logging=logging, filter_matching=fm, invert=inv)
+        assert keep == keep_o and rows == rows_o and c == c_o, (seed, it, fm, inv)
+        assert found == [sorted(set(f)) for f in found_o]

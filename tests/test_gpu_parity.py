@@ -274,12 +274,11 @@ def test_scan_matches_oracle(mk, case):
 
 
 @pytest.mark.parametrize("stride", [1, 2, 4, 8, 16])
-def test_all_strides_agree(mk, stride, monkeypatch):
+def test_all_strides_agree(mk, stride):
     """every kernel variant (sampling stride) yields the same result set"""
-    monkeypatch.setenv("MERKURIO_FORCE_STRIDE", str(stride))
     raw, recs = _make_case(77, 500, [31], 1500, 150)
     patterns = mk.parse_pattern_list(kmer_seq=raw, reverse_complement=True)
-    m = mk.Matcher(patterns)
+    m = mk.Matcher(patterns, options=dict(force_stride=stride))
     assert m.filter_info()["stride"] == stride
     exp, _, _ = _oracle_hits(patterns, True, recs)
     flags, hits = m.scan(recs)
@@ -287,7 +286,7 @@ def test_all_strides_agree(mk, stride, monkeypatch):
     # narrow keys (q <= 16) too
     raw2, recs2 = _make_case(78, 100, [16 + stride - 1], 800, 100)
     p2 = mk.parse_pattern_list(kmer_seq=raw2)
-    m2 = mk.Matcher(p2)
+    m2 = mk.Matcher(p2, options=dict(force_stride=stride))
     assert m2.filter_info()["q_gram"] == 16
     exp2, _, _ = _oracle_hits(p2, True, recs2)
     _, h2 = m2.scan(recs2)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = mk.load()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.mk_abi_version() == 1
+    assert L.mk_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -95,3 +95,48 @@ def test_pattern_list_matches_oracle_and_kats(golden):
         assert mk.reverse_complement(s) == ob.reverse_complement(s) and mk.canonical(s) == ob.canonical(s)
     txt = b"AC\n   \n#x\n>y\n  #notcomment\nGT\r\n\nTT"
     assert mk.read_kmers_from_text(txt) == ob.read_kmers_from_text(txt)[1]
+
+
+def test_options_are_validated_before_device_use():
+    # mk_matcher_create_ex: explicit options struct instead of environment variables
+    for bad in (dict(force_stride=3), dict(gbloom_log2_blocks=40)):
+        with pytest.raises(mk.MerkurioError) as e:
+            mk.Matcher([b"ACGTACGTACGTACGTACGTA"] * 1, options=bad)
+        assert e.value.code == mk.MK_E_INVALID_ARG
+    opt = mk.MatcherOptions()
+    opt.struct_size = 2
+    with pytest.raises(mk.MerkurioError) as e:
+        mk.Matcher([b"ACGT"], options=opt)
+    assert e.value.code == mk.MK_E_INVALID_ARG
+
+
+def test_product_reads_no_environment_variables():
+    # tuning hooks live in mk_matcher_options; a stray variable must not change geometry
+    import subprocess
+    out = subprocess.run(["strings", mk.lib_path()], capture_output=True, text=True).stdout
+    assert "MERKURIO_" not in out
+
+
+def test_allocation_failure_is_an_error_code_not_an_abort(tmp_path):
+    """bad_alloc inside the library comes back as MK_E_NOMEM across the C ABI (a child process with
+    a small address-space limit builds a pattern list that needs several GB)."""
+    import subprocess
+    import sys
+    code = f"""
+import ctypes as C, resource, sys
+import numpy as np
+sys.path.insert(0, {ROOT!r})
+from merkurio_amd import native as mk
+L = mk.load()
+n = 6_000_000
+data = np.frombuffer(np.random.default_rng(1).integers(65, 69, size=n * 31, dtype=np.uint8).tobytes(), dtype=np.uint8)
+off = (np.arange(n + 1, dtype=np.uint64) * 31).astype(np.uint32)
+soft = 1_200 << 20   # the vector<string> + copies of 6 M patterns (+ reverse complements) need > 1.2 GB
+resource.setrlimit(resource.RLIMIT_AS, (soft, soft))
+pb, po, cnt = C.c_void_p(), C.c_void_p(), C.c_uint32()
+rc = L.mk_parse_pattern_list(data.ctypes.data, off.ctypes.data, n, 1, 0, 0, 0, C.byref(pb), C.byref(po), C.byref(cnt))
+print("rc", rc, L.mk_last_error().decode())
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"rc {mk.MK_E_NOMEM} " in r.stdout, r.stdout
