@@ -114,6 +114,8 @@ def parse_args(argv=None):
     ap.add_argument("--force-stride", type=int, default=0)
     ap.add_argument("--force-global-filter", action="store_true")
     ap.add_argument("--gbloom-log2-blocks", type=int, default=0)
+    ap.add_argument("--tile-run", type=int, default=0)
+    ap.add_argument("--gbloom-kib", type=int, default=0)
     return ap.parse_args(argv)
 
 
@@ -174,9 +176,9 @@ def main():
     if args.rc:
         patterns = mk.parse_pattern_list(kmer_seq=patterns, reverse_complement=True)
     options = None
-    if args.force_stride or args.force_global_filter or args.gbloom_log2_blocks:
+    if args.force_stride or args.force_global_filter or args.gbloom_log2_blocks or args.tile_run or args.gbloom_kib:
         options = dict(force_stride=args.force_stride, force_global_filter=args.force_global_filter,
-                       gbloom_log2_blocks=args.gbloom_log2_blocks)
+                       gbloom_log2_blocks=args.gbloom_log2_blocks, tile_run=args.tile_run, gbloom_kib=args.gbloom_kib)
     m = mk.Matcher(patterns, device=dev_index, options=options)
     assert m.use_ac == mk.recommend_aho_corasick(patterns)
     lib = mk.load()
@@ -275,6 +277,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if args.warmup and not args.no_counters:
+        # feed the hit density the warm-up steps saw back to the library (it picks cacheable stream
+        # loads for hit-dense text); a host that scans batch after batch does the same with mk_scan_batch
+        w = d_cnt.cpu().numpy()[len(patterns):]
+        if w[mk.MK_SUM_RECORDS]:
+            mk._check(lib.mk_matcher_hint_hit_density(m.handle, int(w[mk.MK_SUM_RECORDS_HIT]) * 1000 // int(w[mk.MK_SUM_RECORDS])))
     d_cnt.zero_()
     m.enable_timing(args.steps * n_mates)
     barrier()

@@ -67,7 +67,7 @@ typedef struct mk_matcher mk_matcher;
  * `pos` (0-based) of record `rec`.  == (mat.pattern().as_usize(), mat.start()) of
  * src/cmd_extract.rs:341-342 and the `o` of BNDMq::find_iter (src/cmd_extract.rs:367).
  * Limits of this build: a single record shorter than 4 GiB (`pos` is 32 bits; a batch may hold
- * any number of bytes and records), at most 2^28 - 1 patterns. */
+ * any number of bytes and records), at most 2^27 - 2 patterns. */
 typedef struct {
     uint64_t rec;
     uint32_t pat;
@@ -148,6 +148,8 @@ typedef struct {
     uint32_t force_stride;        /* 0 = geometry rule; else sampling stride 1, 2, 4, 8 or 16 */
     uint32_t force_global_filter; /* 1 = level-1 filter in global memory even for small sets */
     uint32_t gbloom_log2_blocks;  /* 0 = rule; else log2 of the number of 64-bit blocks of a global filter */
+    uint32_t tile_run;            /* 0 = rule; else 1..8 consecutive 31 KiB tiles a scan wave takes before it jumps ahead */
+    uint32_t gbloom_kib;          /* 0 = rule; else size of a global filter in KiB (any size, overrides gbloom_log2_blocks) */
 } mk_matcher_options;
 int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
                          uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out);
@@ -192,7 +194,9 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
  * back); in MK_MODE_HITS *d_n_hits counts every occurrence even beyond hits_cap (0 in MK_MODE_ANY).
  * d_counters (may be NULL): uint64[n_pat + MK_NUM_SUMMARY] accumulated (+=) by the scan:
  *   [0, n_pat)            occurrences per pattern (the AC meaning of pattern_hit_counts,
- *                         src/cmd_extract.rs:353)
+ *                         src/cmd_extract.rs:353).  MK_MODE_HITS only, counted from the stored tuples
+ *                         (all of them unless *d_n_hits exceeds hits_cap); MK_MODE_ANY leaves these
+ *                         entries untouched -- the reference's no-logging path counts nothing either
  *   [n_pat + MK_SUM_*]    see below
  * It is the vector a multi-GPU host sums across ranks (RCCL allReduce) at the end of a job.
  * ---------------------------------------------------------------------------------- */
@@ -206,6 +210,12 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
 int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const void *d_seq_off, uint64_t n_rec,
                    uint32_t mode, void *d_rec_flags, void *d_hits, uint64_t hits_cap, void *d_n_hits,
                    void *d_counters, void *stream);
+
+/* Performance hint for mk_scan_device (never changes results): how many of 1000 records the caller
+ * expects to contain a pattern.  Dense text (>= 150) is streamed with cacheable loads, because the
+ * exact verification re-reads every hit window; sparse text with non-temporal loads.  mk_scan_batch
+ * and the driver-loop entry points maintain the value themselves from the batch they have just scanned. */
+int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000);
 
 /* Sort hits (host memory) into the reference's emission order for this matcher. */
 int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);

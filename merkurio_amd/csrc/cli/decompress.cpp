@@ -19,8 +19,13 @@ void *open_any(std::initializer_list<const char *> names) {
     return nullptr;
 }
 
+const std::string *g_path = nullptr;  // the file being inflated (error text of the memory check)
 void grow(std::vector<char> &out, size_t used) {
-    if (out.size() - used < (1u << 16)) out.resize(std::max<size_t>(out.size() * 2, 1u << 22));
+    if (out.size() - used < (1u << 16)) {
+        const size_t want = std::max<size_t>(out.size() * 2, 1u << 22);
+        if (g_path && want > (1u << 30)) require_host_memory(out.size() + want, *g_path);
+        out.resize(want);
+    }
 }
 
 // ---- bzip2 (bzlib.h) ------------------------------------------------------------------------------
@@ -170,6 +175,7 @@ void inflate_zstd(const std::string &path, const unsigned char *d, size_t n, std
 }  // namespace
 
 bool inflate_by_magic(const std::string &path, const unsigned char *d, size_t n, std::vector<char> &out) {
+    g_path = &path;
     if (n >= 3 && !memcmp(d, "BZh", 3)) {
         inflate_bz2(path, d, n, out);
         return true;

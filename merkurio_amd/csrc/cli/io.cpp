@@ -46,6 +46,41 @@ unsigned io_threads() {
     return cached;
 }
 
+// Host memory this process may still take: MemAvailable, capped by the cgroup limit.  0 = unknown.
+static uint64_t host_memory_available() {
+    uint64_t avail = 0;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof(line), f)) {
+            unsigned long long kb = 0;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) avail = (uint64_t)kb << 10;
+        }
+        fclose(f);
+    }
+    unsigned long long lim = 0, cur = 0;
+    FILE *fl = fopen("/sys/fs/cgroup/memory.max", "r"), *fc = fopen("/sys/fs/cgroup/memory.current", "r");
+    if (fl && fc && fscanf(fl, "%llu", &lim) == 1 && fscanf(fc, "%llu", &cur) == 1 && lim > cur) {
+        const uint64_t room = lim - cur;
+        if (avail == 0 || room < avail) avail = room;
+    }
+    if (fl) fclose(fl);
+    if (fc) fclose(fc);
+    return avail;
+}
+
+// This build holds a decompressed input (and its record index) in host memory; the reference streams
+// it.  Fail early and say so instead of being killed by the kernel half way through.
+void require_host_memory(uint64_t need, const std::string &path) {
+    const uint64_t avail = host_memory_available();
+    if (avail == 0 || need <= avail) return;
+    char buf[256];
+    snprintf(buf, sizeof(buf), " needs about %.1f GiB of host memory once decompressed, %.1f GiB are available. ",
+             need / 1073741824.0, avail / 1073741824.0);
+    bail(path + buf +
+         "This build keeps a compressed input in memory while it is processed (plain-text inputs are memory-mapped and do not "
+         "count): decompress it first, split it, or run on a host with more memory.");
+}
+
 // BGZF = a series of gzip members, each with the extra subfield 'B','C' holding the member's
 // size (SAM spec 4.1).  Walk the member headers, size the output from the ISIZE trailers, then
 // inflate the members independently.  Returns false (out untouched) if the file is not BGZF all
@@ -105,6 +140,7 @@ static bool inflate_bgzf_parallel(const std::string &path, std::vector<char> &ou
         munmap(m, n);
         return false;
     }
+    require_host_memory(total + total / 8, path);  // + record index
     out.resize(total);
     const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), mem.size() / 16 + 1));
     std::vector<int> bad(T, 0);
@@ -167,6 +203,7 @@ std::vector<char> read_file_maybe_gz(const std::string &path) {
     size_t n = 0;
     for (;;) {
         if (n == cap) {
+            require_host_memory(cap * 2, path);  // the buffer doubles: both copies exist for a moment
             cap *= 2;
             out.resize(cap);
         }

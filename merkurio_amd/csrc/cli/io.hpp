@@ -40,6 +40,8 @@ void run_threads(size_t T, F fn) {
 // whole file into memory; transparently inflates gzip (magic 1f 8b; BGZF members in parallel) and,
 // like needletail's `compression` feature, bzip2 / xz / zstd (decompress.cpp)
 std::vector<char> read_file_maybe_gz(const std::string &path);
+// raises cli::Error if `need` bytes of host memory are not available (decompressed inputs are held in memory)
+void require_host_memory(uint64_t need, const std::string &path);
 // bzip2 / xz / zstd by magic bytes through the system's runtime libraries (bound with dlopen):
 // false = none of the three; raises cli::Error on corrupt input or a missing library
 bool inflate_by_magic(const std::string &path, const unsigned char *data, size_t n, std::vector<char> &out);

@@ -79,10 +79,16 @@ MK_HD uint32_t bloom_bit_c(uint32_t h) { return (h >> 17) & 31u; }
 // Global-memory variant of the filter for pattern sets too large for a useful 128 KiB LDS
 // image (more than ~96 k filter entries even at stride 1): the same 3-bit / 64-bit blocks,
 // but 2^g_log2 of them in HBM (resident in L2 / Infinity Cache), sized ~32 bits per entry.
-// Block index = high bits of h, bit positions from a second multiply so that they do not
+// Block index = scaled high bits of h, bit positions from a second multiply so that they do not
 // correlate with the block index.
-MK_HD uint32_t gbloom_block(uint32_t h, uint32_t block_mask) { return (h >> 5) & block_mask; }
-MK_HD uint32_t gbloom_bits(uint32_t h) { return h * 0x9E3779B1u; }  // a,b,c = top three 5-bit groups
+// block = floor(h * n_blocks / 2^32): one v_mul_hi, and the filter need not be a power of two in size
+// (the fastest size is "as large as still stays in the 4 MiB L2 next to the text stream": r02_c5_*)
+MK_HD uint32_t gbloom_block(uint32_t h, uint32_t n_blocks) { return (uint32_t)(((uint64_t)h * n_blocks) >> 32); }
+MK_HD uint32_t gbloom_bits(uint32_t h) { return h * 0x9E3779B1u; }  // a,b,c,d = top four 5-bit groups
+// the global filter sets FOUR bits per key (a, d in the block's low word, b, c in its high word): at the
+// 6-8 bits per entry an L2-resident filter for millions of entries affords, that is a quarter fewer
+// false positives than three, and a false positive there is a random HBM read
+MK_HD uint32_t bloom_bit_d(uint32_t h) { return (h >> 12) & 31u; }
 
 // ---- context fingerprints (global-filter kernels with a compile-time q: gf_has_ctx) ---------------
 // With hundreds of thousands of patterns the sampled q-grams get short (500 k 21-mers: q = 14) and

@@ -103,9 +103,12 @@ static void choose_geometry(uint32_t lmin, uint64_t n_pat, const mk_matcher_opti
     // Filter size: measured with 500 k 21-mers (2 M entries, profiles/r01_gbloom_sweep.txt) a
     // 2 MiB image (8 entries per 64-bit block, 1.2 % of samples pass) is fastest because it
     // stays resident in the 4 MiB XCD L2; 8 MiB (0.09 % pass) is 1.8x slower.  ~8 entries/block.
-    uint64_t blocks = 1ull << 17;  // >= 1 MiB
-    while (blocks < n_pat * *S / 8 && blocks < (1ull << 25)) blocks <<= 1;
-    if (opt.gbloom_log2_blocks) blocks = 1ull << opt.gbloom_log2_blocks;  // tuning hook
+    // r02 (profiles/r02_c5_filter_size.txt, tools/probes/stream_policy.hip): next to the text stream the
+    // L2 serves ~208 G random reads/s from a table of up to 3 MiB, 176 G/s at 4 MiB, 105 G/s at 8 MiB;
+    // 8 bits per entry, at least 1 MiB, at most 3 MiB.
+    uint64_t blocks = std::min<uint64_t>(std::max<uint64_t>(n_pat * *S / 8, 1ull << 17), 3ull << 17);
+    if (opt.gbloom_log2_blocks) blocks = 1ull << opt.gbloom_log2_blocks;  // tuning hooks
+    if (opt.gbloom_kib) blocks = (uint64_t)opt.gbloom_kib * 128;
     *gblocks = (uint32_t)blocks;
 }
 
@@ -164,6 +167,8 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
             return fail(MK_E_INVALID_ARG, "force_stride %u: must be 0, 1, 2, 4, 8 or 16", fs);
         if (opt.gbloom_log2_blocks != 0 && (opt.gbloom_log2_blocks < 10 || opt.gbloom_log2_blocks > 25))
             return fail(MK_E_INVALID_ARG, "gbloom_log2_blocks %u out of range (10..25)", opt.gbloom_log2_blocks);
+        if (opt.tile_run > 8) return fail(MK_E_INVALID_ARG, "tile_run %u out of range (0..8)", opt.tile_run);
+        if (opt.gbloom_kib > (1u << 18)) return fail(MK_E_INVALID_ARG, "gbloom_kib %u out of range (<= 256 MiB)", opt.gbloom_kib);
     }
     MK_ABI_BEGIN
     if (n_pat == 0 || !pat_off || !pat_bytes) return fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
@@ -222,6 +227,7 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
         m->num_cus = prop.multiProcessorCount;
 
     m->uniform_len = (lmin == lmax) ? lmin : 0;
+    m->tile_run = opt.tile_run;
     // ---- compile the pattern set: Bloom filter + exact table
     choose_geometry(lmin, n_pat, opt, &m->q, &m->S, &m->gbloom_blocks);
     if (opt.force_stride && m->S != opt.force_stride)
@@ -235,7 +241,7 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     if (slots > (1ull << 27))  // bucket index has 26 bits
         return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", (unsigned long long)m->entries);
     m->table_slots = (uint32_t)slots;
-    const uint32_t gmask = m->gbloom_blocks ? m->gbloom_blocks - 1 : 0;
+    const uint32_t gmask = m->gbloom_blocks;  // number of blocks
     std::vector<uint32_t> bloom(m->gbloom_blocks ? (size_t)m->gbloom_blocks * 2 : (size_t)kBloomWords, 0);
     std::vector<TableEntry> table(slots);
     for (auto &e : table) {
@@ -255,7 +261,7 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
             if (m->gbloom_blocks) {
                 const size_t blk = (size_t)gbloom_block(h, gmask) * 2;
                 const uint32_t hb = gbloom_bits(h);
-                bloom[blk] |= 1u << bloom_bit_a(hb);
+                bloom[blk] |= (1u << bloom_bit_a(hb)) | (1u << bloom_bit_d(hb));
                 bloom[blk + 1] |= (1u << bloom_bit_b(hb)) | (1u << bloom_bit_c(hb));
             } else {
                 const uint32_t blk = bloom_block_byte(h) >> 2;  // index of the block's low word
@@ -354,7 +360,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t tile_bytes = (uint64_t)kTileChunks * kChunkBytes;
     const uint64_t n_tiles = (n_bytes + tile_bytes - 1) / tile_bytes;
     p.bloom = m->d_bloom;
-    p.gbloom_mask = m->gbloom_blocks ? m->gbloom_blocks - 1 : 0;
+    p.gbloom_blocks = m->gbloom_blocks;
     p.table = m->d_table;
     p.table_mask = m->table_slots / kBucketEntries - 1;  // bucket mask
     p.pat_bytes = m->d_pat_bytes;
@@ -376,19 +382,39 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
     p.stage = m->d_stage;
     p.rec_per_byte = (double)n_rec / (double)n_bytes;
+    // tiles a wave scans back to back before it jumps ahead by n_waves * run tiles: runs of 4 keep a wave
+    // inside one 2 MiB page for 124 KiB (-4 % on 15 GB batches, profiles/r02_tile_run.txt); small batches
+    // keep runs short so that every wave still gets tiles
+    const uint64_t tiles_per_wave = n_tiles / (blocks * waves_per_block);
+    p.tile_run = m->tile_run ? m->tile_run : tiles_per_wave >= 16 ? 4 : tiles_per_wave >= 8 ? 2 : 1;
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
     if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
-    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, (int)blocks, st);
+    // hit-dense text (tag on already extracted reads: every other record hits): level 3 re-reads each
+    // verified window, so the stream is read with cacheable loads and the re-read finds it in L2 / MALL
+    // (every read hitting: 8.6 -> 7.4 ms per 15 GB; sparse text is 5 % faster non-temporal; crossover at
+    // ~10-20 % of the records, profiles/r02_hitrate_sweep.txt)
+    constexpr uint32_t kDensePerMille = 150;
+    const bool plain_loads = m->hit_density_pm >= kDensePerMille;
+    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, plain_loads, (int)blocks, st);
     if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);
     if (slots) {
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));
         m->timed_launches++;
     }
-    if (d_counters) launch_count_flags(p, st);
+    if (d_counters) {
+        launch_count_flags(p, st);
+        if (mode == MK_MODE_HITS && p.hits && p.hits_cap) launch_hist_hits(p, m->num_cus, st);
+    }
     m->kernel_name = name;
     m->last_grid = (int)blocks;
     MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    m->hit_density_pm = records_hit_per_1000 > 1000 ? 1000 : records_hit_per_1000;
     return MK_OK;
 }
 
@@ -497,6 +523,11 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
         cap = found;  // device buffer was the limit, the caller's buffer is big enough: rescan
     }
     MK_HIP(hipMemcpy(rec_flags, m->d_flags, n_rec, hipMemcpyDeviceToHost));
+    {  // what this batch looked like steers the load flavour of the next one
+        uint64_t flagged = 0;
+        for (uint64_t i = 0; i < n_rec; ++i) flagged += rec_flags[i] != 0;
+        m->hit_density_pm = (uint32_t)(flagged * 1000 / n_rec);
+    }
     if (mode == MK_MODE_HITS) {
         if (n_hits) *n_hits = found;
         if (found > hits_cap)

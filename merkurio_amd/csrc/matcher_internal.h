@@ -23,6 +23,10 @@ struct mk_matcher {
     uint32_t table_slots = 0;
     uint32_t *d_bloom = nullptr;
     uint32_t gbloom_blocks = 0;  // > 0: filter lives in global memory (large pattern sets)
+    uint32_t tile_run = 0;       // 0 = rule (per scan, from the batch size); else forced by mk_matcher_options
+    // records with a hit per 1000 records, as last observed by mk_scan_batch or told by
+    // mk_matcher_hint_hit_density: >= kDensePerMille selects the plain-load kernel variant
+    uint32_t hit_density_pm = 0;
     mk::TableEntry *d_table = nullptr;
     uint8_t *d_pat_bytes = nullptr;
     uint32_t *d_pat_off = nullptr;

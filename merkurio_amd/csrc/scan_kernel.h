@@ -17,8 +17,8 @@ struct ScanParams {
     const uint64_t *rec_off;  // n_rec + 1
     uint64_t n_rec;
     // compiled pattern set
-    const uint32_t *bloom;    // LDS mode: kBloomWords words; global mode: 2 * (gbloom_mask + 1) words
-    uint32_t gbloom_mask;     // global mode: 64-bit-block index mask (0 = LDS mode)
+    const uint32_t *bloom;    // LDS mode: kBloomWords words; global mode: 2 * gbloom_blocks words
+    uint32_t gbloom_blocks;   // global mode: number of 64-bit filter blocks (0 = LDS mode)
     const TableEntry *table;  // (table_mask + 1) buckets of kBucketEntries entries
     uint32_t table_mask;      // bucket index mask
     const uint8_t *pat_bytes;
@@ -30,6 +30,7 @@ struct ScanParams {
     uint32_t case_insensitive;
     uint32_t uniform_len;  // > 0: every pattern has this length (pattern i starts at i * uniform_len)
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
+    uint32_t tile_run;    // consecutive tiles a wave takes before it jumps ahead (>= 1)
     // per-scan-wave staging of verified occurrences (EMIT kernels; kHitStage tuples each)
     mk_hit *stage;
     // outputs
@@ -42,15 +43,20 @@ struct ScanParams {
 
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
-const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
+// plain_loads: the stream is read with cacheable loads (hit-dense text); honoured by the k-mer-family
+// kernels of the LDS filter, ignored by the others.
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, bool plain_loads, int grid_blocks,
                         hipStream_t stream);
 
 // host-side launcher of one kernel variant; defined (explicitly instantiated) in scan_variants.hip
-template <int S, int QC, bool EMIT, bool GF>
+template <int S, int QC, bool EMIT, bool GF, bool NTL>
 void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream);
 
 // static LDS bytes of one scan workgroup (filter + candidate rings + pattern counters)
 uint32_t scan_lds_bytes();
+
+// counters[pat] += occurrences of pat among the stored tuples (hits[0 .. min(*n_hits, hits_cap)))
+void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t stream);
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

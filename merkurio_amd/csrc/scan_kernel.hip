@@ -48,6 +48,45 @@ void launch_count_flags(const ScanParams &p, hipStream_t st) {
                        p.n_rec, p.counters + p.n_pat + MK_SUM_RECORDS_HIT);
 }
 
+// ---- occurrences per pattern from the emitted tuples (MK_MODE_HITS with a counter vector) ------------
+// counters[pat] += 1 for every stored tuple.  Workgroups take slabs of >= 64 Ki tuples; a slab is
+// histogrammed in LDS (pattern sets up to 36 Ki patterns: 144 KiB of u32 bins) and flushed with one
+// atomic per non-empty bin, so a launch with few tuples costs a few microseconds and a launch where
+// every read hits (100 M tuples) reads 1.6 GB once.  Larger pattern sets go straight to global atomics
+// (their counters spread over megabytes: no hot line).
+constexpr uint32_t kHistLdsBins = 36864;
+__global__ __launch_bounds__(1024) void mk_hist_hits_kernel(const mk_hit *__restrict__ hits, const unsigned long long *__restrict__ n_hits,
+                                                            uint64_t cap, unsigned long long *__restrict__ counters, uint32_t n_pat) {
+    __shared__ uint32_t bins[kHistLdsBins];
+    const uint64_t n = std::min<uint64_t>(*n_hits, cap);
+    const uint64_t per = std::max<uint64_t>(65536, (n + gridDim.x - 1) / gridDim.x);
+    const uint64_t lo = (uint64_t)blockIdx.x * per;
+    if (lo >= n) return;  // block-uniform
+    const uint64_t hi = std::min(n, lo + per);
+    const bool in_lds = n_pat <= kHistLdsBins;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < n_pat; i += blockDim.x) bins[i] = 0;
+        __syncthreads();
+    }
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t pat = hits[i].pat;
+        if (pat >= n_pat) continue;
+        if (in_lds)
+            atomicAdd(&bins[pat], 1u);
+        else
+            atomicAdd(&counters[pat], 1ull);
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_pat; i += blockDim.x)
+            if (bins[i]) atomicAdd(&counters[i], (unsigned long long)bins[i]);
+    }
+}
+
+void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(mk_hist_hits_kernel, dim3(grid_blocks), dim3(1024), 0, st, p.hits, p.n_hits, p.hits_cap, p.counters, p.n_pat);
+}
+
 // dst[i] += src[i]: counter vectors of two handles that share a device (mk_reduce_counters)
 __global__ void mk_add_u64_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, size_t len) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
@@ -60,9 +99,9 @@ void launch_add_u64(unsigned long long *dst, const unsigned long long *src, size
 
 // the kernel variants are instantiated in groups by scan_variants.hip (one translation unit per
 // group, compiled in parallel); launch_variant<...> is the host-side launcher of one of them
-template <int S, int QC, bool EMIT, bool GF>
+template <int S, int QC, bool EMIT, bool GF, bool NTL = true>
 static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
-    launch_variant<S, QC, EMIT, GF>(p, grid, st);
+    launch_variant<S, QC, EMIT, GF, NTL>(p, grid, st);
     return name;
 }
 
@@ -70,7 +109,11 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
     return emit ? launch_one<S_, QC_, true, GF_>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true," #GF_ ">") \
                 : launch_one<S_, QC_, false, GF_>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false," #GF_ ">")
 
-const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int grid_blocks,
+#define MK_VARIANT_PLAIN(S_, QC_)                                                                                       \
+    return emit ? launch_one<S_, QC_, true, false, false>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,plain>") \
+                : launch_one<S_, QC_, false, false, false>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,plain>")
+
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, bool plain_loads, int grid_blocks,
                         hipStream_t stream) {
     if (global_filter) {  // large pattern sets: filter blocks in global memory
         if (S == 8 && p.q == 14) MK_VARIANT(8, 14, true);  // 21-mers
@@ -95,6 +138,12 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
     }
     // k-mer sizes with their own kernels (q fixed at compile time): the 31-mer family
     // (q = 32 - S) and the 21-mer family (q = 22 - S, S <= 4)
+    if (plain_loads) {  // hit-dense text: cacheable stream loads
+        if (S == 16 && p.q == 16) MK_VARIANT_PLAIN(16, 16);
+        if (S == 8 && p.q == 24) MK_VARIANT_PLAIN(8, 24);
+        if (S == 4 && p.q == 28) MK_VARIANT_PLAIN(4, 28);
+        if (S == 4 && p.q == 18) MK_VARIANT_PLAIN(4, 18);
+    }
     if (S == 16 && p.q == 16) MK_VARIANT(16, 16, false);
     if (S == 8 && p.q == 24) MK_VARIANT(8, 24, false);
     if (S == 4 && p.q == 28) MK_VARIANT(4, 28, false);
@@ -118,6 +167,7 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
     }
 }
 #undef MK_VARIANT
+#undef MK_VARIANT_PLAIN
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
 // byte0 = global position of seq[0] in the synthetic stream (a multiple of 32)

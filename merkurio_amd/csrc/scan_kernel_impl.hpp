@@ -28,6 +28,7 @@
 //     global atomics otherwise), optional (record, pattern, position) tuples staged through a
 //     per-wave ring so the output cursor sees one atomic per 64 hits.
 #include <algorithm>
+#include <type_traits>
 
 #include "scan_kernel.h"
 
@@ -68,17 +69,17 @@ struct alignas(8) CandEntry {
     uint32_t t_lo;
 };
 constexpr uint32_t kRingEntries = 128;  // per wave; <= 64 pending before an append round of <= 64
-constexpr uint32_t kLdsPatCounters = 64;  // pattern sets up to this size count their hits in LDS
 constexpr uint32_t kHitSlots = 64;  // per wave: verified-q-gram hits waiting for level 3 (one per lane)
-constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) + kLdsPatCounters * 8 +
-                               (kBlockThreads / 64) * kHitSlots * 8;  // 152.5 KiB
+constexpr uint32_t kLdsSumWords = 4;  // per-workgroup sums of the summary counters (candidates, occurrences)
+constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) +
+                               (kBlockThreads / 64) * kHitSlots * 8 + kLdsSumWords * 4;  // 152 KiB
 static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
 // compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
 //   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only,
 //   8 = filter positives are queued in the LDS ring but never probed (level 1 -> 2 hand-off cost),
 //   16 = level 3 dropped (q-gram hits are queued, never resolved), 32 = level 3 without its stores / atomics,
-//   64 = q-gram hits are not even queued, 128 = no per-pattern counter atomics, 256 = no record-flag stores
+//   64 = q-gram hits are not even queued, 256 = no record-flag stores
 #ifndef MK_ABLATE
 #define MK_ABLATE 0
 #endif
@@ -88,8 +89,7 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 // check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
 // its tuple in `out`.
 template <bool EMIT>
-__device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt, mk_hit &out) {
+__device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true, mk_hit &out) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
     if constexpr ((MK_ABLATE & 16) != 0) return false;
     const uint32_t a = P.uniform_len ? pat * P.uniform_len : P.pat_off[pat];
@@ -175,16 +175,8 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     }
     if constexpr ((MK_ABLATE & 256) == 0) reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
     n_true++;
-    if (P.counters && (MK_ABLATE & 128) == 0) {
-        if (P.n_pat <= kLdsPatCounters) {
-            // few patterns: their counters share a cache line or two, and a million global atomics
-            // on one line serialise in one L2 channel (+0.5 ms at 13 patterns).  Count in LDS,
-            // flush once per workgroup at kernel end.
-            atomicAdd(&lds_pat_cnt[pat], 1ull);
-        } else {
-            atomicAdd(&P.counters[pat], 1ull);
-        }
-    }
+    // (occurrences per pattern are counted from the emitted tuples by mk_hist_hits_kernel after the
+    // scan: an atomic per occurrence in here cost 0.65 ms per 10 M occurrences, r02_hitrate_sweep)
     if (EMIT) {  // the caller stages the tuple (HitStage)
         out.rec = lo;
         out.pat = pat;
@@ -235,8 +227,7 @@ __device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, ui
 }
 
 template <bool EMIT>
-__device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint64_t newest_end, uint32_t lane, uint32_t &n_true,
-                                           unsigned long long *lds_pat_cnt) {
+__device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint64_t newest_end, uint32_t lane, uint32_t &n_true) {
     const uint32_t n = hr.count;
     // entries were written by other lanes of this wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -248,7 +239,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
     if (lane < n) {
         uint64_t p = (newest_end & 0xFFFFFFFF00000000ull) | e.x;
         if (p >= newest_end) p -= 1ull << 32;
-        hit = resolve_one<EMIT>(P, e.y, p, n_true, lds_pat_cnt, out);
+        hit = resolve_one<EMIT>(P, e.y, p, n_true, out);
     }
     hr.count = 0;
     if constexpr (EMIT) {
@@ -273,8 +264,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
 // is then the q-gram hash mixed with the candidate's context bases under the mask of the entry's offset.
 template <bool EMIT, int CS>
 __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint32_t ctx, uint64_t t, uint4 v0, uint4 v1,
-                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt) {
+                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true) {
     const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
     const uint32_t epo[4] = {v0.y, v0.w, v1.y, v1.w};
 #pragma unroll
@@ -286,7 +276,7 @@ __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, ui
         const uint64_t mm = (MK_ABLATE & 64) ? 0ull : __ballot(match);
         if (mm) {  // uniform, rare
             const uint32_t cnt = (uint32_t)__popcll(mm);
-            if (hr.count + cnt > kHitSlots) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);  // make room
+            if (hr.count + cnt > kHitSlots) drain_hits<EMIT>(P, hr, newest_end, lane, n_true);  // make room
             if (match) {
                 const uint32_t below =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
@@ -313,19 +303,15 @@ __device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, ui
 // bucket is full), each iteration one memory round trip
 template <bool EMIT, int CS>
 __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint32_t ctx, uint64_t t,
-                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true,
-                                            unsigned long long *lds_pat_cnt) {
+                                            uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true) {
     while (__ballot(active)) {
         uint4 v0, v1;
         load_bucket(P, active, b, v0, v1);
-        active = probe_round<EMIT, CS>(P, active, fp, ctx, t, v0, v1, lane, hr, newest_end, n_true, lds_pat_cnt);
+        active = probe_round<EMIT, CS>(P, active, fp, ctx, t, v0, v1, lane, hr, newest_end, n_true);
         b = (b + 1) & P.table_mask;
     }
 }
 
-#ifndef MK_STREAM_NT
-#define MK_STREAM_NT 1  // 1: non-temporal stream loads; 0: plain loads (tools/hitpath_ab2.sh: 6 % slower on the headline workload, 12 % faster when every read hits)
-#endif
 #ifndef MK_ISSUE_AT
 #define MK_ISSUE_AT 56  // ring fill at which a group ends with an asynchronous level-2 probe
 #endif
@@ -392,7 +378,7 @@ __device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32
 }
 
 // ---- main kernel -----------------------------------------------------------------------
-template <int S, int QC, bool EMIT, bool GF>
+template <int S, int QC, bool EMIT, bool GF, bool NTL>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
     // context kernels: global filter with a compile-time q (filter.hpp: gf_has_ctx); kPipe: their
     // filter probes run one chunk ahead of their use (two samples per lane keeps that in registers)
@@ -401,8 +387,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     using G = Geo<S, QC, kCtx>;
     constexpr bool kPipe = kCtx && G::kNS <= 2 && (MK_ABLATE & 7) == 0;
     __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
-    if (threadIdx.x < kLdsPatCounters)
-        reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2)[threadIdx.x] = 0;
+    uint32_t *lds_sums = bloom + kLdsBytes / 4 - kLdsSumWords;
+    if (threadIdx.x < kLdsSumWords) lds_sums[threadIdx.x] = 0;
     if constexpr (GF) __syncthreads();
     if constexpr (!GF) {  // stage the filter image of the pattern set in LDS
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
@@ -411,7 +397,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         __syncthreads();
     }
     const uint2 *__restrict__ gbloom = reinterpret_cast<const uint2 *>(P.bloom);  // GF: filter blocks in global memory
-    const uint32_t gmask = P.gbloom_mask;
+    const uint32_t gmask = P.gbloom_blocks;  // number of 64-bit filter blocks in global memory
 
     if (P.counters && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&P.counters[P.n_pat + MK_SUM_RECORDS], (unsigned long long)P.n_rec);
@@ -432,13 +418,11 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     uint32_t *ctx_ring = bloom + wave_in_block * kRingEntries;
     uint32_t q_head = 0, q_count = 0, n_cand = 0;  // wave-uniform
     HitRing hr;  // this wave's q-gram-hit ring
-    hr.q = reinterpret_cast<uint2 *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2 + kLdsPatCounters * 2) +
-           wave_in_block * kHitSlots;
+    hr.q = reinterpret_cast<uint2 *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2) + wave_in_block * kHitSlots;
     hr.count = 0;
     hr.stage = EMIT ? P.stage + wave_id * (uint64_t)kHitStage : nullptr;
     hr.staged = 0;
     uint32_t n_true = 0;  // per lane: occurrences found
-    unsigned long long *lds_pat_cnt = reinterpret_cast<unsigned long long *>(bloom + kBloomWords + (kBlockThreads / 64) * kRingEntries * 2);
     uint32_t abl_acc = 0;              // ablation builds only
 
     // ---- level 1 for one 1 KiB chunk: pk_cur = this lane's 16 packed bases, pk_nxt = the
@@ -483,7 +467,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 blk = *reinterpret_cast<const uint2 *>(bloom_bytes + bloom_block_byte(h));  // ds_read_b64
             }
             // all three filter bits set?  (shift counts use the low 5 bits of their register)
-            const uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
+            uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
+            if constexpr (GF) m &= blk.x >> (h >> 12);  // the global filter's fourth bit (d)
             cand |= (m & 1u) << j;
         }
         if constexpr ((MK_ABLATE & 1) != 0) {  // keep the filter work alive, drop its result
@@ -525,7 +510,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint64_t t;
         uint32_t ctx;
         take_from_ring(n, active, b, fp, ctx, t);
-        probe_chain<EMIT, CS>(P, active, b, fp, ctx, t, lane, hr, newest_end, n_true, lds_pat_cnt);
+        probe_chain<EMIT, CS>(P, active, b, fp, ctx, t, lane, hr, newest_end, n_true);
     };
     auto issue_probe = [&](uint32_t n) __attribute__((always_inline)) {  // asynchronous: loads only
         take_from_ring(n, pend_active, pend_b, pend_fp, pend_ctx, pend_t);
@@ -533,9 +518,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         pend_on = true;
     };
     auto consume_probe = [&]() __attribute__((always_inline)) {
-        const bool more = probe_round<EMIT, CS>(P, pend_active, pend_fp, pend_ctx, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true, lds_pat_cnt);
+        const bool more = probe_round<EMIT, CS>(P, pend_active, pend_fp, pend_ctx, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true);
         if (__ballot(more))  // some home bucket had overflowed: finish those chains synchronously
-            probe_chain<EMIT, CS>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_ctx, pend_t, lane, hr, newest_end, n_true, lds_pat_cnt);
+            probe_chain<EMIT, CS>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_ctx, pend_t, lane, hr, newest_end, n_true);
         pend_on = false;
     };
 
@@ -603,22 +588,31 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // No bounds checks here; loads run one group (4 chunks = 4 KiB per wave, 64 KiB per CU)
     // ahead of their use.
     const uint64_t n_main_tiles = n_bytes >= kChunkBytes ? (n_bytes - kChunkBytes) / kTileBytes : 0;
-    if (wave_id < n_main_tiles) {
+    if (wave_id * (P.tile_run ? P.tile_run : 1u) < n_main_tiles) {
         // loader cursor (wave-uniform): pointer to the next chunk to fetch.  Past this wave's
         // last tile the pointer parks on the last main tile: the loads stay unconditional (a
         // branch around a load would force s_waitcnt vmcnt(0) at the join), their data unused.
-        uint64_t ld_tile = wave_id;
+        // Tile dealing: a wave takes `run` consecutive tiles, then jumps ahead by n_waves * run tiles
+        // (run = 1: plain round-robin).  Longer runs keep a wave inside one 2 MiB page for several tiles.
+        const uint32_t run = P.tile_run ? P.tile_run : 1u;
+        const uint64_t jump = (n_waves - 1) * (uint64_t)run + 1;  // from the last tile of a run to the first of the next
+        uint64_t ld_tile = wave_id * run;
+        uint32_t ld_run = 0;
         uint32_t ld_g = 0;  // group index inside the tile (a tile is 8 groups of 4 chunk loads)
         const uint64_t last_tile = n_main_tiles - 1;
-        const uint8_t *ld_ptr = seq + wave_id * kTileBytes + lane * 16;
+        const uint8_t *ld_ptr = seq + (ld_tile < last_tile ? ld_tile : last_tile) * kTileBytes + lane * 16;
         auto nt_load = [](const uint8_t *p) -> uint4 {
-            // non-temporal: the text is read once; keep L2 for the exact table and the filter image
-#if MK_STREAM_NT
-            const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-#else
-            const u32x4 nv = *reinterpret_cast<const u32x4 *>(p);
-#endif
-            return make_uint4(nv.x, nv.y, nv.z, nv.w);
+            // NTL (the normal case): non-temporal, the text is read once; keep L2 for the exact table and
+            // the filter image (-15 % kernel time).  Plain loads are the variant for hit-dense text, where
+            // level 3 re-reads every verified window: a non-temporal stream has left L2 by then (2.4x HBM
+            // traffic when every read hits), a plain one is still in L2 / Infinity Cache.  The host picks
+            // the variant per launch from the hit density it has seen (matcher.cpp).
+            if constexpr (NTL) {
+                const u32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+                return make_uint4(nv.x, nv.y, nv.z, nv.w);
+            } else {
+                return *reinterpret_cast<const uint4 *>(p);
+            }
         };
         // four loads off one address register (immediate offsets); the tile wrap is checked
         // once per group so that the group stays one basic block
@@ -630,7 +624,12 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             ld_ptr += 4 * kChunkBytes;
             if (++ld_g == (uint32_t)(kTileChunks + 1) / 4) {  // next tile of this wave
                 ld_g = 0;
-                ld_tile += n_waves;
+                if (++ld_run == run) {
+                    ld_run = 0;
+                    ld_tile += jump;
+                } else {
+                    ld_tile += 1;
+                }
                 const uint64_t t = ld_tile < last_tile ? ld_tile : last_tile;
                 ld_ptr = seq + t * kTileBytes + lane * 16;
             }
@@ -654,7 +653,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         auto test_pending = [&]() __attribute__((always_inline)) {
             auto pass = [](uint32_t h, uint2 blk) -> uint32_t {
                 const uint32_t hb = gbloom_bits(h);
-                return (blk.x >> (hb >> 27)) & (blk.y >> (hb >> 22)) & (blk.y >> (hb >> 17)) & 1u;
+                return (blk.x >> (hb >> 27)) & (blk.x >> (hb >> 12)) & (blk.y >> (hb >> 22)) & (blk.y >> (hb >> 17)) & 1u;
             };
             uint32_t cand = pass(pd_h0, pd_b0);
             if constexpr (NS > 1) cand |= pass(pd_h1, pd_b1) << 1;
@@ -662,21 +661,21 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         };
         // Queued filter positives carry only the low 32 bits of their position, restored relative to
         // the wave's current position: none may stay queued while the wave advances 4 GiB.  A wave's
-        // tiles are n_waves * 31 KiB apart, so every `age_limit` tiles (1 GiB of advance) whatever
+        // runs of tiles are n_waves * run * 31 KiB apart, so after every 1 GiB of advance whatever
         // is parked or queued is pushed on to level 2 (sparse candidates never reach the ring's
         // fill threshold by themselves: 1 pattern on 15 GB lost two hits in three before this).
-        const uint32_t age_limit = (uint32_t)std::max<uint64_t>(1, (1ull << 30) / (n_waves * kTileBytes));
-        uint32_t tiles_since_push = 0;
-        for (uint64_t tile = wave_id; tile < n_main_tiles; tile += n_waves) {
+        uint64_t last_push_base = 0;
+        uint32_t sc_run = 0;
+        for (uint64_t tile = wave_id * run; tile < n_main_tiles;) {
             const uint64_t base = tile * kTileBytes;
             if constexpr (kCtx) {  // 16 bases in front of the tile (one address for the whole wave)
                 pk_tile_prev = 0;
                 if (base >= 16) pk_tile_prev = pack16(*reinterpret_cast<const uint4 *>(seq + base - 16));
             }
-            if (++tiles_since_push >= age_limit) {
-                tiles_since_push = 0;
+            if (base - last_push_base >= (1ull << 30)) {
+                last_push_base = base;
                 flush_slots();
-                if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);  // 32-bit positions too
+                if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true);  // 32-bit positions too
                 if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
             }
 #pragma unroll 1
@@ -750,6 +749,12 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 }
                 pk_prev = p3;
             }
+            if (++sc_run == run) {  // the same sequence as the loader cursor's
+                sc_run = 0;
+                tile += jump;
+            } else {
+                tile += 1;
+            }
         }
         if constexpr (kPipe) {
             if (pd_on) test_pending();
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // round trip per chunk and finishes up to 60 us after everybody else (r02: 10 M x 150 bp
     // batches ran at 0.65 of the roofline mostly because of it).
     {
-        const uint64_t tail_rank = (wave_id + n_waves - n_main_tiles % n_waves) % n_waves;
+        const uint64_t tail_rank = (wave_id + n_waves - (n_main_tiles / (P.tile_run ? P.tile_run : 1u)) % n_waves) % n_waves;
         for (uint64_t cpos = n_main_tiles * kTileBytes + tail_rank * kChunkBytes; cpos < n_bytes; cpos += n_waves * kChunkBytes) {
             const uint32_t pk_cur = pack16(load16(seq, cpos + lane * 16, n_bytes));
             const uint32_t pk_nxt = pack16(load16(seq, cpos + kChunkBytes + lane * 16, n_bytes));
@@ -784,17 +789,18 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // drain what is left in this wave's slots and rings
     flush_slots();
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
-    if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true, lds_pat_cnt);
+    if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true);
     if constexpr (EMIT) flush_stage(P, hr, lane);
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
-        if (lane == 0 && n_cand) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)n_cand);
-        // uniform addresses: the compiler folds each of these into one atomic per wave
-        if (n_true) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)n_true);
-    }
-    if (P.counters && P.n_pat <= kLdsPatCounters) {  // flush the workgroup's per-pattern counts
+        // One global atomic per WORKGROUP and counter: a single address retires an atomic every ~11 ns,
+        // so one per wave (4096 x 2 on one cache line) kept every launch alive for 80 us after its
+        // last wave had finished -- a quarter of the kernel time of a 1.5 GB batch (r02_small_ablate).
+        if (lane == 0 && n_cand) atomicAdd(&lds_sums[0], n_cand);
+        if (n_true) atomicAdd(&lds_sums[1], n_true);  // per-wave totals stay far below 2^32
         __syncthreads();
-        if (threadIdx.x < P.n_pat && lds_pat_cnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x], lds_pat_cnt[threadIdx.x]);
+        if (threadIdx.x == 0 && lds_sums[0]) atomicAdd(&P.counters[P.n_pat + MK_SUM_CANDIDATES], (unsigned long long)lds_sums[0]);
+        if (threadIdx.x == 1 && lds_sums[1]) atomicAdd(&P.counters[P.n_pat + MK_SUM_HITS], (unsigned long long)lds_sums[1]);
     }
 }
 

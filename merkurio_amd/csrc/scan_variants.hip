@@ -10,14 +10,18 @@
 
 namespace mk {
 
-template <int S, int QC, bool EMIT, bool GF>
+template <int S, int QC, bool EMIT, bool GF, bool NTL>
 void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT, GF>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, p);
+    hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT, GF, NTL>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, p);
 }
 
-#define MK_INST(S_, QC_, GF_)                                                             \
-    template void launch_variant<S_, QC_, false, GF_>(const ScanParams &, int, hipStream_t); \
-    template void launch_variant<S_, QC_, true, GF_>(const ScanParams &, int, hipStream_t)
+#define MK_INST(S_, QC_, GF_)                                                                    \
+    template void launch_variant<S_, QC_, false, GF_, true>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, GF_, true>(const ScanParams &, int, hipStream_t)
+// the same variant with plain (cacheable) stream loads, for hit-dense text
+#define MK_INST_PLAIN(S_, QC_, GF_)                                                               \
+    template void launch_variant<S_, QC_, false, GF_, false>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, GF_, false>(const ScanParams &, int, hipStream_t)
 
 #if MK_TU == 0  // LDS filter, q fixed at compile time: the 31-mer and 21-mer families
 uint32_t scan_lds_bytes() { return kLdsBytes; }
@@ -25,6 +29,11 @@ MK_INST(16, 16, false);
 MK_INST(8, 24, false);
 MK_INST(4, 28, false);
 MK_INST(4, 18, false);
+#elif MK_TU == 6  // the k-mer families again, plain stream loads
+MK_INST_PLAIN(16, 16, false);
+MK_INST_PLAIN(8, 24, false);
+MK_INST_PLAIN(4, 28, false);
+MK_INST_PLAIN(4, 18, false);
 #elif MK_TU == 1  // LDS filter, runtime q <= 16
 MK_INST(1, 0, false);
 MK_INST(2, 0, false);

@@ -47,7 +47,7 @@ EXPORTS = [
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
-    "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times",
+    "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_destroy",
@@ -73,11 +73,11 @@ class PatternError(MerkurioError):
 class MatcherOptions(C.Structure):
     """mk_matcher_options (include/merkurio_hip.h): tuning / test hooks of mk_matcher_create_ex"""
     _fields_ = [("struct_size", C.c_uint32), ("force_stride", C.c_uint32), ("force_global_filter", C.c_uint32),
-                ("gbloom_log2_blocks", C.c_uint32)]
+                ("gbloom_log2_blocks", C.c_uint32), ("tile_run", C.c_uint32), ("gbloom_kib", C.c_uint32)]
 
-    def __init__(self, force_stride=0, force_global_filter=False, gbloom_log2_blocks=0):
+    def __init__(self, force_stride=0, force_global_filter=False, gbloom_log2_blocks=0, tile_run=0, gbloom_kib=0):
         super().__init__(C.sizeof(MatcherOptions), int(force_stride), int(bool(force_global_filter)),
-                         int(gbloom_log2_blocks))
+                         int(gbloom_log2_blocks), int(tile_run), int(gbloom_kib))
 
 
 class Counters(C.Structure):
@@ -162,6 +162,7 @@ def load(build_if_missing=True):
     L.mk_order_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.mk_matcher_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mk_matcher_enable_timing.argtypes = [C.c_void_p, C.c_uint32]
+    L.mk_matcher_hint_hit_density.argtypes = [C.c_void_p, C.c_uint32]
     L.mk_matcher_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -85,7 +85,7 @@ def test_bz2_xz_zstd_decoders(tmp_path, golden):
     import ctypes
     import lzma
     exe = str(tmp_path / "dz")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "merkurio_amd/csrc/cli"), "-o", exe,
+    subprocess.run(["g++", "-std=c++17", "-O1", "-DMK_DECOMPRESS_HARNESS", "-I", os.path.join(ROOT, "merkurio_amd/csrc/cli"), "-o", exe,
                     os.path.join(ROOT, "tests/helpers/decompress_harness.cpp"),
                     os.path.join(ROOT, "merkurio_amd/csrc/cli/decompress.cpp"), "-ldl"], check=True)
 

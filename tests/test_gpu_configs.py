@@ -92,7 +92,7 @@ def test_config5_large_pattern_set(mk, stride):
     assert m.use_ac and m.filter_mode()["in_lds"] is False
     if stride is None:
         assert m.filter_info()["stride"] == 8 and m.filter_info()["q_gram"] == 14
-        assert m.filter_mode()["filter_bytes"] == 4 << 20
+        assert m.filter_mode()["filter_bytes"] == 3 << 20
     else:
         assert m.filter_info()["stride"] == stride
     om = ob.Matcher(patterns, True, 0, False)
@@ -144,7 +144,8 @@ def test_headline_full_size_properties(mk):
     f_any, _, _, c_any = scan(d_seq, d_off, n_rec, mk.MK_MODE_ANY)
     cap = 4_000_000
     f_hit, d_hits, nh, c_hit = scan(d_seq, d_off, n_rec, mk.MK_MODE_HITS, cap)
-    assert torch.equal(f_any, f_hit) and np.array_equal(c_any, c_hit)  # modes agree, run-to-run identical
+    assert torch.equal(f_any, f_hit) and np.array_equal(c_any[npat:], c_hit[npat:])  # modes agree, run-to-run identical
+    assert not c_any[:npat].any()  # occurrences per pattern exist in hits mode only (no-logging extract counts nothing)
     s = c_hit[npat:]
     n_flag = int(f_hit.sum(dtype=torch.int64).item())
     assert s[mk.MK_SUM_RECORDS] == n_rec and s[mk.MK_SUM_BASES] == n_bytes
@@ -160,10 +161,10 @@ def test_headline_full_size_properties(mk):
     # shard additivity: scanning [0, h) and [h, n) separately == the whole batch
     h = 50_000_008  # multiple of 8 records -> byte offset multiple of 16
     off_hi = (d_off[h:] - d_off[h]).contiguous()
-    f_lo, _, _, c_lo = scan(d_seq, d_off, h, mk.MK_MODE_ANY)
-    f_hi, _, _, c_hi = scan(d_seq[h * L:], off_hi, n_rec - h, mk.MK_MODE_ANY)
+    f_lo, _, _, c_lo = scan(d_seq, d_off, h, mk.MK_MODE_HITS, cap)
+    f_hi, _, _, c_hi = scan(d_seq[h * L:], off_hi, n_rec - h, mk.MK_MODE_HITS, cap)
     assert torch.equal(torch.cat([f_lo, f_hi]), f_any)
-    assert np.array_equal((c_lo + c_hi)[:npat], c_any[:npat])
+    assert np.array_equal((c_lo + c_hi)[:npat], c_hit[:npat])
     for k in (mk.MK_SUM_HITS, mk.MK_SUM_RECORDS_HIT, mk.MK_SUM_RECORDS, mk.MK_SUM_BASES):
         assert c_lo[npat + k] + c_hi[npat + k] == c_any[npat + k]
 
@@ -224,7 +225,7 @@ def test_sparse_candidates_full_size(mk, n_pat, every):
     assert np.array_equal(c_all[:npat], c_sum[:npat])
     for k in (mk.MK_SUM_HITS, mk.MK_SUM_RECORDS_HIT, mk.MK_SUM_RECORDS, mk.MK_SUM_BASES):
         assert c_all[npat + k] == c_sum[npat + k]
-    assert c_all[npat + mk.MK_SUM_HITS] == int(c_all[:npat].sum())
+    assert not c_all[:npat].any()  # per-pattern occurrences are a MK_MODE_HITS output
     assert torch.equal(torch.cat(parts), f_all)
     n_flag = int(f_all.sum(dtype=torch.int64).item())
     assert n_rec // every * 0.9 - 10 < n_flag < n_rec // every * 1.1 + 10
@@ -320,17 +321,111 @@ def test_config5_full_size_shard_additivity(mk):
 
     f_all, _, c_all = scan(d_seq, d_off, n_rec)
     f_hit, nh, c_hit = scan(d_seq, d_off, n_rec, mk.MK_MODE_HITS, 2_000_000)
-    assert torch.equal(f_all, f_hit) and np.array_equal(c_all, c_hit) and nh == c_hit[npat + mk.MK_SUM_HITS]
+    assert torch.equal(f_all, f_hit) and np.array_equal(c_all[npat:], c_hit[npat:]) and nh == c_hit[npat + mk.MK_SUM_HITS]
+    assert nh == int(c_hit[:npat].sum())
     shard = 12_500_000  # x 250 B: a multiple of 16 bytes
     parts, c_sum = [], np.zeros_like(c_all)
     for b in range(0, n_rec, shard):
         off_s = (d_off[b:b + shard + 1] - d_off[b]).contiguous()
-        f, _, c = scan(d_seq[b * L:], off_s, shard)
+        f, _, c = scan(d_seq[b * L:], off_s, shard, mk.MK_MODE_HITS, 2_000_000)
         parts.append(f)
         c_sum += c
     assert torch.equal(torch.cat(parts), f_all)
-    assert np.array_equal(c_all[:npat], c_sum[:npat])
+    assert np.array_equal(c_hit[:npat], c_sum[:npat])
     for k in (mk.MK_SUM_HITS, mk.MK_SUM_RECORDS_HIT, mk.MK_SUM_RECORDS, mk.MK_SUM_BASES):
         assert c_all[npat + k] == c_sum[npat + k]
     n_flag = int(f_all.sum(dtype=torch.int64).item())
     assert n_rec // 100 * 0.9 < n_flag < n_rec // 100 * 1.2
+
+
+def test_config4_full_size_bam_through_the_cli(mk, tmp_path):
+    """BASELINE config 4 end to end: a synthetic 20 M-record BAM (150 bp, 4-bit sequences, BGZF) through
+    `merkurio tag -m` with 10 k 31-mers.  The codec side (parallel BGZF inflate, un-nibbling, batched
+    scan, tag append, BAM pass-through) must agree with the library called directly on the same
+    sequences: the kept records, in order, and every km value.  MERKURIO_C4_RECORDS scales it down."""
+    import gzip
+    import os
+    import struct
+    import subprocess
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "merkurio_amd", "lib", "merkurio")
+    n, L, every = int(os.environ.get("MERKURIO_C4_RECORDS", "20000000")), 150, 100
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(10_000, 31, 44))
+    (tmp_path / "k.txt").write_bytes(b"\n".join(patterns) + b"\n")
+    pat_arr = np.frombuffer(b"".join(patterns), dtype=np.uint8).reshape(len(patterns), 31)
+    rec_bytes = 4 + 32 + 11 + (L + 1) // 2 + L
+    fixed = struct.pack("<iiiBBHHHiiii", rec_bytes - 4, -1, -1, 11, 0, 4680, 0, 4, L, -1, -1, 0)
+    nib = np.zeros(256, dtype=np.uint8)
+    for ch, v in zip(b"ACGT", (1, 2, 4, 8)):
+        nib[ch] = v
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+    def bgzf_block(chunk):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        c = co.compress(chunk) + co.flush()
+        return (bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(c) + 25) + c +
+                struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+
+    header_text = b"@HD\tVN:1.6\tSO:unsorted\n"
+    head = b"BAM\x01" + struct.pack("<i", len(header_text)) + header_text + struct.pack("<i", 0)
+    seq_all = np.zeros(n * L + 1, dtype=np.uint8)  # the ASCII sequences the matcher must see (+1 pad byte)
+    slab = 1_000_000
+    rng = np.random.default_rng(2024)
+    with open(tmp_path / "big.bam", "wb") as f, ThreadPoolExecutor(16) as ex:
+        f.write(bgzf_block(head))
+        for s0 in range(0, n, slab):
+            m_ = min(slab, n - s0)
+            seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(m_, L), dtype=np.uint8)]
+            idx = np.arange(s0, s0 + m_)
+            planted = idx[idx % every == 7] - s0
+            which = (idx[planted] * 2654435761) % len(patterns)
+            offs = (idx[planted] * 40503) % (L - 31 + 1)
+            for r, w, o in zip(planted.tolist(), which.tolist(), offs.tolist()):
+                seq[r, o:o + 31] = pat_arr[w]
+            seq_all[s0 * L:(s0 + m_) * L] = seq.reshape(-1)
+            rec = np.empty((m_, rec_bytes), dtype=np.uint8)
+            rec[:, :36] = np.frombuffer(fixed, dtype=np.uint8)
+            rec[:, 36] = ord("r")
+            digits = idx.copy()
+            for d in range(9, 0, -1):
+                rec[:, 36 + d] = 48 + digits % 10
+                digits //= 10
+            rec[:, 46] = 0
+            nb = nib[seq]
+            rec[:, 47:47 + L // 2] = (nb[:, 0::2] << 4) | nb[:, 1::2]
+            rec[:, 47 + L // 2:] = 40
+            raw = rec.tobytes()
+            per = (0xff00 // rec_bytes) * rec_bytes  # whole records per BGZF block
+            for blk in ex.map(bgzf_block, [raw[b:b + per] for b in range(0, len(raw), per)]):
+                f.write(blk)
+        f.write(eof)
+    p = subprocess.run([cli, "tag", "-i", str(tmp_path / "big.bam"), "-f", str(tmp_path / "k.txt"), "-m", "-o",
+                        str(tmp_path / "out.bam")], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    # expected: the library on the same sequences (device path), whole batch at once
+    m = mk.Matcher(patterns)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    flags, hits = m.scan_packed(seq_all, off, mk.MK_MODE_HITS, hits_cap=max(1 << 20, 4 * n // every))
+    want = {}
+    for r, pt in zip(hits["rec"].tolist(), hits["pat"].tolist()):
+        want.setdefault(r, set()).add(pt)
+    assert sorted(want) == np.flatnonzero(flags).tolist() and len(want) >= n // every
+    # got: records of out.bam in order (name, km value)
+    raw = gzip.decompress(open(tmp_path / "out.bam", "rb").read())
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    pos = 8 + l_text + 4
+    got = []
+    while pos < len(raw):
+        bs = struct.unpack_from("<i", raw, pos)[0]
+        body = raw[pos + 4:pos + 4 + bs]
+        name = body[32:32 + 10]
+        aux = body[32 + 11 + (L + 1) // 2 + L:]
+        assert aux[:3] == b"kmZ" and aux[-1:] == b"\0"
+        got.append((int(name[1:]), aux[3:-1]))
+        pos += 4 + bs
+    assert [g[0] for g in got] == sorted(want)
+    for r, val in got[:: max(1, len(got) // 5000)]:
+        assert val == b",".join(patterns[k] for k in sorted(want[r])), r

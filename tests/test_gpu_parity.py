@@ -314,6 +314,40 @@ def test_record_boundaries_and_edges(mk):
     assert e.value.code == mk.MK_E_CAPACITY
 
 
+@pytest.mark.parametrize("k,options", [
+    (31, None), (31, dict(tile_run=4)), (31, dict(tile_run=8)), (21, dict(force_stride=4)),
+    (21, dict(force_global_filter=True, force_stride=8)),             # context kernel <8,14>
+    (21, dict(force_global_filter=True, force_stride=4)),             # context kernel <4,18>
+    (31, dict(force_global_filter=True, force_stride=8, tile_run=2)),  # context kernel <8,24>
+    (21, dict(force_global_filter=True, force_stride=2)),             # global filter, runtime q
+])
+def test_occurrences_across_chunk_and_tile_borders(mk, k, options):
+    """occurrences that start up to k bases before every 1 KiB chunk border, 31 KiB tile border and the
+    start of the guarded tail are found exactly once by every kernel family (halo lanes, the packed
+    16 bases in front of a tile that feed the context fingerprints, run-length tile dealing)"""
+    rnd = np.random.default_rng(100 + k)
+    n = 31744 * 9 + 5000  # nine main tiles + a tail
+    seq = bytearray(np.frombuffer(b"ACGT", dtype=np.uint8)[rnd.integers(0, 4, n)].tobytes())
+    pats = [bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rnd.integers(0, 4, k)]) for _ in range(64)]
+    offs = (0, 1, 7, 8, 9, 15, 16, 17, k - 1)  # bases of the occurrence in front of the border
+    plants = [(31744 * t, offs[t - 1]) for t in range(1, 10)]                      # one tile border per offset
+    plants += [(1024 * c, offs[i % 9]) for i, c in enumerate(range(2, 270, 7))]     # chunk borders, all offsets
+    plants += [(31744 * 9 + 1024 * c, offs[c % 9]) for c in range(1, 4)] + [(n, k)]  # guarded tail, very end
+    for i, (b, o) in enumerate(plants):
+        at = b - o
+        if 0 <= at <= n - k:
+            seq[at:at + k] = pats[i % len(pats)]
+    seq = bytes(seq)
+    patterns = mk.parse_pattern_list(kmer_seq=pats)
+    m = mk.Matcher(patterns, options=options)
+    flags, hits = m.scan([seq[:40000], seq[40000:], seq])  # record borders inside tiles as well
+    exp = []
+    for r, s in enumerate((seq[:40000], seq[40000:], seq)):
+        exp += [(r, p, pos) for p, pos in naive.ac_order(patterns, s)]
+    assert len(exp) >= 2 * (len(plants) - 8)  # every plant shows up in two of the three records
+    assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp
+
+
 def test_long_single_record(mk):
     """one chromosome-sized record is split across lanes / tiles with a halo"""
     rnd = np.random.default_rng(3)
