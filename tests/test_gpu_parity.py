@@ -348,6 +348,23 @@ def test_occurrences_across_chunk_and_tile_borders(mk, k, options):
     assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp
 
 
+def test_device_out_of_memory_is_an_error_code(mk):
+    """hipErrorOutOfMemory comes back across the C ABI as MK_E_NOMEM (not MK_E_HIP, not an abort), and the
+    handle stays usable"""
+    import ctypes as C
+    pat = b"ACGTTGCAACGTTGCAACGTTGCAACGTTGC"
+    m = mk.Matcher([pat])
+    data, off = mk.pack_records([pat, b"ACGT"])
+    flags = np.zeros(2, dtype=np.uint8)
+    hits = np.zeros(4, dtype=mk.HIT_DTYPE)  # never written: the device buffer of 2^40 tuples cannot be allocated
+    nh = C.c_uint64()
+    rc = mk.load().mk_scan_batch(m.handle, data.ctypes.data, off.ctypes.data, 2, mk.MK_MODE_HITS, flags.ctypes.data,
+                                 hits.ctypes.data, 1 << 40, C.byref(nh))
+    assert rc == mk.MK_E_NOMEM, (rc, mk.load().mk_last_error())
+    f, h = m.scan([pat, b"ACGT"])
+    assert f.tolist() == [True, False] and h["pos"].tolist() == [0]
+
+
 def test_long_single_record(mk):
     """one chromosome-sized record is split across lanes / tiles with a halo"""
     rnd = np.random.default_rng(3)
