@@ -119,7 +119,7 @@ def build_cli(force=False, verbose=False):
         o = os.path.join(obj_dir, os.path.basename(s).replace(".cpp", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + cli_hdrs):
-            jobs.append([HIPCC, "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-c", "-o", o, s])
+            jobs.append([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", "-c", "-o", o, s])
 
     def run(cmd):
         if verbose:

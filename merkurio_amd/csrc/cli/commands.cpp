@@ -269,22 +269,23 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     const std::vector<int> devs = device_list(a);
     std::future<std::vector<mk_matcher *>> fm = std::async(std::launch::async, [&] { return make_matchers(a, pats, devs, &use_ac); });
 
-    FastxFile f1, f2;
+    // The inputs are read a window at a time (--window-mb of text, decompressed if need be): the host holds
+    // one window and its record index, like the reference, which streams records.
+    FastxStream s1, s2;
+    FastxFile &f1 = s1.view, &f2 = s2.view;
     const bool paired = (bool)a.in_fastq_2;
+    const uint64_t window_bytes = (uint64_t)a.window_mb << 20;
+    bool more1 = false, more2 = false;
     try {
-        f1.parse(a.in_fastx);
-        if (paired) {
-            f2.parse(*a.in_fastq_2);
-            if (f2.recs.size() < f1.recs.size())
-                bail("Error during FASTQ record parsing of second file. Do the two input files contain the same number of records?");
-            if (f2.recs.size() > f1.recs.size())
-                bail("The two input files have a different number of records. Please provide valid paired-end read files.");
-        }
+        s1.open(a.in_fastx);
+        if (paired) s2.open(*a.in_fastq_2);
+        more1 = s1.fill(window_bytes);
+        if (paired) more2 = s2.fill(window_bytes);
     } catch (...) {
         fm.get();  // a matcher error comes first, as in the serial order of the reference
         throw;
     }
-    tm.mark("read + parse input");
+    tm.mark("open + first window");
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
     tm.mark("matcher create (HIP init), remainder");
@@ -308,7 +309,6 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     mk_counters c;
     memset(&c, 0, sizeof(c));
     std::vector<uint32_t> counts(pats.list.size(), 0);
-    const size_t n = f1.recs.size();
     const uint64_t batch_bytes = (uint64_t)a.batch_mb << 20;
     // what a batch's results turn into: log rows (reference emission order) and the kept records
     auto emit_rows = [&](size_t b0, const mk_row *rows, uint64_t n_rows) {
@@ -394,56 +394,66 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             cur ^= 1;
         }
     };
-    if (ms.size() == 1) {
-        scan_range(m, 0, n, c, counts, [&](size_t b0, uint64_t nb, const uint8_t *keep, const mk_row *rows, uint64_t n_rows) {
-            tm.mark("batch: gather + H2D + scan + D2H");
-            emit_rows(b0, rows, n_rows);
-            emit_records(b0, keep, nb);
-            tm.mark("batch: rows + records out");
-        });
-    } else {
-        // --gpus N: device d scans the contiguous record (pair) range shard_range(n, N, d) on its own
-        // host thread; results are buffered per device and emitted in device order, which is record order
-        struct Shard {
-            size_t r0 = 0, r1 = 0;
-            mk_counters c;
-            std::vector<uint32_t> counts;
-            std::vector<uint8_t> keep;
-            std::vector<mk_row> rows;  // rec = index inside the shard
-        };
-        std::vector<Shard> shards(ms.size());
-        for (size_t d = 0; d < ms.size(); ++d) {
-            auto [lo, hi] = shard_range(n, ms.size(), d);
-            shards[d].r0 = lo;
-            shards[d].r1 = hi;
-            memset(&shards[d].c, 0, sizeof(mk_counters));
-            shards[d].counts.assign(counts.size(), 0);
-            shards[d].keep.assign(hi - lo, 0);
-        }
-        run_threads(ms.size(), [&](size_t d) {
-            Shard &S = shards[d];
-            scan_range(ms[d], S.r0, S.r1, S.c, S.counts, [&](size_t b0, uint64_t nb, const uint8_t *keep, const mk_row *rows, uint64_t n_rows) {
-                memcpy(S.keep.data() + (b0 - S.r0), keep, nb);
-                for (uint64_t k = 0; k < n_rows; ++k) {
-                    mk_row r = rows[k];
-                    r.rec += b0 - S.r0;
-                    S.rows.push_back(r);
-                }
+    // per-device counters of a --gpus N job (summed once, at the end, by RCCL)
+    std::vector<mk_counters> dev_c(ms.size());
+    std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
+    for (auto &x : dev_c) memset(&x, 0, sizeof(x));
+    while (more1 || more2) {
+        if (paired && !more2)  // src/cmd_extract.rs:465-468: file 2 ends first
+            bail("Error during FASTQ record parsing of second file. Do the two input files contain the same number of records?");
+        if (paired && !more1)  // src/cmd_extract.rs:608-612: file 2 still has records
+            bail("The two input files have a different number of records. Please provide valid paired-end read files.");
+        // pairs are matched by ordinal: both windows advance by the same number of records
+        const size_t n = paired ? std::min(f1.recs.size(), f2.recs.size()) : f1.recs.size();
+        if (ms.size() == 1) {
+            scan_range(m, 0, n, c, counts, [&](size_t b0, uint64_t nb, const uint8_t *keep, const mk_row *rows, uint64_t n_rows) {
+                tm.mark("batch: gather + H2D + scan + D2H");
+                emit_rows(b0, rows, n_rows);
+                emit_records(b0, keep, nb);
+                tm.mark("batch: rows + records out");
             });
-        });
-        tm.mark("scan on all devices");
-        for (auto &S : shards) {
-            emit_rows(S.r0, S.rows.data(), S.rows.size());
-            emit_records(S.r0, S.keep.data(), S.r1 - S.r0);
+        } else {
+            // --gpus N: device d scans the contiguous record (pair) range shard_range(n, N, d) of the window on
+            // its own host thread; results are buffered per device and emitted in device order = record order
+            struct Shard {
+                size_t r0 = 0, r1 = 0;
+                std::vector<uint8_t> keep;
+                std::vector<mk_row> rows;  // rec = index inside the shard
+            };
+            std::vector<Shard> shards(ms.size());
+            for (size_t d = 0; d < ms.size(); ++d) {
+                auto [lo, hi] = shard_range(n, ms.size(), d);
+                shards[d].r0 = lo;
+                shards[d].r1 = hi;
+                shards[d].keep.assign(hi - lo, 0);
+            }
+            run_threads(ms.size(), [&](size_t d) {
+                Shard &S = shards[d];
+                scan_range(ms[d], S.r0, S.r1, dev_c[d], dev_counts[d],
+                           [&](size_t b0, uint64_t nb, const uint8_t *keep, const mk_row *rows, uint64_t n_rows) {
+                               memcpy(S.keep.data() + (b0 - S.r0), keep, nb);
+                               for (uint64_t k = 0; k < n_rows; ++k) {
+                                   mk_row r = rows[k];
+                                   r.rec += b0 - S.r0;
+                                   S.rows.push_back(r);
+                               }
+                           });
+            });
+            tm.mark("window: scan on all devices");
+            for (auto &S : shards) {
+                emit_rows(S.r0, S.rows.data(), S.rows.size());
+                emit_records(S.r0, S.keep.data(), S.r1 - S.r0);
+            }
         }
-        std::vector<mk_counters> cs;
-        std::vector<std::vector<uint32_t>> cts;
-        for (auto &S : shards) {
-            cs.push_back(S.c);
-            cts.push_back(S.counts);
-        }
-        reduce_device_counters(ms, devs, cs, cts, c, counts);
-        tm.mark("rows + records out, counter reduction");
+        s1.consume(n);
+        if (paired) s2.consume(n);
+        more1 = s1.fill(window_bytes);
+        if (paired) more2 = s2.fill(window_bytes);
+        tm.mark("next window");
+    }
+    if (ms.size() > 1) {
+        reduce_device_counters(ms, devs, dev_c, dev_counts, c, counts);
+        tm.mark("counter reduction");
     }
     w1.flush();
     w2.flush();
@@ -518,12 +528,12 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
 
     SamFile sam;
     try {
-        sam.parse(a.in_file);  // "Input file must be a BAM or SAM file." for other extensions
+        sam.open(a.in_file);  // "Input file must be a BAM or SAM file." for other extensions; header only
     } catch (...) {
         fm.get();  // a matcher error comes first, as in the serial order of the reference
         throw;
     }
-    tm.mark("parse");
+    tm.mark("open + header");
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
     tm.mark("matcher (HIP init), remainder");
@@ -545,12 +555,13 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         w.write(out_header);
     }
 
-    const size_t n = sam.recs.size();
     mk_counters c;
     memset(&c, 0, sizeof(c));
     std::vector<uint32_t> counts(pats.list.size(), 0);
     const uint64_t batch_bytes = (uint64_t)a.batch_mb << 20;
-    // One batch = a slab of records whose sequences fill --batch-mb: gather (upper-case / un-nibble)
+    const uint64_t window_bytes = (uint64_t)a.window_mb << 20;
+    // The input is read a window at a time (--window-mb of SAM text / inflated BAM); inside a window,
+    // one batch = a slab of records whose sequences fill --batch-mb: gather (upper-case / un-nibble)
     // -> mk_tag_records -> log rows -> tag + encode the kept records.  Only the input buffer and its
     // record index are whole-file; device buffers, hit rows and matched-pattern sets are per batch.
     // The results of a batch: its log rows and the encoded output of its kept records, in record order.
@@ -665,40 +676,35 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
             b0 = b1;
         }
     };
-    if (ms.size() == 1) {
-        scan_range(m, 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
-            emit(o);
-            tm.mark("batch: gather + scan + tag + write");
-        });
-    } else {
-        // --gpus N: contiguous record ranges per device, one host thread each; batch results are kept
-        // per device and emitted in device order = record order; counters reduced with RCCL
-        struct Shard {
-            mk_counters c;
-            std::vector<uint32_t> counts;
-            std::vector<BatchOut> outs;
-        };
-        std::vector<Shard> shards(ms.size());
-        for (auto &S : shards) {
-            memset(&S.c, 0, sizeof(mk_counters));
-            S.counts.assign(counts.size(), 0);
+    // per-device counters of a --gpus N job (summed once, at the end, by RCCL)
+    std::vector<mk_counters> dev_c(ms.size());
+    std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
+    for (auto &x : dev_c) memset(&x, 0, sizeof(x));
+    while (sam.fill(window_bytes)) {
+        const size_t n = sam.recs.size();
+        if (ms.size() == 1) {
+            scan_range(m, 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
+                emit(o);
+                tm.mark("batch: gather + scan + tag + write");
+            });
+        } else {
+            // --gpus N: contiguous record ranges of the window per device, one host thread each; batch results
+            // are kept per device and emitted in device order = record order
+            std::vector<std::vector<BatchOut>> outs(ms.size());
+            run_threads(ms.size(), [&](size_t d) {
+                auto [lo, hi] = shard_range(n, ms.size(), d);
+                scan_range(ms[d], lo, hi, dev_c[d], dev_counts[d], std::max<size_t>(1, io_threads() / ms.size()),
+                           [&](BatchOut &&o) { outs[d].push_back(std::move(o)); });
+            });
+            tm.mark("window: scan + tag on all devices");
+            for (auto &v : outs)
+                for (auto &o : v) emit(o);
         }
-        run_threads(ms.size(), [&](size_t d) {
-            auto [lo, hi] = shard_range(n, ms.size(), d);
-            scan_range(ms[d], lo, hi, shards[d].c, shards[d].counts, std::max<size_t>(1, io_threads() / ms.size()),
-                       [&](BatchOut &&o) { shards[d].outs.push_back(std::move(o)); });
-        });
-        tm.mark("scan + tag on all devices");
-        for (auto &S : shards)
-            for (auto &o : S.outs) emit(o);
-        std::vector<mk_counters> cs;
-        std::vector<std::vector<uint32_t>> cts;
-        for (auto &S : shards) {
-            cs.push_back(S.c);
-            cts.push_back(S.counts);
-        }
-        reduce_device_counters(ms, devs, cs, cts, c, counts);
-        tm.mark("write, counter reduction");
+        tm.mark("window done");
+    }
+    if (ms.size() > 1) {
+        reduce_device_counters(ms, devs, dev_c, dev_counts, c, counts);
+        tm.mark("counter reduction");
     }
     w.flush();
     bw.close();

@@ -14,17 +14,6 @@
 
 namespace cli {
 
-// MERKURIO_TIMING=1: wall time of the codec phases on stderr
-static void io_mark(const char *what) {
-    static const bool on = getenv("MERKURIO_TIMING") != nullptr;
-    static double t0 = 0;
-    if (!on) return;
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    const double t = ts.tv_sec + ts.tv_nsec * 1e-9;
-    if (what && t0 > 0) fprintf(stderr, "[timing]   io: %-22s %8.3f s\n", what, t - t0);
-    t0 = t;
-}
 
 unsigned io_threads() {
     static const unsigned cached = [] {
@@ -85,6 +74,66 @@ void require_host_memory(uint64_t need, const std::string &path) {
 // size (SAM spec 4.1).  Walk the member headers, size the output from the ISIZE trailers, then
 // inflate the members independently.  Returns false (out untouched) if the file is not BGZF all
 // the way through -- the caller falls back to the serial gzip reader.
+// Member table of a BGZF file held in d[0,n): false if it is not BGZF all the way through.
+struct BgzfMember {
+    size_t data_off, data_len;  // raw deflate stream
+    size_t out_off;
+    uint32_t isize, crc;
+};
+static bool bgzf_members(const uint8_t *d, size_t n, std::vector<BgzfMember> &mem, size_t *total_out) {
+    size_t p = 0, total = 0;
+    while (p < n) {
+        if (n - p < 18 || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return false;
+        const size_t xlen = d[p + 10] | (size_t)d[p + 11] << 8;
+        if (n - p < 12 + xlen + 8) return false;
+        size_t bsize = 0;
+        for (size_t x = p + 12; x + 4 <= p + 12 + xlen;) {  // extra subfields
+            const size_t slen = d[x + 2] | (size_t)d[x + 3] << 8;
+            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= p + 12 + xlen) bsize = (d[x + 4] | (size_t)d[x + 5] << 8) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || (d[p + 3] & ~4) || n - p < bsize) return false;
+        BgzfMember b;
+        b.data_off = p + 12 + xlen;
+        b.data_len = bsize - (12 + xlen) - 8;
+        memcpy(&b.crc, d + p + bsize - 8, 4);
+        memcpy(&b.isize, d + p + bsize - 4, 4);
+        b.out_off = total;
+        total += b.isize;
+        mem.push_back(b);
+        p += bsize;
+    }
+    if (total_out) *total_out = total;
+    return !mem.empty();
+}
+// inflates members [m0, m1) into out + (member.out_off - mem[m0].out_off) on the host threads
+static void bgzf_inflate_range(const uint8_t *d, const std::vector<BgzfMember> &mem, size_t m0, size_t m1, char *out,
+                               const std::string &path) {
+    const size_t cnt = m1 - m0;
+    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), cnt / 16 + 1));
+    const size_t base = mem[m0].out_off;
+    run_threads(T, [&](size_t t) {
+        z_stream z;
+        memset(&z, 0, sizeof(z));
+        if (inflateInit2(&z, -15) != Z_OK) bail("Error while decompressing " + path);
+        for (size_t i = m0 + cnt * t / T; i < m0 + cnt * (t + 1) / T; ++i) {
+            const BgzfMember &b = mem[i];
+            inflateReset(&z);
+            z.next_in = const_cast<Bytef *>(d + b.data_off);
+            z.avail_in = (uInt)b.data_len;
+            z.next_out = (Bytef *)out + (b.out_off - base);
+            z.avail_out = b.isize;
+            const int r = inflate(&z, Z_FINISH);
+            if ((r != Z_STREAM_END && !(b.isize == 0 && r == Z_BUF_ERROR)) || z.avail_out != 0 ||
+                (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef *)out + (b.out_off - base), b.isize) != b.crc) {
+                inflateEnd(&z);
+                bail("Error while decompressing " + path);
+            }
+        }
+        inflateEnd(&z);
+    });
+}
+
 static bool inflate_bgzf_parallel(const std::string &path, std::vector<char> &out) {
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
@@ -98,81 +147,21 @@ static bool inflate_bgzf_parallel(const std::string &path, std::vector<char> &ou
     close(fd);
     if (m == MAP_FAILED) return false;
     const uint8_t *d = (const uint8_t *)m;
-    struct Member {
-        size_t data_off, data_len;  // raw deflate stream
-        size_t out_off;
-        uint32_t isize, crc;
-    };
-    std::vector<Member> mem;
-    size_t p = 0, total = 0;
-    bool ok = true;
-    while (p < n) {
-        if (n - p < 18 || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) {
-            ok = false;
-            break;
-        }
-        const size_t xlen = d[p + 10] | (size_t)d[p + 11] << 8;
-        if (n - p < 12 + xlen + 8) {
-            ok = false;
-            break;
-        }
-        size_t bsize = 0;
-        for (size_t x = p + 12; x + 4 <= p + 12 + xlen;) {  // extra subfields
-            const size_t slen = d[x + 2] | (size_t)d[x + 3] << 8;
-            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= p + 12 + xlen) bsize = (d[x + 4] | (size_t)d[x + 5] << 8) + 1;
-            x += 4 + slen;
-        }
-        if (bsize < 12 + xlen + 8 || (d[p + 3] & ~4) || n - p < bsize) {  // other header flags: not BGZF as written by anyone
-            ok = false;
-            break;
-        }
-        Member b;
-        b.data_off = p + 12 + xlen;
-        b.data_len = bsize - (12 + xlen) - 8;
-        memcpy(&b.crc, d + p + bsize - 8, 4);
-        memcpy(&b.isize, d + p + bsize - 4, 4);
-        b.out_off = total;
-        total += b.isize;
-        mem.push_back(b);
-        p += bsize;
-    }
-    if (!ok || mem.empty()) {
+    std::vector<BgzfMember> mem;
+    size_t total = 0;
+    if (!bgzf_members(d, n, mem, &total)) {
         munmap(m, n);
         return false;
     }
-    require_host_memory(total + total / 8, path);  // + record index
-    out.resize(total);
-    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), mem.size() / 16 + 1));
-    std::vector<int> bad(T, 0);
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; ++t)
-        th.emplace_back([&, t] {
-            z_stream z;
-            memset(&z, 0, sizeof(z));
-            if (inflateInit2(&z, -15) != Z_OK) {
-                bad[t] = 1;
-                return;
-            }
-            for (size_t i = mem.size() * t / T; i < mem.size() * (t + 1) / T; ++i) {
-                const Member &b = mem[i];
-                inflateReset(&z);
-                z.next_in = const_cast<Bytef *>(d + b.data_off);
-                z.avail_in = (uInt)b.data_len;
-                z.next_out = (Bytef *)out.data() + b.out_off;
-                z.avail_out = b.isize;
-                const int r = inflate(&z, Z_FINISH);
-                if ((r != Z_STREAM_END && !(b.isize == 0 && r == Z_BUF_ERROR)) || z.avail_out != 0 ||
-                    (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef *)out.data() + b.out_off, b.isize) != b.crc) {
-                    bad[t] = 1;
-                    break;
-                }
-            }
-            inflateEnd(&z);
-        });
-    for (auto &x : th) x.join();
+    try {
+        require_host_memory(total + total / 8, path);  // + record index
+        out.resize(total);
+        bgzf_inflate_range(d, mem, 0, mem.size(), out.data(), path);
+    } catch (...) {
+        munmap(m, n);
+        throw;
+    }
     munmap(m, n);
-    for (int b : bad)
-        if (b) bail("Error while decompressing " + path);
     return true;
 }
 
@@ -268,8 +257,10 @@ static uint64_t strip_cr(const char *d, uint64_t b, uint64_t e) { return (e > b 
 
 // records of d[p, stop): p is at a record start (or blank lines before one); a record that starts
 // before `stop` is parsed completely even if it runs past it
-static void parse_fastx_range(const char *d, uint64_t n, uint64_t p, uint64_t stop, bool fastq,
-                              std::vector<FastxFile::Rec> &recs) {
+// partial_ok (windowed reading: more text follows d[0,n)): a record that cannot be shown to end inside
+// d[0,n) is not an error, parsing stops in front of it.  Returns the offset where parsing stopped.
+static uint64_t parse_fastx_range(const char *d, uint64_t n, uint64_t p, uint64_t stop, bool fastq,
+                                  std::vector<FastxFile::Rec> &recs, bool partial_ok = false) {
     while (p < stop) {
         if (d[p] == '\n' || d[p] == '\r') {  // blank line between records
             ++p;
@@ -288,6 +279,7 @@ static void parse_fastx_range(const char *d, uint64_t n, uint64_t p, uint64_t st
                 if (q >= n || d[q] == '>') break;
                 q = std::min(line_end(d, n, q) + 1, n);
             }
+            if (partial_ok && q >= n) return p;  // no following header in sight: the record may go on
             uint64_t re = q;
             while (re > s && (d[re - 1] == '\n' || d[re - 1] == '\r')) --re;  // drop the final line end
             r.raw_e = re;
@@ -296,6 +288,11 @@ static void parse_fastx_range(const char *d, uint64_t n, uint64_t p, uint64_t st
         } else {
             if (d[p] != '@') bail("Error during FASTQ/A record parsing.");
             uint64_t e1 = line_end(d, n, p);
+            if (partial_ok) {  // all four lines, line ends included, must be inside the window
+                uint64_t e = e1;
+                for (int k = 0; k < 3 && e < n; ++k) e = line_end(d, n, e + 1);
+                if (e >= n) return p;
+            }
             if (e1 >= n) bail("Error during FASTQ/A record parsing.");
             r.id_b = p + 1;
             r.id_e = strip_cr(d, p + 1, e1);
@@ -313,6 +310,7 @@ static void parse_fastx_range(const char *d, uint64_t n, uint64_t p, uint64_t st
         }
         recs.push_back(r);
     }
+    return p;
 }
 
 // first record start at or after `from` (line-aligned).  FASTQ: a line starting with '@' whose
@@ -337,6 +335,7 @@ void FastxFile::parse(const std::string &path) {
     file.load(path);
     data = file.p;
     const uint64_t n = file.n;
+    data_n = n;
     recs.clear();
     uint64_t p = 0;
     while (p < n && (data[p] == '\n' || data[p] == '\r')) ++p;
@@ -413,7 +412,7 @@ void FastxFile::write(size_t i, Sink &w) const {
     // ending, detected on its header line: CRLF input stays CRLF (the wrapped lines inside a FASTA
     // raw_seq keep theirs anyway)
     const Rec &r = recs[i];
-    const bool crlf = r.id_e < file.n && data[r.id_e] == '\r';
+    const bool crlf = r.id_e < data_n && data[r.id_e] == '\r';
     const char *nl = crlf ? "\r\n" : "\n";
     const size_t nl_len = crlf ? 2 : 1;
     w.write(fastq ? "@" : ">", 1);
@@ -429,17 +428,189 @@ void FastxFile::write(size_t i, Sink &w) const {
     }
 }
 
+// ---- WindowSource: the bytes of an input, decompressed a window at a time -----------------------------
+WindowSource::~WindowSource() {
+    if (zs) {
+        inflateEnd((z_stream *)zs);
+        delete (z_stream *)zs;
+    }
+}
+
+void WindowSource::open(const std::string &p) {
+    path = p;
+    int fd = ::open(p.c_str(), O_RDONLY);
+    if (fd < 0) bail("No such file or directory: " + p);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = pread(fd, magic, 2, 0);
+    struct stat st;
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (gz && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) bail("Cannot open " + p);
+        src.map = m;
+        src.map_len = (uint64_t)st.st_size;
+        src.p = (const char *)m;
+        src.n = src.map_len;
+        std::vector<BgzfMember> mem;
+        if (bgzf_members((const uint8_t *)src.p, src.n, mem, nullptr)) {
+            kind = BGZF;
+            for (auto &b : mem) members.push_back(Member{b.data_off, b.data_len, b.isize, b.crc});
+        } else {
+            kind = GZIP;
+            z_stream *z = new z_stream;
+            memset(z, 0, sizeof(*z));
+            if (inflateInit2(z, 15 + 32) != Z_OK) {  // gzip or zlib header, detected
+                delete z;
+                bail("Error while decompressing " + p);
+            }
+            zs = z;
+        }
+        return;
+    }
+    close(fd);
+    kind = PLAIN;
+    src.load(p);  // mmap; bzip2 / xz / zstd are inflated whole by magic
+}
+
+void WindowSource::drop_front(uint64_t k) {
+    if (kind == PLAIN || k == 0) return;
+    if (k > buf_len) k = buf_len;
+    memmove(buf.data(), buf.data() + k, buf_len - k);
+    buf_len -= k;
+}
+
+bool WindowSource::more(uint64_t want) {
+    if (kind == PLAIN || src_eof) return false;
+    if (want < (1u << 16)) want = 1u << 16;
+    require_host_memory(buf_len + want + (buf_len + want) / 8, path);
+    if (kind == BGZF) {
+        size_t m1 = (size_t)src_pos;
+        uint64_t add = 0;
+        while (m1 < members.size() && (add < want || m1 == (size_t)src_pos)) add += members[m1++].isize;
+        if (buf.size() < buf_len + add) buf.resize(buf_len + add);
+        std::vector<BgzfMember> part;
+        uint64_t o = 0;
+        for (size_t i = (size_t)src_pos; i < m1; ++i) {
+            part.push_back(BgzfMember{(size_t)members[i].data_off, (size_t)members[i].data_len, (size_t)o, members[i].isize, members[i].crc});
+            o += members[i].isize;
+        }
+        if (!part.empty()) bgzf_inflate_range((const uint8_t *)src.p, part, 0, part.size(), buf.data() + buf_len, path);
+        buf_len += add;
+        src_pos = m1;
+        if (src_pos >= members.size()) src_eof = true;
+        return true;
+    }
+    // GZIP: zlib streaming over the mapped file, concatenated members included
+    z_stream *z = (z_stream *)zs;
+    if (buf.size() < buf_len + want) buf.resize(buf_len + want);
+    uint64_t room = buf.size() - buf_len;
+    while (room > 0 && !src_eof) {
+        z->next_in = (Bytef *)const_cast<char *>(src.p + src_pos);
+        const uInt in_piece = (uInt)std::min<uint64_t>(src.n - src_pos, 1u << 30);
+        z->avail_in = in_piece;
+        z->next_out = (Bytef *)buf.data() + buf_len;
+        const uInt out_piece = (uInt)std::min<uint64_t>(room, 1u << 30);
+        z->avail_out = out_piece;
+        const int r = inflate(z, Z_NO_FLUSH);
+        src_pos += in_piece - z->avail_in;
+        buf_len += out_piece - z->avail_out;
+        room -= out_piece - z->avail_out;
+        if (r == Z_STREAM_END) {
+            if (src_pos >= src.n) {
+                src_eof = true;
+            } else if (inflateReset(z) != Z_OK) {  // next member
+                bail("Error while decompressing " + path);
+            }
+        } else if (r != Z_OK && r != Z_BUF_ERROR) {
+            bail("Error while decompressing " + path);
+        } else if (src_pos >= src.n && z->avail_out != 0) {
+            bail("Error while decompressing " + path);  // the input ends inside a member
+        }
+    }
+    return true;
+}
+
+// ---- FastxStream: FASTA / FASTQ records, one window at a time -----------------------------------------
+void FastxStream::parse_window(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool partial_ok) {
+    view.data = d;
+    view.data_n = n;
+    view.recs.clear();
+    uint64_t p = from;
+    while (p < n && (d[p] == '\n' || d[p] == '\r')) ++p;
+    parsed_end = p;
+    if (p >= n) return;
+    if (!started) {
+        if (d[p] != '>' && d[p] != '@') bail("Error during FASTQ/A record parsing.");
+        view.fastq = d[p] == '@';
+        started = true;
+    }
+    const bool fastq = view.fastq;
+    if (stop <= p) stop = std::min(n, p + 1);
+    // split at record starts and parse the pieces on host threads
+    const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)io_threads(), (stop - p) / (16u << 20) + 1));
+    std::vector<uint64_t> cut(T + 1);
+    cut[0] = p;
+    cut[T] = stop;
+    for (uint64_t t = 1; t < T; ++t) cut[t] = std::min(stop, std::max(cut[t - 1], next_record_start(d, n, p + (stop - p) * t / T, fastq)));
+    std::vector<std::vector<FastxFile::Rec>> parts(T);
+    std::vector<uint64_t> ends(T, 0);
+    run_threads((size_t)T, [&](size_t t) {
+        parts[t].reserve((cut[t + 1] - cut[t]) / 200 + 16);
+        // only the last piece can run into the end of the window
+        ends[t] = parse_fastx_range(d, n, cut[t], cut[t + 1], fastq, parts[t], partial_ok && t + 1 == T);
+    });
+    size_t total = 0;
+    for (auto &v : parts) total += v.size();
+    view.recs.reserve(total);
+    for (auto &v : parts) view.recs.insert(view.recs.end(), v.begin(), v.end());
+    parsed_end = ends[T - 1];
+}
+
+bool FastxStream::fill(uint64_t window_bytes) {
+    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
+    if (src.mapped()) {
+        const uint64_t n = src.size();
+        if (cursor >= n) {
+            view.recs.clear();
+            return false;
+        }
+        // a record that starts inside the window is parsed completely (the text behind it is mapped too)
+        parse_window(src.data(), n, cursor, std::min(n, cursor + window_bytes), false);
+        return !view.recs.empty();
+    }
+    // compressed: unconsumed tail to the front, then inflate until a complete record is in the buffer
+    src.drop_front(cursor);
+    cursor = 0;
+    uint64_t want = window_bytes > src.size() ? window_bytes - src.size() : 0;
+    for (;;) {
+        if (want) src.more(want);
+        parse_window(src.data(), src.size(), 0, src.size(), !src.exhausted());
+        if (!view.recs.empty() || src.exhausted()) break;
+        want = std::max<uint64_t>(window_bytes, src.size());  // one record larger than the window: take more
+    }
+    return !view.recs.empty();
+}
+
+void FastxStream::consume(size_t n) {
+    cursor = n < view.recs.size() ? view.recs[n].id_b - 1 : parsed_end;
+    view.recs.clear();
+}
+
 // ---- SAM / BAM ------------------------------------------------------------------------------------
 // SAM text: header lines ('@') may appear anywhere a line starts; records keep their file order.
 // The text is cut at line starts into one piece per host thread; a record is five offsets.
-static void parse_sam_text(const char *d, uint64_t n, SamFile &out) {
-    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), n / (8u << 20) + 1));
-    std::vector<uint64_t> cut(T + 1, n);
-    cut[0] = 0;
+// lines of d[from, stop) (both at line starts); keep_header: '@' lines are appended to out.header
+// (whole-file parse), else they are skipped (windowed reading took the header at open())
+static void parse_sam_text(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool keep_header, SamFile &out) {
+    const uint64_t span = stop - from;
+    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), span / (8u << 20) + 1));
+    std::vector<uint64_t> cut(T + 1, stop);
+    cut[0] = from;
     for (size_t t = 1; t < T; ++t) {
-        uint64_t p = std::max<uint64_t>(cut[t - 1], n * t / T);
-        if (p > 0 && p < n) p = line_end(d, n, p - 1) + 1;  // first line start at or after p
-        cut[t] = std::min(p, n);
+        uint64_t p = std::max<uint64_t>(cut[t - 1], from + span * t / T);
+        if (p > 0 && p < stop) p = line_end(d, n, p - 1) + 1;  // first line start at or after p
+        cut[t] = std::min(p, stop);
     }
     std::vector<std::vector<SamFile::Rec>> parts(T);
     std::vector<std::string> headers(T);
@@ -452,8 +623,10 @@ static void parse_sam_text(const char *d, uint64_t n, SamFile &out) {
             const uint64_t le = strip_cr(d, p, e);
             if (le > p) {
                 if (d[p] == '@') {
-                    headers[t].append(d + p, le - p);
-                    headers[t] += '\n';
+                    if (keep_header) {
+                        headers[t].append(d + p, le - p);
+                        headers[t] += '\n';
+                    }
                 } else {
                     SamFile::Rec r;
                     r.off = p;
@@ -605,31 +778,62 @@ static void bam_record_to_sam(const uint8_t *at, const std::vector<std::string> 
     aux_to_text(r, s);
 }
 
-static void parse_bam(const char *d, uint64_t n, SamFile &out) {
-    Cur c{(const uint8_t *)d, (const uint8_t *)d + n};
-    if (memcmp(c.take(4), "BAM\1", 4) != 0) bail("Error reading BAM file: bad magic");
-    int32_t l_text = c.get<int32_t>();
+// BAM header + reference dictionary at d[0,n).  false: the bytes end inside it (take more input).
+static bool parse_bam_header(const char *d, uint64_t n, SamFile &out, uint64_t *end) {
+    const uint8_t *p = (const uint8_t *)d, *e = p + n;
+    auto need = [&](size_t k) { return (size_t)(e - p) >= k; };
+    if (!need(8)) return false;
+    if (memcmp(p, "BAM\1", 4) != 0) bail("Error reading BAM file: bad magic");
+    int32_t l_text;
+    memcpy(&l_text, p + 4, 4);
     if (l_text < 0) bail("Error during BAM record parsing: truncated file");
-    const uint8_t *text = c.take((size_t)l_text);
+    p += 8;
+    if (!need((size_t)l_text + 4)) return false;
     size_t tl = (size_t)l_text;
-    while (tl && text[tl - 1] == 0) --tl;
-    out.header.assign((const char *)text, tl);
+    while (tl && p[tl - 1] == 0) --tl;
+    out.header.assign((const char *)p, tl);
     if (!out.header.empty() && out.header.back() != '\n') out.header += '\n';
-    int32_t n_ref = c.get<int32_t>();
+    p += l_text;
+    int32_t n_ref;
+    memcpy(&n_ref, p, 4);
+    p += 4;
+    out.ref_names.clear();
+    out.ref_lens.clear();
     for (int32_t i = 0; i < n_ref; ++i) {
-        int32_t l_name = c.get<int32_t>();
+        if (!need(4)) return false;
+        int32_t l_name;
+        memcpy(&l_name, p, 4);
         if (l_name < 0) bail("Error during BAM record parsing: truncated file");
-        const uint8_t *nm = c.take((size_t)l_name);
-        out.ref_names.emplace_back((const char *)nm, l_name > 0 ? (size_t)l_name - 1 : 0);
-        out.ref_lens.push_back(c.get<uint32_t>());
+        if (!need(4 + (size_t)l_name + 4)) return false;
+        out.ref_names.emplace_back((const char *)p + 4, l_name > 0 ? (size_t)l_name - 1 : 0);
+        uint32_t l_ref;
+        memcpy(&l_ref, p + 4 + l_name, 4);
+        out.ref_lens.push_back(l_ref);
+        p += 4 + (size_t)l_name + 4;
     }
-    // records: a chain of block_size fields; the fixed part of each record is validated here so
-    // that later (parallel) accesses stay inside the record
-    while (c.p < c.e) {
-        const uint8_t *at = c.p;
-        const int32_t block = c.get<int32_t>();
+    *end = (uint64_t)((const char *)p - d);
+    return true;
+}
+
+// Records from d + from on: a chain of block_size fields; the fixed part of each record is validated here
+// so that later (parallel) accesses stay inside the record.  Stops after the record that crosses `soft_stop`
+// (window size) or in front of a record that does not end inside d[0,n) -- an error unless partial_ok.
+// Returns the offset behind the last record taken.
+static uint64_t parse_bam_records(const char *d, uint64_t n, uint64_t from, uint64_t soft_stop, bool partial_ok, SamFile &out) {
+    uint64_t p = from;
+    while (p < n && p < soft_stop) {
+        if (n - p < 4) {
+            if (partial_ok) break;
+            bail("Error during BAM record parsing: truncated file");
+        }
+        int32_t block;
+        memcpy(&block, d + p, 4);
         if (block < 32) bail("Error during BAM record parsing: truncated file");
-        const uint8_t *r = c.take((size_t)block);
+        if (n - p - 4 < (uint64_t)block) {
+            if (partial_ok) break;
+            bail("Error during BAM record parsing: truncated file");
+        }
+        const uint8_t *r = (const uint8_t *)d + p + 4;
         const uint8_t l_name = r[8];
         uint16_t n_cig;
         int32_t l_seq;
@@ -639,16 +843,18 @@ static void parse_bam(const char *d, uint64_t n, SamFile &out) {
         if (l_seq < 0 || fixed + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > (uint64_t)block)
             bail("Error during BAM record parsing: truncated file");
         SamFile::Rec rec;
-        rec.off = (uint64_t)((const char *)at - d);
+        rec.off = p;
         rec.len = (uint32_t)block + 4;
         rec.name_len = l_name ? l_name - 1u : 0u;
         rec.seq_off = rec.off + 4 + fixed;
         rec.l_seq = (uint32_t)l_seq;
         out.recs.push_back(rec);
+        p += 4 + (uint64_t)block;
     }
+    return p;
 }
 
-void SamFile::parse(const std::string &path) {
+void SamFile::open(const std::string &path) {
     const std::string ext = extension(path);
     if (ext.empty()) bail("Could not detect the file extension: \"" + path + "\"");
     if (ext != "sam" && ext != "bam") bail("Input file must be a BAM or SAM file.");
@@ -656,16 +862,94 @@ void SamFile::parse(const std::string &path) {
     recs.clear();
     ref_names.clear();
     ref_lens.clear();
-    io_mark(nullptr);
-    fb.load(path);  // mmap for plain SAM, (parallel) inflate for BAM / gzip
-    data = fb.p;
     is_bam = ext == "bam";
-    io_mark("load / inflate");
-    if (is_bam)
-        parse_bam(fb.p, fb.n, *this);
-    else
-        parse_sam_text(fb.p, fb.n, *this);
-    io_mark("record index");
+    src.open(path);
+    cursor = 0;
+    if (is_bam) {
+        uint64_t end = 0;
+        while (!parse_bam_header(src.data(), src.size(), *this, &end)) {
+            if (src.exhausted()) bail("Error during BAM record parsing: truncated file");
+            src.more(1u << 16);
+        }
+        cursor = end;
+    } else {
+        // header = the '@' lines in front of the first record (SAM spec 1.3); a compressed text needs them
+        // complete in the buffer first
+        for (;;) {
+            const char *d = src.data();
+            const uint64_t n = src.size();
+            uint64_t p = 0;
+            bool complete = false;
+            header.clear();
+            while (p < n) {
+                const uint64_t e = line_end(d, n, p);
+                if (e >= n && !src.exhausted()) break;  // the line may go on
+                const uint64_t le = strip_cr(d, p, e);
+                if (le > p && d[p] != '@') {
+                    complete = true;
+                    break;
+                }
+                if (le > p) {
+                    header.append(d + p, le - p);
+                    header += '\n';
+                }
+                p = std::min(e + 1, n);
+            }
+            if (complete || p >= n) {
+                if (complete || src.exhausted()) {
+                    cursor = p;
+                    break;
+                }
+            }
+            if (!src.more(1u << 16)) {
+                cursor = p;
+                break;
+            }
+        }
+    }
+    data = src.data();
+}
+
+bool SamFile::fill(uint64_t window_bytes) {
+    recs.clear();
+    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
+    if (!src.mapped()) {  // compressed: drop what became records, take more
+        src.drop_front(cursor);
+        cursor = 0;
+    }
+    for (;;) {
+        if (!src.mapped() && src.size() < window_bytes) src.more(window_bytes - src.size());
+        const char *d = src.data();
+        const uint64_t n = src.size();
+        data = d;
+        if (cursor >= n && src.exhausted()) return false;
+        if (is_bam) {
+            cursor = parse_bam_records(d, n, cursor, std::min<uint64_t>(n, cursor + window_bytes), !src.exhausted(), *this);
+        } else {
+            uint64_t stop;
+            if (src.mapped()) {
+                stop = std::min(n, cursor + window_bytes);
+                if (stop < n) stop = std::min(line_end(d, n, stop > 0 ? stop - 1 : 0) + 1, n);  // first line start at or after
+            } else {
+                stop = std::min(n, cursor + window_bytes);
+                if (stop < n) stop = std::min(line_end(d, n, stop > 0 ? stop - 1 : 0) + 1, n);  // first line start at or after
+                if (stop >= n && !src.exhausted()) {  // the last line of the buffer may go on: complete lines only
+                    stop = n;
+                    while (stop > cursor && d[stop - 1] != '\n') --stop;
+                }
+            }
+            if (stop > cursor) parse_sam_text(d, n, cursor, stop, false, *this);
+            cursor = stop;
+        }
+        if (!recs.empty()) return true;
+        if (src.exhausted() && cursor >= n) return false;
+        if (src.exhausted()) {  // bytes are left that are no record
+            if (is_bam) bail("Error during BAM record parsing: truncated file");
+            return false;
+        }
+        if (src.mapped()) continue;       // a window without records (blank lines): next one
+        src.more(std::max<uint64_t>(window_bytes, src.size()));  // one record larger than the window
+    }
 }
 
 void SamFile::gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const {

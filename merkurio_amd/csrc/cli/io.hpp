@@ -63,7 +63,8 @@ struct FileBytes {
 
 struct FastxFile {
     FileBytes file;
-    const char *data = nullptr;  // = file.p
+    const char *data = nullptr;  // = file.p (FastxStream: the current window)
+    uint64_t data_n = 0;         // bytes behind `data`
     bool fastq = false;
     struct Rec {
         uint64_t id_b, id_e;    // header line without the marker ('>' / '@') and line end
@@ -84,6 +85,62 @@ struct FastxFile {
     void write(size_t i, Sink &w) const;
 };
 
+// An input file as a sequence of (decompressed) bytes that is looked at through a sliding window, so that
+// the host holds one window at a time, like the reference, which streams records.  Plain files are
+// memory-mapped: the "window" is the whole mapping and costs nothing.  gzip is inflated incrementally
+// (zlib streaming, concatenated members included), BGZF a group of members at a time on all host
+// threads; bzip2 / xz / zstd inputs are inflated whole (their libraries are bound through dlopen without
+// any block index) and then behave like plain text.
+struct WindowSource {
+    void open(const std::string &path);
+    bool mapped() const { return kind == PLAIN; }  // data()/size() is the complete text
+    const char *data() const { return kind == PLAIN ? src.p : buf.data(); }
+    uint64_t size() const { return kind == PLAIN ? src.n : buf_len; }
+    // compressed kinds: the first k bytes of the buffer are done with
+    void drop_front(uint64_t k);
+    // compressed kinds: appends up to ~want more bytes (at least one member / some progress); false if the
+    // source was already exhausted
+    bool more(uint64_t want);
+    bool exhausted() const { return kind == PLAIN || src_eof; }
+    const std::string &name() const { return path; }
+    ~WindowSource();
+    WindowSource() = default;
+    WindowSource(const WindowSource &) = delete;
+    WindowSource &operator=(const WindowSource &) = delete;
+
+   private:
+    enum Kind { PLAIN, GZIP, BGZF } kind = PLAIN;
+    std::string path;
+    FileBytes src;  // the file as stored (PLAIN: the text itself, or inflated bzip2 / xz / zstd)
+    std::vector<char> buf;
+    uint64_t buf_len = 0;
+    bool src_eof = false;
+    void *zs = nullptr;    // GZIP: z_stream
+    uint64_t src_pos = 0;  // GZIP: next compressed byte; BGZF: next member
+    struct Member { uint64_t data_off, data_len; uint32_t isize, crc; };
+    std::vector<Member> members;
+};
+
+// A FASTA/FASTQ input read window by window (needletail's parse_fastx_file streams records:
+// src/cmd_extract.rs:281,321).
+// Usage: while (s.fill(W)) { ...records [0, s.view.recs.size()) of s.view...; s.consume(n); }
+struct FastxStream {
+    FastxFile view;  // the current window: view.data / view.recs / view.fastq; all FastxFile accessors work on it
+    void open(const std::string &path) { src.open(path); }
+    // Parses the next window: every complete record among the unconsumed bytes plus up to `window_bytes`
+    // new ones.  Returns false when no record is left.
+    bool fill(uint64_t window_bytes);
+    // The first n records of the window are done; fill() continues with record n.
+    void consume(size_t n);
+
+   private:
+    WindowSource src;
+    uint64_t cursor = 0;      // mapped text: next unconsumed byte; compressed: bytes to drop before the next fill
+    uint64_t parsed_end = 0;  // where the records of the current window end (offset in view.data)
+    bool started = false;
+    void parse_window(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool partial_ok);
+};
+
 // ---- SAM / BAM ------------------------------------------------------------------------------------
 // A whole SAM or BAM input held as ONE buffer (mmap of the text / inflated BAM); records are
 // index entries into it, nothing is copied or converted until it is needed: sequences are
@@ -92,8 +149,7 @@ struct FastxFile {
 // the raw record through with the new tag appended (as the reference's bam crate does).
 struct SamFile {
     std::string header;  // header text, every line '\n'-terminated
-    FileBytes fb;
-    const char *data = nullptr;  // = fb.p
+    const char *data = nullptr;  // the current window (whole text for a memory-mapped SAM)
     bool is_bam = false;
     std::vector<std::string> ref_names;  // BAM: reference dictionary of the binary header
     std::vector<uint32_t> ref_lens;
@@ -105,7 +161,12 @@ struct SamFile {
         uint32_t l_seq;    // bases ('*' -> 0)
     };
     std::vector<Rec> recs;
-    void parse(const std::string &path);  // by extension: "sam" / "bam" (src/cmd_tag.rs:503-615)
+    // A window of records at a time (the bam crate's readers stream records, src/cmd_tag.rs:515,567):
+    // open() (by extension: "sam" / "bam", src/cmd_tag.rs:503-615) reads the header and a BAM's reference
+    // dictionary, every fill() replaces `recs` by the next records worth ~window_bytes of input; `data`
+    // then points at that window.
+    void open(const std::string &path);
+    bool fill(uint64_t window_bytes);
     std::string name(size_t i) const { return std::string(data + recs[i].off + (is_bam ? 36 : 0), recs[i].name_len); }
     // SEQ of records [b0, b1) as the matcher sees it (upper-case ASCII), concatenated (+1 pad byte)
     void gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const;
@@ -117,6 +178,10 @@ struct SamFile {
     // value of an existing `tag` field: 0 = absent, 1 = Z value in *val, 2 = present with a
     // non-string type (the reference bails: "Invalid tag value format...")
     int find_tag(size_t i, const std::string &tag, std::string *val) const;
+
+   private:
+    WindowSource src;
+    uint64_t cursor = 0;  // mapped input: next unread byte; compressed: bytes of the window already turned into records
 };
 // BAM writer (BGZF): encodes SAM text lines against the header's @SQ dictionary.  Used for
 // `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.

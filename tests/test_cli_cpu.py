@@ -120,3 +120,122 @@ def test_bz2_xz_zstd_decoders(tmp_path, golden):
         assert f"1 {len(big)} bytes hash {fnv(big)}" in line, line
     for line in out[5:]:
         assert "error Error while decompressing" in line, line
+
+
+def test_windowed_fastx_reader(tmp_path):
+    """extract reads its input a window at a time (FastxStream): plain / gzip / multi-member gzip / BGZF /
+    bzip2, FASTA and FASTQ (quality lines that start with '@' and '+'), CRLF, no final newline -- every
+    window size and a partial consume must hand over exactly the records a whole-file parse sees;
+    a truncated gzip is an error."""
+    import bz2
+    import gzip
+    import random
+    import struct
+    import zlib
+    cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
+    exe = str(tmp_path / "fs")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/fastx_stream_harness.cpp"),
+                    os.path.join(cli_dir, "io.cpp"), os.path.join(cli_dir, "decompress.cpp"), os.path.join(cli_dir, "util.cpp"),
+                    "-lz", "-ldl", "-lpthread"], check=True)
+
+    def bgzf(data, block=0xff00):
+        out = bytearray()
+        for b in range(0, len(data), block):
+            chunk = data[b:b + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            c = co.compress(chunk) + co.flush()
+            out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(c) + 25)
+            out += c + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        return bytes(out) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+    rnd = random.Random(3)
+    recs = []
+    for i in range(6000):
+        L = rnd.choice([1, 50, 100, 151, 700])
+        recs.append((f"r{i} desc x", "".join(rnd.choice("ACGT") for _ in range(L)), "".join(rnd.choice("@+IJ#") for _ in range(L))))
+    fq = "".join(f"@{a}\n{s}\n+\n{q}\n" for a, s, q in recs).encode()
+    fa = "".join(f">{a}\n" + "\n".join(s[k:k + 60] for k in range(0, len(s), 60)) + "\n" for a, s, q in recs).encode()
+    half = fq.index(b"\n@r3000 ") + 1
+    files = {"x.fastq": fq, "x.fasta": fa, "x.fastq.gz": gzip.compress(fq, 1),
+             "multi.fastq.gz": gzip.compress(fq[:half], 1) + gzip.compress(fq[half:], 1), "b.fastq.gz": bgzf(fq),
+             "b.fasta.gz": bgzf(fa), "x.fastq.bz2": bz2.compress(fq), "crlf.fastq": fq.replace(b"\n", b"\r\n"),
+             "nonl.fastq": fq[:-1], "trunc.fastq.gz": gzip.compress(fq, 1)[:-100]}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    for name in files:
+        want = "".join(f"{a}\t{s}\t{q if 'fastq' in name else ''}\n" for a, s, q in recs)
+        for w, cap in ((1 << 16, None), (1 << 20, None), (1 << 30, None), (1 << 18, 777)):
+            out = subprocess.run([exe, str(tmp_path / name), str(w)] + ([str(cap)] if cap else []), capture_output=True, text=True).stdout
+            if name.startswith("trunc"):
+                assert "#error Error while decompressing" in out, (name, w)
+                continue
+            body, last = out.rsplit("#windows", 1)
+            assert body == want, (name, w, cap)
+            assert last.split()[2] == str(len(recs)) and (w >= 1 << 30) == (last.split()[0] == "1"), (name, w, last)
+
+
+def test_windowed_sam_bam_reader(tmp_path, golden):
+    """tag reads its input a window at a time (SamFile::open / fill): SAM text, BGZF BAM, a BAM written as ONE
+    gzip member, and an uncompressed BAM must yield the same header and records whatever the window size."""
+    import gzip
+    import random
+    import struct
+    import zlib
+    cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
+    exe = str(tmp_path / "ss")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/sam_stream_harness.cpp"),
+                    os.path.join(cli_dir, "io.cpp"), os.path.join(cli_dir, "decompress.cpp"), os.path.join(cli_dir, "util.cpp"),
+                    "-lz", "-ldl", "-lpthread"], check=True)
+    rnd = random.Random(9)
+    n = 8000
+    seqs = ["".join(rnd.choice("ACGTacgtN") for _ in range(rnd.choice((1, 36, 100, 151)))) for _ in range(n)]
+    header = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000\n@CO\t" + "x" * 300 + "\n"
+    sam = header + "".join(f"read{i}\t4\t*\t0\t0\t*\t*\t0\t0\t{s}\t{'I' * len(s)}" + ("\tkm:Z:OLD,VAL" if i % 97 == 0 else "") + "\tNM:i:3\n"
+                           for i, s in enumerate(seqs))
+    (tmp_path / "x.sam").write_text(sam)
+    # the same records as BAM (unmapped, no CIGAR), built by hand
+    nib = {c: v for c, v in zip("=ACMGRSVTWYHKDBN", range(16))}
+    body = bytearray()
+    for i, s in enumerate(seqs):
+        name = f"read{i}".encode() + b"\0"
+        packed = bytearray((len(s) + 1) // 2)
+        for k, ch in enumerate(s.upper()):
+            packed[k // 2] |= nib[ch] << (4 if k % 2 == 0 else 0)
+        aux = (b"kmZOLD,VAL\0" if i % 97 == 0 else b"") + b"NMC\x03"
+        rec = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, len(s), -1, -1, 0) + name + bytes(packed) + bytes([40] * len(s)) + aux
+        body += struct.pack("<i", len(rec)) + rec
+    ht = header.encode()
+    raw = b"BAM\x01" + struct.pack("<i", len(ht)) + ht + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<I", 1000) + bytes(body)
+
+    def bgzf(data, block=0xff00):
+        out = bytearray()
+        for b in range(0, len(data), block):
+            chunk = data[b:b + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            c = co.compress(chunk) + co.flush()
+            out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(c) + 25)
+            out += c + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        return bytes(out) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+    (tmp_path / "b.bam").write_bytes(bgzf(raw))
+    (tmp_path / "g.bam").write_bytes(gzip.compress(raw, 1))
+    (tmp_path / "u.bam").write_bytes(raw)
+    (tmp_path / "trunc.bam").write_bytes(bgzf(raw[:-7]))
+
+    def run_h(name, w):
+        return subprocess.run([exe, str(tmp_path / name), str(w)], capture_output=True, text=True).stdout
+
+    ref = {}
+    for name in ("x.sam", "b.bam", "g.bam", "u.bam"):
+        outs = [run_h(name, w) for w in (1 << 16, 1 << 19, 1 << 30)]
+        bodies = [o.rsplit("#windows", 1)[0] for o in outs]
+        assert bodies[0] == bodies[1] == bodies[2], name
+        assert outs[0].rsplit("#windows", 1)[1].split()[2] == str(n) and int(outs[0].rsplit("#windows", 1)[1].split()[0]) > 3, name
+        assert outs[2].rsplit("#windows", 1)[1].split()[0] == "1"
+        lines = bodies[0].split("\n")
+        assert "".join(l + "\n" for l in lines[:3]) == header
+        ref[name] = [l.split("\t|")[0] for l in lines[3:] if l]  # name, matcher's sequence, existing km value
+    # what the matcher sees: upper-case sequence; the three BAM containers agree with each other and with the SAM
+    want = [f"read{i}\t{s.upper()}\t" + ("1:OLD,VAL" if i % 97 == 0 else "0:") for i, s in enumerate(seqs)]
+    assert ref["x.sam"] == want and ref["b.bam"] == want and ref["g.bam"] == want and ref["u.bam"] == want
+    assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16)

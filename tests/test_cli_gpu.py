@@ -354,18 +354,24 @@ def test_tag_is_batched(tmp_path):
     for mb in ("1", "512"):
         for extra in ([], ["-m"]):
             o = tmp_path / f"o_{mb}_{len(extra)}.sam"
+            win = ["--window-mb", "1"] if mb == "1" else []  # the small-batch runs also read the input in 1 MB windows
             run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(o), "-l", str(tmp_path / "x.log"),
-                 "--batch-mb", mb, *extra])
+                 "--batch-mb", mb, *win, *extra])
             outs[(mb, len(extra))] = (sam_without_own_pg(o), open(tmp_path / "x.log", "rb").read().split(b"\n", 5)[5])
     assert outs[("1", 0)] == outs[("512", 0)] and outs[("1", 1)] == outs[("512", 1)]
     kept = [ln for ln in outs[("1", 1)][0] if ln and not ln.startswith(b"@")]
     assert 9000 < len(kept) < 40000 and all(b"\tkm:Z:" in ln for ln in kept)
     assert any(ln.endswith(b",OLD") or b",OLD," in ln or b"km:Z:OLD" in ln for ln in outs[("1", 0)][0])
-    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "a.bam"), "--batch-mb", "1"])
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "a.bam"), "--batch-mb", "1", "--window-mb", "1"])
     run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "b.bam"), "--batch-mb", "512"])
     import gzip
     a, b = (gzip.decompress(open(tmp_path / f, "rb").read()).split(b"\tVN:1.0.0\n", 1)[1] for f in ("a.bam", "b.bam"))
     assert a == b and len(a) > 40000 * 100  # everything after the @PG line: reference dictionary + records
+    # BAM input in windows (BGZF members inflated a group at a time), two GPUs per window: same records out
+    run(["tag", "-i", str(tmp_path / "a.bam"), "-s", "ZZZZZZ", "-t", "zz", "-o", str(tmp_path / "w1.sam"), "--window-mb", "1", "--gpus", "2"])
+    run(["tag", "-i", str(tmp_path / "a.bam"), "-s", "ZZZZZZ", "-t", "zz", "-o", str(tmp_path / "w2.sam")])
+    assert sam_without_own_pg(tmp_path / "w1.sam") == sam_without_own_pg(tmp_path / "w2.sam")
+    assert len(sam_without_own_pg(tmp_path / "w1.sam")) > 40000
 
 
 def test_crlf_records_keep_their_line_ending(tmp_path):
@@ -379,3 +385,56 @@ def test_crlf_records_keep_their_line_ending(tmp_path):
     (tmp_path / "crlf.fastq").write_bytes(fq)
     run(["extract", "-i", str(tmp_path / "crlf.fastq"), "-s", "GGGTTTA", "-o", str(tmp_path / "q")])
     assert (tmp_path / "q.fastq").read_bytes() == b"@q1\r\nACGTGGGTTTA\r\n+\r\nIIIIIIIIIII\r\n"
+
+
+def test_extract_reads_its_input_in_windows(tmp_path):
+    """extract holds one window of input at a time (--window-mb): many small windows, one big window and
+    two GPUs per window must give the same bytes, single and paired, plain and gzip; a pair-count
+    mismatch is reported after the common part was processed, with the reference's two messages"""
+    import gzip
+    import random
+    rnd = random.Random(17)
+    kmers = ["".join(rnd.choice("ACGT") for _ in range(25)) for _ in range(30)]
+    (tmp_path / "k.txt").write_text("\n".join(kmers) + "\n")
+
+    def reads(tag, n):
+        out = []
+        for i in range(n):
+            s = "".join(rnd.choice("ACGT") for _ in range(rnd.choice((60, 100, 151))))
+            if i % 11 == 0:
+                k = rnd.choice(kmers)
+                o = rnd.randrange(len(s) - 25)
+                s = s[:o] + k + s[o + 25:]
+            out.append(f"@p{i}/{tag}\n{s}\n+\n{'I' * len(s)}\n")
+        return out
+
+    r1, r2 = reads(1, 25000), reads(2, 25000)
+    (tmp_path / "a_1.fastq").write_text("".join(r1))
+    (tmp_path / "a_2.fastq").write_text("".join(r2))
+    (tmp_path / "g_1.fastq.gz").write_bytes(gzip.compress("".join(r1).encode(), 1))
+    (tmp_path / "g_2.fastq.gz").write_bytes(gzip.compress("".join(r2).encode(), 1))
+    res = {}
+    for name, f1, f2, extra in (("big", "a_1.fastq", "a_2.fastq", ["--window-mb", "1024"]),
+                                ("small", "a_1.fastq", "a_2.fastq", ["--window-mb", "1", "--batch-mb", "1"]),
+                                ("small-gz", "g_1.fastq.gz", "g_2.fastq.gz", ["--window-mb", "1"]),
+                                ("small-2gpu", "a_1.fastq", "a_2.fastq", ["--window-mb", "1", "--gpus", "2"])):
+        d = tmp_path / name
+        d.mkdir()
+        run(["extract", "-i", str(tmp_path / f1), "-2", str(tmp_path / f2), "-f", str(tmp_path / "k.txt"), "-r", "-o", str(d / "o"),
+             "-l", str(d / "x.log"), *extra])
+        body = log_body(d / "x.log").replace(b"g_1.fastq.gz\t", b"a_1.fastq\t").replace(b"g_2.fastq.gz\t", b"a_2.fastq\t")
+        res[name] = ((d / "o_1.fastq").read_bytes(), (d / "o_2.fastq").read_bytes(), body)
+    assert res["big"][0].count(b"\n") >= 4 * 2000
+    assert res["big"] == res["small"] == res["small-gz"] == res["small-2gpu"]
+    run(["extract", "-i", str(tmp_path / "a_1.fastq"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "s_big")])
+    run(["extract", "-i", str(tmp_path / "g_1.fastq.gz"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "s_small"), "--window-mb", "1"])
+    assert (tmp_path / "s_big.fastq").read_bytes() == (tmp_path / "s_small.fastq").read_bytes() != b""
+    # pair-count mismatches surface where the reference notices them: at the end of the shorter file
+    (tmp_path / "short_2.fastq").write_text("".join(r2[:-1]))
+    p = run(["extract", "-i", str(tmp_path / "a_1.fastq"), "-2", str(tmp_path / "short_2.fastq"), "-f", str(tmp_path / "k.txt"),
+             "-o", str(tmp_path / "m"), "--window-mb", "1"], check=False)
+    assert p.returncode == 1 and b"Error during FASTQ record parsing of second file" in p.stderr
+    (tmp_path / "short_1.fastq").write_text("".join(r1[:-3]))
+    p = run(["extract", "-i", str(tmp_path / "short_1.fastq"), "-2", str(tmp_path / "a_2.fastq"), "-f", str(tmp_path / "k.txt"),
+             "-o", str(tmp_path / "m2"), "--window-mb", "1"], check=False)
+    assert p.returncode == 1 and b"different number of records" in p.stderr
