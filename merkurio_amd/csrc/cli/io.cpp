@@ -473,14 +473,7 @@ void WindowSource::open(const std::string &p) {
     src.load(p);  // mmap; bzip2 / xz / zstd are inflated whole by magic
 }
 
-void WindowSource::drop_front(uint64_t k) {
-    if (kind == PLAIN || k == 0) return;
-    if (k > buf_len) k = buf_len;
-    memmove(buf.data(), buf.data() + k, buf_len - k);
-    buf_len -= k;
-}
-
-bool WindowSource::more(uint64_t want) {
+bool WindowSource::more_into(std::vector<char> &buf, uint64_t &buf_len, uint64_t want) {
     if (kind == PLAIN || src_eof) return false;
     if (want < (1u << 16)) want = 1u << 16;
     require_host_memory(buf_len + want + (buf_len + want) / 8, path);
@@ -532,20 +525,20 @@ bool WindowSource::more(uint64_t want) {
 }
 
 // ---- FastxStream: FASTA / FASTQ records, one window at a time -----------------------------------------
+// parses d[from, stop) into spare_recs (spare_data / spare_n / spare_end)
 void FastxStream::parse_window(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool partial_ok) {
-    view.data = d;
-    view.data_n = n;
-    view.recs.clear();
+    spare_data = d;
+    spare_n = n;
+    spare_recs.clear();
     uint64_t p = from;
     while (p < n && (d[p] == '\n' || d[p] == '\r')) ++p;
-    parsed_end = p;
+    spare_end = p;
     if (p >= n) return;
     if (!started) {
         if (d[p] != '>' && d[p] != '@') bail("Error during FASTQ/A record parsing.");
-        view.fastq = d[p] == '@';
+        fastq = d[p] == '@';
         started = true;
     }
-    const bool fastq = view.fastq;
     if (stop <= p) stop = std::min(n, p + 1);
     // split at record starts and parse the pieces on host threads
     const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)io_threads(), (stop - p) / (16u << 20) + 1));
@@ -562,40 +555,57 @@ void FastxStream::parse_window(const char *d, uint64_t n, uint64_t from, uint64_
     });
     size_t total = 0;
     for (auto &v : parts) total += v.size();
-    view.recs.reserve(total);
-    for (auto &v : parts) view.recs.insert(view.recs.end(), v.begin(), v.end());
-    parsed_end = ends[T - 1];
+    spare_recs.reserve(total);
+    for (auto &v : parts) spare_recs.insert(spare_recs.end(), v.begin(), v.end());
+    spare_end = ends[T - 1];
+}
+
+void FastxStream::prefetch(uint64_t window_bytes) {
+    if (have_spare) return;
+    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
+    if (src.mapped()) {
+        const uint64_t n = src.text_size();
+        // a record that starts inside the window is parsed completely (the text behind it is mapped too)
+        if (cursor < n)
+            parse_window(src.text(), n, cursor, std::min(n, cursor + window_bytes), false);
+        else
+            parse_window(src.text(), n, n, n, false);
+        have_spare = true;
+        return;
+    }
+    // compressed: the unconsumed tail of the current buffer opens the other one, then inflate until a
+    // complete record is in it
+    std::vector<char> &nb = bufs[cur ^ 1];
+    uint64_t &nl = lens[cur ^ 1];
+    const uint64_t tail = lens[cur] > cursor ? lens[cur] - cursor : 0;
+    if (nb.size() < tail) nb.resize(tail);
+    if (tail) memcpy(nb.data(), bufs[cur].data() + cursor, tail);
+    nl = tail;
+    uint64_t want = window_bytes > nl ? window_bytes - nl : 0;
+    for (;;) {
+        if (want) src.more_into(nb, nl, want);
+        parse_window(nb.data(), nl, 0, nl, !src.exhausted());
+        if (!spare_recs.empty() || src.exhausted()) break;
+        want = std::max<uint64_t>(window_bytes, nl);  // one record larger than the window: take more
+    }
+    have_spare = true;
 }
 
 bool FastxStream::fill(uint64_t window_bytes) {
-    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
-    if (src.mapped()) {
-        const uint64_t n = src.size();
-        if (cursor >= n) {
-            view.recs.clear();
-            return false;
-        }
-        // a record that starts inside the window is parsed completely (the text behind it is mapped too)
-        parse_window(src.data(), n, cursor, std::min(n, cursor + window_bytes), false);
-        return !view.recs.empty();
-    }
-    // compressed: unconsumed tail to the front, then inflate until a complete record is in the buffer
-    src.drop_front(cursor);
-    cursor = 0;
-    uint64_t want = window_bytes > src.size() ? window_bytes - src.size() : 0;
-    for (;;) {
-        if (want) src.more(want);
-        parse_window(src.data(), src.size(), 0, src.size(), !src.exhausted());
-        if (!view.recs.empty() || src.exhausted()) break;
-        want = std::max<uint64_t>(window_bytes, src.size());  // one record larger than the window: take more
-    }
+    prefetch(window_bytes);
+    have_spare = false;
+    view.recs.swap(spare_recs);
+    spare_recs.clear();
+    view.data = spare_data;
+    view.data_n = spare_n;
+    view.fastq = fastq;
+    cur_end = spare_end;
+    if (!src.mapped()) cur ^= 1;
+    cursor = cur_end;  // until consume() says otherwise: the whole window
     return !view.recs.empty();
 }
 
-void FastxStream::consume(size_t n) {
-    cursor = n < view.recs.size() ? view.recs[n].id_b - 1 : parsed_end;
-    view.recs.clear();
-}
+void FastxStream::consume(size_t n) { cursor = n < view.recs.size() ? view.recs[n].id_b - 1 : cur_end; }
 
 // ---- SAM / BAM ------------------------------------------------------------------------------------
 // SAM text: header lines ('@') may appear anywhere a line starts; records keep their file order.
@@ -867,17 +877,17 @@ void SamFile::open(const std::string &path) {
     cursor = 0;
     if (is_bam) {
         uint64_t end = 0;
-        while (!parse_bam_header(src.data(), src.size(), *this, &end)) {
+        while (!parse_bam_header(bytes(), n_bytes(), *this, &end)) {
             if (src.exhausted()) bail("Error during BAM record parsing: truncated file");
-            src.more(1u << 16);
+            src.more_into(buf, buf_len, 1u << 16);
         }
         cursor = end;
     } else {
         // header = the '@' lines in front of the first record (SAM spec 1.3); a compressed text needs them
         // complete in the buffer first
         for (;;) {
-            const char *d = src.data();
-            const uint64_t n = src.size();
+            const char *d = bytes();
+            const uint64_t n = n_bytes();
             uint64_t p = 0;
             bool complete = false;
             header.clear();
@@ -901,26 +911,33 @@ void SamFile::open(const std::string &path) {
                     break;
                 }
             }
-            if (!src.more(1u << 16)) {
+            if (!src.more_into(buf, buf_len, 1u << 16)) {
                 cursor = p;
                 break;
             }
         }
     }
-    data = src.data();
+    data = bytes();
+}
+
+void SamFile::drop_front(uint64_t k) {
+    if (src.mapped() || k == 0) return;
+    if (k > buf_len) k = buf_len;
+    memmove(buf.data(), buf.data() + k, buf_len - k);
+    buf_len -= k;
 }
 
 bool SamFile::fill(uint64_t window_bytes) {
     recs.clear();
     if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
     if (!src.mapped()) {  // compressed: drop what became records, take more
-        src.drop_front(cursor);
+        drop_front(cursor);
         cursor = 0;
     }
     for (;;) {
-        if (!src.mapped() && src.size() < window_bytes) src.more(window_bytes - src.size());
-        const char *d = src.data();
-        const uint64_t n = src.size();
+        if (!src.mapped() && buf_len < window_bytes) src.more_into(buf, buf_len, window_bytes - buf_len);
+        const char *d = bytes();
+        const uint64_t n = n_bytes();
         data = d;
         if (cursor >= n && src.exhausted()) return false;
         if (is_bam) {
@@ -948,7 +965,7 @@ bool SamFile::fill(uint64_t window_bytes) {
             return false;
         }
         if (src.mapped()) continue;       // a window without records (blank lines): next one
-        src.more(std::max<uint64_t>(window_bytes, src.size()));  // one record larger than the window
+        src.more_into(buf, buf_len, std::max<uint64_t>(window_bytes, buf_len));  // one record larger than the window
     }
 }
 

@@ -93,14 +93,12 @@ struct FastxFile {
 // any block index) and then behave like plain text.
 struct WindowSource {
     void open(const std::string &path);
-    bool mapped() const { return kind == PLAIN; }  // data()/size() is the complete text
-    const char *data() const { return kind == PLAIN ? src.p : buf.data(); }
-    uint64_t size() const { return kind == PLAIN ? src.n : buf_len; }
-    // compressed kinds: the first k bytes of the buffer are done with
-    void drop_front(uint64_t k);
-    // compressed kinds: appends up to ~want more bytes (at least one member / some progress); false if the
-    // source was already exhausted
-    bool more(uint64_t want);
+    bool mapped() const { return kind == PLAIN; }  // text()/text_size() is the complete text
+    const char *text() const { return src.p; }
+    uint64_t text_size() const { return src.n; }
+    // compressed kinds: appends up to ~want more inflated bytes to dst[0,len) (some progress unless the
+    // source is exhausted); false if it already was
+    bool more_into(std::vector<char> &dst, uint64_t &len, uint64_t want);
     bool exhausted() const { return kind == PLAIN || src_eof; }
     const std::string &name() const { return path; }
     ~WindowSource();
@@ -112,8 +110,6 @@ struct WindowSource {
     enum Kind { PLAIN, GZIP, BGZF } kind = PLAIN;
     std::string path;
     FileBytes src;  // the file as stored (PLAIN: the text itself, or inflated bzip2 / xz / zstd)
-    std::vector<char> buf;
-    uint64_t buf_len = 0;
     bool src_eof = false;
     void *zs = nullptr;    // GZIP: z_stream
     uint64_t src_pos = 0;  // GZIP: next compressed byte; BGZF: next member
@@ -122,22 +118,34 @@ struct WindowSource {
 };
 
 // A FASTA/FASTQ input read window by window (needletail's parse_fastx_file streams records:
-// src/cmd_extract.rs:281,321).
-// Usage: while (s.fill(W)) { ...records [0, s.view.recs.size()) of s.view...; s.consume(n); }
+// src/cmd_extract.rs:281,321), with the next window parsed (and inflated) while the current one is in use:
+//     bool more = s.fill(W);
+//     while (more) { n = s.view.recs.size(); s.consume(n); s.prefetch(W) on another thread;
+//                    ...records [0, n) of s.view...; join; more = s.fill(W); }
 struct FastxStream {
     FastxFile view;  // the current window: view.data / view.recs / view.fastq; all FastxFile accessors work on it
     void open(const std::string &path) { src.open(path); }
-    // Parses the next window: every complete record among the unconsumed bytes plus up to `window_bytes`
-    // new ones.  Returns false when no record is left.
+    // Makes the next window current: every complete record among the unconsumed bytes plus up to
+    // `window_bytes` new ones (parsed here unless prefetch() already did).  false: no record is left.
     bool fill(uint64_t window_bytes);
-    // The first n records of the window are done; fill() continues with record n.
+    // The first n records of the current window are all this window hands out; the next window starts
+    // with record n.  The records stay valid until the next fill().
     void consume(size_t n);
+    // Parses the window behind the consumed records into a spare index (and, for compressed input, a second
+    // buffer); may run on another thread while `view` is being used.  Call after consume().
+    void prefetch(uint64_t window_bytes);
 
    private:
     WindowSource src;
-    uint64_t cursor = 0;      // mapped text: next unconsumed byte; compressed: bytes to drop before the next fill
-    uint64_t parsed_end = 0;  // where the records of the current window end (offset in view.data)
-    bool started = false;
+    uint64_t cursor = 0;  // mapped text: first byte of the next window; compressed: offset of the unconsumed tail in bufs[cur]
+    bool started = false, fastq = false;
+    std::vector<char> bufs[2];  // compressed input: the current window lives in bufs[cur]
+    uint64_t lens[2] = {0, 0};
+    int cur = 0;
+    bool have_spare = false;
+    std::vector<FastxFile::Rec> spare_recs;
+    const char *spare_data = nullptr;
+    uint64_t spare_n = 0, spare_end = 0, cur_end = 0;  // *_end: where the records of a window end
     void parse_window(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool partial_ok);
 };
 
@@ -181,7 +189,12 @@ struct SamFile {
 
    private:
     WindowSource src;
-    uint64_t cursor = 0;  // mapped input: next unread byte; compressed: bytes of the window already turned into records
+    std::vector<char> buf;  // compressed input: the window
+    uint64_t buf_len = 0;
+    uint64_t cursor = 0;    // mapped input: next unread byte; compressed: bytes of the window already turned into records
+    const char *bytes() const { return src.mapped() ? src.text() : buf.data(); }
+    uint64_t n_bytes() const { return src.mapped() ? src.text_size() : buf_len; }
+    void drop_front(uint64_t k);
 };
 // BAM writer (BGZF): encodes SAM text lines against the header's @SQ dictionary.  Used for
 // `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.
