@@ -600,12 +600,20 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         for (auto &b : o.bin) bw.put_encoded(b);
         for (auto &t : o.txt) w.write(t);
     };
-    auto scan_range = [&](mk_matcher *mm, size_t r0, size_t r1, mk_counters &cc, std::vector<uint32_t> &cnts, size_t enc_threads,
-                          auto on_batch) {
+    // scan buffers of one device thread, reused by every batch of every window
+    struct TagBuffers {
         std::vector<uint8_t> seq, keep;
         std::vector<uint64_t> off, foff;
-        std::vector<uint32_t> fpat(1024);
-        std::vector<mk_row> rows(4096);
+        std::vector<uint32_t> fpat = std::vector<uint32_t>(1024);
+        std::vector<mk_row> rows = std::vector<mk_row>(4096);
+    };
+    std::vector<TagBuffers> dev_bufs(ms.size());
+    auto scan_range = [&](mk_matcher *mm, TagBuffers &TB, size_t r0, size_t r1, mk_counters &cc, std::vector<uint32_t> &cnts,
+                          size_t enc_threads, auto on_batch) {
+        std::vector<uint8_t> &seq = TB.seq, &keep = TB.keep;
+        std::vector<uint64_t> &off = TB.off, &foff = TB.foff;
+        std::vector<uint32_t> &fpat = TB.fpat;
+        std::vector<mk_row> &rows = TB.rows;
         for (size_t b0 = r0; b0 < r1;) {
             size_t b1 = b0;
             uint64_t bytes = 0;
@@ -703,7 +711,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     while (sam.fill(window_bytes)) {
         const size_t n = sam.recs.size();
         if (ms.size() == 1) {
-            scan_range(m, 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
+            scan_range(m, dev_bufs[0], 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
                 emit(o);
                 tm.mark("batch: gather + scan + tag + write");
             });
@@ -713,7 +721,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
             std::vector<std::vector<BatchOut>> outs(ms.size());
             run_threads(ms.size(), [&](size_t d) {
                 auto [lo, hi] = shard_range(n, ms.size(), d);
-                scan_range(ms[d], lo, hi, dev_c[d], dev_counts[d], std::max<size_t>(1, io_threads() / ms.size()),
+                scan_range(ms[d], dev_bufs[d], lo, hi, dev_c[d], dev_counts[d], std::max<size_t>(1, io_threads() / ms.size()),
                            [&](BatchOut &&o) { outs[d].push_back(std::move(o)); });
             });
             tm.mark("window: scan + tag on all devices");

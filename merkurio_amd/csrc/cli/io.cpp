@@ -221,10 +221,12 @@ void FileBytes::load(const std::string &path) {
     struct stat st;
     const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (!gz && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-        const char *pop = getenv("MERKURIO_MMAP_POPULATE");  // tuning hook
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | ((pop && atoi(pop) == 0) ? 0 : MAP_POPULATE), fd, 0);
+        // no MAP_POPULATE: the inputs are read a window at a time; the reader asks for each window ahead of
+        // its parse (FastxStream::prefetch, SamFile::fill), the kernel reads ahead sequentially
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m != MAP_FAILED) {
             close(fd);
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
             map = m;
             map_len = (uint64_t)st.st_size;
             p = (const char *)m;
@@ -329,44 +331,6 @@ static uint64_t next_record_start(const char *d, uint64_t n, uint64_t from, bool
         p = std::min(line_end(d, n, p) + 1, n);
     }
     return n;
-}
-
-void FastxFile::parse(const std::string &path) {
-    file.load(path);
-    data = file.p;
-    const uint64_t n = file.n;
-    data_n = n;
-    recs.clear();
-    uint64_t p = 0;
-    while (p < n && (data[p] == '\n' || data[p] == '\r')) ++p;
-    if (p >= n) return;
-    if (data[p] != '>' && data[p] != '@') bail("Error during FASTQ/A record parsing.");
-    fastq = data[p] == '@';
-    // split at record starts and parse the pieces on host threads (the ingest side of the hot path)
-    uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)io_threads(), n / (16u << 20) + 1));
-    std::vector<uint64_t> cut(T + 1);
-    cut[0] = p;
-    cut[T] = n;
-    for (uint64_t t = 1; t < T; ++t) cut[t] = std::max(cut[t - 1], next_record_start(data, n, p + (n - p) * t / T, fastq));
-    std::vector<std::vector<Rec>> parts(T);
-    std::vector<std::string> errs(T);
-    std::vector<std::thread> th;
-    for (uint64_t t = 0; t < T; ++t)
-        th.emplace_back([&, t] {
-            try {
-                parts[t].reserve((cut[t + 1] - cut[t]) / 200 + 16);
-                parse_fastx_range(data, n, cut[t], cut[t + 1], fastq, parts[t]);
-            } catch (const Error &e) {
-                errs[t] = e.what();
-            }
-        });
-    for (auto &x : th) x.join();
-    for (auto &e : errs)
-        if (!e.empty()) bail(e);
-    size_t total = 0;
-    for (auto &v : parts) total += v.size();
-    recs.reserve(total);
-    for (auto &v : parts) recs.insert(recs.end(), v.begin(), v.end());
 }
 
 uint64_t FastxFile::append_seq(size_t i, std::vector<uint8_t> &out) const {
@@ -566,8 +530,11 @@ void FastxStream::prefetch(uint64_t window_bytes) {
     if (src.mapped()) {
         const uint64_t n = src.text_size();
         // a record that starts inside the window is parsed completely (the text behind it is mapped too)
-        if (cursor < n)
+        if (cursor < n) {
+            const uint64_t a0 = cursor & ~(uint64_t)4095;  // page-aligned hint: this window's pages, now
+            (void)madvise(const_cast<char *>(src.text()) + a0, (size_t)(std::min(n, cursor + window_bytes + (1u << 20)) - a0), MADV_WILLNEED);
             parse_window(src.text(), n, cursor, std::min(n, cursor + window_bytes), false);
+        }
         else
             parse_window(src.text(), n, n, n, false);
         have_spare = true;

@@ -72,7 +72,6 @@ struct FastxFile {
         uint64_t qual_b, qual_e;
     };
     std::vector<Rec> recs;
-    void parse(const std::string &path);
     std::string id(size_t i) const { return std::string(data + recs[i].id_b, recs[i].id_e - recs[i].id_b); }
     // record.seq(): newline-free sequence appended to `out`; returns num_bases()
     uint64_t append_seq(size_t i, std::vector<uint8_t> &out) const;
