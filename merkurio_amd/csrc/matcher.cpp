@@ -495,6 +495,11 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
     const uint64_t base = seq_off[0];
     const uint64_t n_bytes = seq_off[n_rec] - base;
     if (n_bytes && !seq_bytes) return fail(MK_E_INVALID_ARG, "null sequence buffer");
+    if (n_bytes >= (1ull << 32))  // mk_hit.pos is 32 bits: refuse a record it cannot address instead of wrapping
+        for (uint64_t i = 0; i < n_rec; ++i)
+            if (seq_off[i + 1] - seq_off[i] >= (1ull << 32))
+                return fail(MK_E_UNSUPPORTED, "record %llu is %llu bytes long: a single record must be shorter than 4 GiB",
+                            (unsigned long long)i, (unsigned long long)(seq_off[i + 1] - seq_off[i]));
     MK_ABI_BEGIN
     MK_HIP(hipSetDevice(m->device));
     int rc;
