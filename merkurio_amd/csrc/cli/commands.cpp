@@ -529,6 +529,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     const std::string in_name = file_name(a.in_file);
     Patterns pats = load_patterns(a);
     if (a.threads < 1) bail("Number of threads must be at least 1.");
+    if (a.threads_given) set_io_threads_cap((unsigned)a.threads);
     if (a.tag.size() != 2) bail("Tag must be exactly two characters long.");
     Loggers lg;
     open_loggers(a, lg);

@@ -41,6 +41,7 @@ struct TagArgs : CommonArgs {
     std::optional<std::string> out_file;  // -o
     std::string tag = "km";               // -t
     int threads = 1;                      // -p
+    bool threads_given = false;           // -p on the command line: caps the codec threads (default: all cores)
     bool filter_matching = false;         // -m
 };
 

@@ -15,6 +15,9 @@
 namespace cli {
 
 
+static unsigned g_io_threads_cap = 0;  // 0 = no cap
+void set_io_threads_cap(unsigned n) { g_io_threads_cap = n; }
+
 unsigned io_threads() {
     static const unsigned cached = [] {
         if (const char *e = getenv("MERKURIO_IO_THREADS")) return (unsigned)std::max(1, atoi(e));
@@ -32,7 +35,7 @@ unsigned io_threads() {
         if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
         return std::min(hw, 32u);
     }();
-    return cached;
+    return g_io_threads_cap ? std::min(cached, g_io_threads_cap) : cached;
 }
 
 // Host memory this process may still take: MemAvailable, capped by the cgroup limit.  0 = unknown.

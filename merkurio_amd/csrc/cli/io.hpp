@@ -14,6 +14,9 @@ namespace cli {
 
 // host threads for ingest / codec work: hardware concurrency, capped at 32, MERKURIO_IO_THREADS overrides
 unsigned io_threads();
+// `tag -p N` given explicitly: at most N host threads for the codec work (the reference's meaning of -p:
+// BAM (de)compression threads, src/cmd_tag.rs:102-104,506); without it every core the process may use
+void set_io_threads_cap(unsigned n);
 
 // runs fn(t) for t in [0, T) on T host threads; the first cli::Error is re-raised on the caller
 template <class F>

@@ -52,7 +52,7 @@ void print_help(const char *sub) {
              "  -i, --in-file <PATH>         SAM/BAM input\n  -o, --out-file <PATH>        SAM output (stdout if absent)\n"
              "  -s, --kmer-seq <SEQ>... | -f, --kmer-file <PATH>\n  -t, --tag <TAG>              two-character tag [km]\n"
              "  -m, --filter-matching        keep only records with a hit\n  -v, --invert-match           keep only records without a hit\n"
-             "  -p, --threads <N>            accepted for compatibility\n  -r -c -l -j -S -I -L -U -q -a --device --gpus --batch-mb  as for extract");
+             "  -p, --threads <N>            at most N host threads for the BAM/SAM codec work [all cores]\n  -r -c -l -j -S -I -L -U -q -a --device --gpus --batch-mb  as for extract");
     }
 }
 
@@ -229,7 +229,10 @@ int main(int argc, char **argv) {
             a.in_file = (*in)[0];
             if (auto v = p.get("out-file")) a.out_file = (*v)[0];
             if (auto v = p.get("tag")) a.tag = (*v)[0];
-            if (auto v = p.get("threads")) a.threads = (int)to_num((*v)[0], "--threads <THREADS>");
+            if (auto v = p.get("threads")) {
+                a.threads = (int)to_num((*v)[0], "--threads <THREADS>");
+                a.threads_given = true;
+            }
             a.filter_matching = p.get("filter-matching") != nullptr;
             fill_common(p, a, (bool)a.out_file);
             if (a.filter_matching && a.invert_match)
