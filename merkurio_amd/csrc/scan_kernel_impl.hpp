@@ -102,7 +102,12 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     // index (reads are mostly of similar length, so the guess is usually right) and the four
     // 8-byte text / pattern loads of the comparison.
     const uint64_t n = P.n_rec;
-    uint64_t lo = (uint64_t)((double)p * P.rec_per_byte);
+    // + 1e-6: with equal-length records the quotient of a record's FIRST byte is an integer, and the rounded
+    // factor n_rec / n_bytes can land it a hair below -- the guess is then one record short and the wave
+    // walks the gallop / bisect path (4-5 dependent memory round trips) for it: 0.8 % of the occurrences,
+    // i.e. 4 of 10 drains of 64.  The nudge is far below 1 / record length and above the rounding error
+    // for up to ~10^10 records.
+    uint64_t lo = (uint64_t)((double)p * P.rec_per_byte + 1e-6);
     if (lo >= n) lo = n - 1;
     uint64_t rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];  // seq_off[0] == 0 is part of the ABI
     if (P.case_insensitive) {
@@ -661,8 +666,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         };
         // Queued filter positives carry only the low 32 bits of their position, restored relative to
         // the wave's current position: none may stay queued while the wave advances 4 GiB.  A wave's
-        // runs of tiles are n_waves * run * 31 KiB apart, so after every 1 GiB of advance whatever
-        // is parked or queued is pushed on to level 2 (sparse candidates never reach the ring's
+        // runs of tiles are n_waves * run * 31 KiB <= 1 GiB apart, so after every 1 GiB of advance whatever
+        // is parked or queued is pushed on to level 2.  (Not 2 GiB: a push that finds a probe still pending
+        // leaves the queued candidates for the NEXT push, and two intervals must stay below 4 GiB -- r02,
+        // test_sparse_candidates_full_size caught exactly that.)  (Sparse candidates never reach the ring's
         // fill threshold by themselves: 1 pattern on 15 GB lost two hits in three before this).
         uint64_t last_push_base = 0;
         uint32_t sc_run = 0;
