@@ -12,8 +12,8 @@
 //   * one persistent 1024-thread workgroup per CU (16 waves); level 1, the 128 KiB blocked
 //     q-gram Bloom filter of the pattern set, lives in LDS for the life of the workgroup
 //     (pattern sets too large for it use the same filter layout in global memory / L2: GF);
-//   * the concatenated text is cut into 31 KiB tiles dealt round-robin to the 4096 waves; a wave
-//     walks a tile in 1 KiB chunks: each lane issues ONE non-temporal global_load_dwordx4
+//   * the concatenated text is cut into 31 KiB tiles dealt to the 4096 waves in short runs (1, 2 or 4
+//     consecutive tiles, then a jump of n_waves runs); a wave walks a tile in 1 KiB chunks: each lane issues ONE non-temporal global_load_dwordx4
 //     (64 lanes x 16 B, fully coalesced) per chunk, four chunks (one group) are in flight while
 //     the previous group is filtered;
 //   * a lane 2-bit-packs its 16 bytes into one dword (11 VALU ops), gets the 32-base halo from
@@ -24,11 +24,13 @@
 //     fills, 64 candidates at a time go through level 2 (bucketised exact table in L2, loads
 //     issued at the end of one group and consumed at the top of the next) and level 3
 //     (byte-exact compare, record lookup, boundary check) with all 64 lanes busy;
-//   * results: one byte store per hit record (flags), per-pattern counters (LDS for tiny sets,
-//     global atomics otherwise), optional (record, pattern, position) tuples staged through a
-//     per-wave ring so the output cursor sees one atomic per 64 hits.
+//   * results: one byte store per hit record (flags), optional (record, pattern, position) tuples
+//     staged through a per-wave buffer so the output cursor sees one atomic per ~1000 hits, summary
+//     counters summed per workgroup (one global atomic per workgroup and counter); occurrences per
+//     pattern are counted from the tuples afterwards (mk_hist_hits_kernel, scan_kernel.hip);
+//   * global-filter kernels with a compile-time q also carry 14 context bases with each candidate
+//     and fingerprint level 2 with them (filter.hpp: context fingerprints).
 #include <algorithm>
-#include <type_traits>
 
 #include "scan_kernel.h"
 
