@@ -244,7 +244,8 @@ def main():
         # ranks agree before any of them enters the collective init: none may wait for a peer
         # that has already given up
         buf = np.zeros(mk.MK_COMM_ID_BYTES, dtype=np.uint8)
-        ok = torch.tensor([1 if lib.mk_comm_unique_id(buf.ctypes.data) == 0 else 0], dtype=torch.int32, device=dev)
+        rc0 = lib.mk_comm_unique_id(buf.ctypes.data) if rank == 0 else lib.mk_comm_available()
+        ok = torch.tensor([1 if rc0 == 0 else 0], dtype=torch.int32, device=dev)
         why = "" if int(ok.item()) else lib.mk_last_error().decode()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:

@@ -299,6 +299,8 @@ int mk_synth_reads_device_range(mk_matcher *m, uint64_t seed, uint64_t rec0, uin
  * ---------------------------------------------------------------------------------- */
 #define MK_COMM_ID_BYTES 128
 int mk_reduce_counters(mk_matcher *const *per_gpu, int n, void *const *d_counters, size_t len, uint64_t *host_sum);
+/* MK_OK if librccl could be bound in this process (ranks other than 0 can check before the collective init) */
+int mk_comm_available(void);
 int mk_comm_unique_id(uint8_t id[MK_COMM_ID_BYTES]);
 int mk_comm_init(mk_matcher *m, const uint8_t id[MK_COMM_ID_BYTES], int rank, int n_ranks);
 int mk_comm_reduce_counters(mk_matcher *m, void *d_counters, size_t len, void *stream);

@@ -189,6 +189,11 @@ int mk_reduce_counters(mk_matcher *const *per_gpu, int n, void *const *d_counter
     MK_ABI_END
 }
 
+int mk_comm_available(void) {
+    if (!rccl()) return fail(MK_E_RCCL, "%s", g_rccl.why);
+    return MK_OK;
+}
+
 int mk_comm_unique_id(uint8_t id[MK_COMM_ID_BYTES]) {
     if (!id) return fail(MK_E_INVALID_ARG, "null id");
     Rccl *R = rccl();

@@ -49,7 +49,7 @@ EXPORTS = [
     "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
-    "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_unique_id", "mk_comm_init",
+    "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_destroy",
 ]
 

@@ -162,6 +162,7 @@ def test_comm_single_rank_c_abi():
     patterns, _ = _workload(seed=13, n_rec=1, n_pat=20)
     m = mk.Matcher(patterns, device=0)
     idb = np.zeros(mk.MK_COMM_ID_BYTES, dtype=np.uint8)
+    assert lib.mk_comm_available() == 0, lib.mk_last_error()
     assert lib.mk_comm_unique_id(idb.ctypes.data) == 0, lib.mk_last_error()
     assert idb.any()
     assert lib.mk_comm_init(m.handle, idb.ctypes.data, 0, 1) == 0, lib.mk_last_error()
