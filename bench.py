@@ -107,6 +107,10 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["any", "hits"], default="any",
                     help="any = per-record flags (extract without logging, the headline); hits = also emit every "
                          "(record, pattern, position) tuple (extract/tag with logging)")
+    ap.add_argument("--ragged", type=int, default=0, metavar="SPREAD",
+                    help="diagnostic: record lengths uniform in [read_len - SPREAD, read_len + SPREAD] over the same bytes "
+                         "(trimmed reads: the record lookup of a verified occurrence can no longer guess its index)")
+    ap.add_argument("--no-rec-index", action="store_true", help="diagnostic with --ragged: do not tell the library that lengths vary")
     ap.add_argument("--no-counters", action="store_true", help="diagnostic: scan without the device counter vector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -139,6 +143,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse_args()
+    if args.ragged and (args.paired or args.ragged >= args.read_len):
+        raise SystemExit("--ragged SPREAD: single-end only, SPREAD < --read-len")
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env != args.gpus:
         if "RANK" in os.environ:
@@ -182,6 +188,8 @@ def main():
     m = mk.Matcher(patterns, device=dev_index, options=options)
     assert m.use_ac == mk.recommend_aho_corasick(patterns)
     lib = mk.load()
+    if args.ragged and not args.no_rec_index:
+        mk._check(lib.mk_matcher_hint_record_lengths(m.handle, 0))
 
     # ---- this rank's shard of the job: contiguous range of records (pairs), in units of 16 so
     # that every shard starts on a block of the counter-based generator
@@ -208,7 +216,18 @@ def main():
         rc = lib.mk_synth_reads_device_range(m.handle, seed + f, lo, n_rec, L, args.plant_every, d_seq.data_ptr(),
                                              d_off.data_ptr(), st)
         assert rc == 0, lib.mk_last_error()
+        if args.ragged:  # same bytes, cut into records of random length; the batch ends with the last whole record
+            g = torch.Generator(device="cpu").manual_seed(1234 + f)
+            lens = torch.randint(L - args.ragged, L + args.ragged + 1, (n_rec,), generator=g, dtype=torch.int64)
+            off = torch.zeros(n_rec + 1, dtype=torch.int64)
+            torch.cumsum(lens, 0, out=off[1:])
+            keep = int(torch.searchsorted(off, torch.tensor([n_bytes]), right=True).item()) - 1
+            ragged_shape = (keep, int(off[keep].item()))
+            d_off = off[:keep + 1].to(dev)
         mates.append((d_seq, d_off, d_flags))
+    if args.ragged:
+        n_rec, n_bytes = ragged_shape
+        total = n_rec * world
     d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
     d_cnt = torch.zeros(len(patterns) + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
     d_keep = torch.empty_like(mates[0][2]) if args.paired else None
@@ -302,12 +321,12 @@ def main():
     summ = cnt[len(patterns):]
 
     if rank == 0:
-        total_bases = total * n_mates * L * args.steps
+        total_bases = (n_bytes * world if args.ragged else total * L) * n_mates * args.steps
         value = total_bases / dt / 1e9
         k_avg_ms = float(np.mean(kernel_ms))
         algo_bytes = n_bytes * 1 + n_rec * 9  # 1 B/base + u64 offset + 1 B flag per record, per launch
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
-        job_bytes = (total * n_mates) * (L + 9) * args.steps
+        job_bytes = ((n_bytes + 9 * n_rec) * world if args.ragged else total * (L + 9)) * n_mates * args.steps
         info = dict(m.filter_info(), **m.filter_mode())
         what = "pairs" if args.paired else "reads"
         out = {
@@ -356,7 +375,7 @@ def main():
             out["rehearsal"] = True
             out["rehearsal_note"] = f"{world} ranks share {n_dev} GPU(s): functional check, not a scaling measurement"
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, len(patterns))
-        if world == 1 and not args.no_cpu_baseline and not args.paired:
+        if world == 1 and not args.no_cpu_baseline and not args.paired and not args.ragged:
             out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, mates[0][2],
                                                args.cpu_seconds)
         print(json.dumps(out), flush=True)

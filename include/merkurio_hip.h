@@ -217,6 +217,12 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
  * and the driver-loop entry points maintain the value themselves from the batch they have just scanned. */
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000);
 
+/* Second hint for mk_scan_device: do the records of the batches differ in length (trimmed reads)?  With
+ * equal_lengths == 0 every scan first builds a coarse record index (one entry per 64 KiB of text) for the
+ * record lookup of verified occurrences; with 1 (the default) the index of a record is estimated from its
+ * position, which is exact for equal lengths and merely slower otherwise.  mk_scan_batch decides by itself. */
+int mk_matcher_hint_record_lengths(mk_matcher *m, int equal_lengths);
+
 /* Sort hits (host memory) into the reference's emission order for this matcher. */
 int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);
 

@@ -311,7 +311,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_stage})
+                    (void *)m->d_stage, (void *)m->d_rec_index})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -387,6 +387,13 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     // keep runs short so that every wave still gets tiles
     const uint64_t tiles_per_wave = n_tiles / (blocks * waves_per_block);
     p.tile_run = m->tile_run ? m->tile_run : tiles_per_wave >= 16 ? 4 : tiles_per_wave >= 8 ? 2 : 1;
+    p.rec_index = nullptr;
+    if (m->ragged && n_rec < (1ull << 32)) {  // coarse record index: one entry per 64 KiB of text, built per scan
+        int rc_i = ensure((void **)&m->d_rec_index, &m->d_rec_index_cap, ((n_bytes >> kRecIndexShift) + 2) * sizeof(uint32_t));
+        if (rc_i) return rc_i;
+        launch_rec_index(p.rec_off, n_rec, n_bytes, m->d_rec_index, st);
+        p.rec_index = m->d_rec_index;
+    }
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
     if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
@@ -415,6 +422,12 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     m->hit_density_pm = records_hit_per_1000 > 1000 ? 1000 : records_hit_per_1000;
+    return MK_OK;
+}
+
+int mk_matcher_hint_record_lengths(mk_matcher *m, int equal_lengths) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    m->ragged = !equal_lengths;
     return MK_OK;
 }
 
@@ -506,6 +519,12 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
     if ((rc = ensure((void **)&m->d_seq, &m->d_seq_cap, n_bytes + 64))) return rc;
     if ((rc = ensure((void **)&m->d_off, &m->d_off_cap, (n_rec + 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure((void **)&m->d_flags, &m->d_flags_cap, n_rec + 8))) return rc;
+    {  // records of unequal length get a coarse index for the record lookup of verified occurrences
+        const uint64_t len0 = seq_off[1] - seq_off[0];
+        bool equal = true;
+        for (uint64_t i = 1; i < n_rec && equal; ++i) equal = seq_off[i + 1] - seq_off[i] == len0;
+        m->ragged = !equal;
+    }
     std::vector<uint64_t> rel;
     const uint64_t *off_src = seq_off;
     if (base != 0) {  // device offsets are relative to the first byte uploaded

@@ -27,6 +27,11 @@ struct mk_matcher {
     // records with a hit per 1000 records, as last observed by mk_scan_batch or told by
     // mk_matcher_hint_hit_density: >= kDensePerMille selects the plain-load kernel variant
     uint32_t hit_density_pm = 0;
+    // records of unequal length (set by mk_scan_batch from the offsets it is given, or by
+    // mk_matcher_hint_record_lengths): every scan then builds a coarse record index first
+    bool ragged = false;
+    uint32_t *d_rec_index = nullptr;
+    size_t d_rec_index_cap = 0;
     mk::TableEntry *d_table = nullptr;
     uint8_t *d_pat_bytes = nullptr;
     uint32_t *d_pat_off = nullptr;

@@ -31,6 +31,9 @@ struct ScanParams {
     uint32_t uniform_len;  // > 0: every pattern has this length (pattern i starts at i * uniform_len)
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
     uint32_t tile_run;    // consecutive tiles a wave takes before it jumps ahead (>= 1)
+    // records of unequal length: rec_index[k] = index of the record that contains byte k * 64 Ki (one more
+    // entry behind the last); null = equal lengths, the quotient p * rec_per_byte is the record
+    const uint32_t *rec_index;
     // per-scan-wave staging of verified occurrences (EMIT kernels; kHitStage tuples each)
     mk_hit *stage;
     // outputs
@@ -57,6 +60,11 @@ uint32_t scan_lds_bytes();
 
 // counters[pat] += occurrences of pat among the stored tuples (hits[0 .. min(*n_hits, hits_cap)))
 void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t stream);
+
+// rec_index[k] = largest r with rec_off[r] <= k * 64 Ki, for k = 0 .. ceil(n_bytes / 64 Ki) (one binary search
+// per entry; records of unequal length only)
+constexpr uint32_t kRecIndexShift = 16;
+void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream);
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

@@ -87,6 +87,28 @@ void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t st) {
     hipLaunchKernelGGL(mk_hist_hits_kernel, dim3(grid_blocks), dim3(1024), 0, st, p.hits, p.n_hits, p.hits_cap, p.counters, p.n_pat);
 }
 
+// ---- coarse record index for batches whose records differ in length -------------------------------------
+__global__ void mk_rec_index_kernel(const uint64_t *__restrict__ rec_off, uint64_t n_rec, uint64_t n_entries, uint32_t *__restrict__ out) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_entries; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = k << kRecIndexShift;
+        uint64_t lo = 0, hi = n_rec;  // invariant: rec_off[lo] <= p (rec_off[0] = 0), and (hi == n_rec or rec_off[hi] > p)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (rec_off[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        out[k] = (uint32_t)lo;
+    }
+}
+
+void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream) {
+    const uint64_t n_entries = (n_bytes >> kRecIndexShift) + 2;
+    const int blocks = (int)std::min<uint64_t>(2048, (n_entries + 255) / 256);
+    hipLaunchKernelGGL(mk_rec_index_kernel, dim3(blocks), dim3(256), 0, stream, rec_off, n_rec, n_entries, rec_index);
+}
+
 // dst[i] += src[i]: counter vectors of two handles that share a device (mk_reduce_counters)
 __global__ void mk_add_u64_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, size_t len) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];

@@ -110,6 +110,16 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     // i.e. 4 of 10 drains of 64.  The nudge is far below 1 / record length and above the rounding error
     // for up to ~10^10 records.
     uint64_t lo = (uint64_t)((double)p * P.rec_per_byte + 1e-6);
+    if (P.rec_index) {
+        // records of unequal length: the quotient drifts by thousands of records over a 15 GB batch and the
+        // gallop below would take ~20 dependent memory round trips (+8 % kernel time at 1 % of the reads
+        // hitting, r02_ragged_sweep).  A coarse index -- the record at every 64 Ki-th byte, L2-resident --
+        // and interpolation inside its 64 KiB window land within a record or two.
+        const uint32_t k = (uint32_t)(p >> kRecIndexShift);
+        const uint32_t r0 = P.rec_index[k], r1 = P.rec_index[k + 1];
+        lo = r0 + ((((uint32_t)p & ((1u << kRecIndexShift) - 1u)) * (uint64_t)(r1 - r0 + 1)) >> kRecIndexShift);
+        if (lo > r1) lo = r1;
+    }
     if (lo >= n) lo = n - 1;
     uint64_t rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];  // seq_off[0] == 0 is part of the ABI
     if (P.case_insensitive) {
