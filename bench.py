@@ -110,6 +110,8 @@ def parse_args(argv=None):
     ap.add_argument("--ragged", type=int, default=0, metavar="SPREAD",
                     help="diagnostic: record lengths uniform in [read_len - SPREAD, read_len + SPREAD] over the same bytes "
                          "(trimmed reads: the record lookup of a verified occurrence can no longer guess its index)")
+    ap.add_argument("--density-hint", type=int, default=-1,
+                    help="diagnostic: records hit per 1000 told to the library instead of what the warm-up saw")
     ap.add_argument("--no-rec-index", action="store_true", help="diagnostic with --ragged: do not tell the library that lengths vary")
     ap.add_argument("--no-counters", action="store_true", help="diagnostic: scan without the device counter vector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,7 +304,8 @@ def main():
         # loads for hit-dense text); a host that scans batch after batch does the same with mk_scan_batch
         w = d_cnt.cpu().numpy()[len(patterns):]
         if w[mk.MK_SUM_RECORDS]:
-            mk._check(lib.mk_matcher_hint_hit_density(m.handle, int(w[mk.MK_SUM_RECORDS_HIT]) * 1000 // int(w[mk.MK_SUM_RECORDS])))
+            seen = int(w[mk.MK_SUM_RECORDS_HIT]) * 1000 // int(w[mk.MK_SUM_RECORDS])
+            mk._check(lib.mk_matcher_hint_hit_density(m.handle, seen if args.density_hint < 0 else args.density_hint))
     d_cnt.zero_()
     m.enable_timing(args.steps * n_mates)
     barrier()

@@ -398,10 +398,11 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
     if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
     // hit-dense text (tag on already extracted reads: every other record hits): level 3 re-reads each
-    // verified window, so the stream is read with cacheable loads and the re-read finds it in L2 / MALL
-    // (every read hitting: 8.6 -> 7.4 ms per 15 GB; sparse text is 5 % faster non-temporal; crossover at
-    // ~10-20 % of the records, profiles/r02_hitrate_sweep.txt)
-    constexpr uint32_t kDensePerMille = 150;
+    // verified window, so the stream is read with cacheable loads and the re-read finds it in L2 / MALL,
+    // and level 3 itself uses 16-byte loads (scan_kernel_impl.hpp: resolve_one).  Every read hitting:
+    // 8.9 -> 6.0 ms per 15 GB; text without hits is 16 % faster non-temporal; the two variants cross at
+    // 10 % of the records (profiles/r02_cmp16_crossover.txt)
+    constexpr uint32_t kDensePerMille = 95;
     const bool plain_loads = m->hit_density_pm >= kDensePerMille;
     const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, plain_loads, (int)blocks, st);
     if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);

@@ -90,7 +90,7 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 // byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
 // check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
 // its tuple in `out`.
-template <bool EMIT>
+template <bool EMIT, bool WIDE>
 __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true, mk_hit &out) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
     if constexpr ((MK_ABLATE & 16) != 0) return false;
@@ -101,8 +101,8 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     const uint8_t *__restrict__ pt = P.pat_bytes + a;
     // Everything below that touches memory is independent of everything else, so it is issued
     // together and costs ONE round trip: the record-offset pair at the interpolated record
-    // index (reads are mostly of similar length, so the guess is usually right) and the four
-    // 8-byte text / pattern loads of the comparison.
+    // index (reads are mostly of similar length, so the guess is usually right) and the text /
+    // pattern loads of the comparison.
     const uint64_t n = P.n_rec;
     // + 1e-6: with equal-length records the quotient of a record's FIRST byte is an integer, and the rounded
     // factor n_rec / n_bytes can land it a hair below -- the guess is then one record short and the wave
@@ -121,15 +121,41 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
         if (lo > r1) lo = r1;
     }
     if (lo >= n) lo = n - 1;
-    uint64_t rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];  // seq_off[0] == 0 is part of the ABI
+    // Two forms of the loads below, chosen with the kernel variant (WIDE = the plain-load kernels,
+    // which run when many reads hit).  With every read hitting the kernel is bound by the number of
+    // memory REQUESTS per occurrence, so the record-offset pair is one 16-byte request and a pattern of
+    // 16..32 bytes -- every k-mer -- is compared with two overlapping 16-byte loads a side, [0, 16) and
+    // [len - 16, len): 7.7 -> 5.9 ms per 100 M reads.  In the kernels for sparse hits the same code costs
+    // the scan loop around it 1.4 % (register allocation; r02_cmp16_ab) and gains little, so they keep
+    // 8-byte loads.  (seq_off[0] == 0 is part of the ABI.)
+    uint64_t rstart, rend;
+    if constexpr (WIDE) {
+        uint64_t rpair[2];
+        __builtin_memcpy(rpair, P.rec_off + lo, 16);
+        rstart = rpair[0], rend = rpair[1];
+    } else {
+        rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];
+    }
     if (P.case_insensitive) {
         for (uint32_t i = 0; i < len; ++i)
             if (fold_ascii(tx[i]) != fold_ascii(pt[i])) return false;
     } else {
-        // independent 8-byte (unaligned) loads, no early-exit chain; the clamped offsets of
-        // patterns up to 32 bytes (every k-mer) overlap harmlessly
+        // independent unaligned loads, no early-exit chain; the clamped / overlapping offsets are harmless
         uint64_t diff = 0;
-        if (len >= 8) {
+        if (WIDE && len >= 16) {
+            const uint32_t last = len - 16;
+            uint64_t x[2], y[2], u[2], v[2];
+            __builtin_memcpy(x, tx, 16);
+            __builtin_memcpy(y, pt, 16);
+            __builtin_memcpy(u, tx + last, 16);
+            __builtin_memcpy(v, pt + last, 16);
+            diff = (x[0] ^ y[0]) | (x[1] ^ y[1]) | (u[0] ^ v[0]) | (u[1] ^ v[1]);
+            for (uint32_t o = 16; o < last; o += 16) {  // patterns longer than 32 bytes
+                __builtin_memcpy(x, tx + o, 16);
+                __builtin_memcpy(y, pt + o, 16);
+                diff |= (x[0] ^ y[0]) | (x[1] ^ y[1]);
+            }
+        } else if (len >= 8) {
             const uint32_t last = len - 8;
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
@@ -243,7 +269,7 @@ __device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, ui
     hr.staged = 0;
 }
 
-template <bool EMIT>
+template <bool EMIT, bool WIDE>
 __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint64_t newest_end, uint32_t lane, uint32_t &n_true) {
     const uint32_t n = hr.count;
     // entries were written by other lanes of this wave
@@ -256,7 +282,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
     if (lane < n) {
         uint64_t p = (newest_end & 0xFFFFFFFF00000000ull) | e.x;
         if (p >= newest_end) p -= 1ull << 32;
-        hit = resolve_one<EMIT>(P, e.y, p, n_true, out);
+        hit = resolve_one<EMIT, WIDE>(P, e.y, p, n_true, out);
     }
     hr.count = 0;
     if constexpr (EMIT) {
@@ -279,7 +305,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
 // hit ring; returns whether this lane must look at the next bucket (its bucket has overflowed).
 // CS > 0: context kernels (filter.hpp: gf_has_ctx), CS = the sampling stride; an entry's fingerprint
 // is then the q-gram hash mixed with the candidate's context bases under the mask of the entry's offset.
-template <bool EMIT, int CS>
+template <bool EMIT, int CS, bool WIDE>
 __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint32_t ctx, uint64_t t, uint4 v0, uint4 v1,
                                             uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true) {
     const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
@@ -293,7 +319,7 @@ __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, ui
         const uint64_t mm = (MK_ABLATE & 64) ? 0ull : __ballot(match);
         if (mm) {  // uniform, rare
             const uint32_t cnt = (uint32_t)__popcll(mm);
-            if (hr.count + cnt > kHitSlots) drain_hits<EMIT>(P, hr, newest_end, lane, n_true);  // make room
+            if (hr.count + cnt > kHitSlots) drain_hits<EMIT, WIDE>(P, hr, newest_end, lane, n_true);  // make room
             if (match) {
                 const uint32_t below =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
@@ -318,13 +344,13 @@ __device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, ui
 
 // synchronous probe: wave-uniform loop over the bucket chain (one iteration unless a home
 // bucket is full), each iteration one memory round trip
-template <bool EMIT, int CS>
+template <bool EMIT, int CS, bool WIDE>
 __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint32_t ctx, uint64_t t,
                                             uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true) {
     while (__ballot(active)) {
         uint4 v0, v1;
         load_bucket(P, active, b, v0, v1);
-        active = probe_round<EMIT, CS>(P, active, fp, ctx, t, v0, v1, lane, hr, newest_end, n_true);
+        active = probe_round<EMIT, CS, WIDE>(P, active, fp, ctx, t, v0, v1, lane, hr, newest_end, n_true);
         b = (b + 1) & P.table_mask;
     }
 }
@@ -403,6 +429,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     constexpr int CS = kCtx ? S : 0;
     using G = Geo<S, QC, kCtx>;
     constexpr bool kPipe = kCtx && G::kNS <= 2 && (MK_ABLATE & 7) == 0;
+    constexpr bool kWide = !NTL;  // level-3 loads: resolve_one
     __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
     uint32_t *lds_sums = bloom + kLdsBytes / 4 - kLdsSumWords;
     if (threadIdx.x < kLdsSumWords) lds_sums[threadIdx.x] = 0;
@@ -527,7 +554,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint64_t t;
         uint32_t ctx;
         take_from_ring(n, active, b, fp, ctx, t);
-        probe_chain<EMIT, CS>(P, active, b, fp, ctx, t, lane, hr, newest_end, n_true);
+        probe_chain<EMIT, CS, kWide>(P, active, b, fp, ctx, t, lane, hr, newest_end, n_true);
     };
     auto issue_probe = [&](uint32_t n) __attribute__((always_inline)) {  // asynchronous: loads only
         take_from_ring(n, pend_active, pend_b, pend_fp, pend_ctx, pend_t);
@@ -535,9 +562,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         pend_on = true;
     };
     auto consume_probe = [&]() __attribute__((always_inline)) {
-        const bool more = probe_round<EMIT, CS>(P, pend_active, pend_fp, pend_ctx, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true);
+        const bool more = probe_round<EMIT, CS, kWide>(P, pend_active, pend_fp, pend_ctx, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true);
         if (__ballot(more))  // some home bucket had overflowed: finish those chains synchronously
-            probe_chain<EMIT, CS>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_ctx, pend_t, lane, hr, newest_end, n_true);
+            probe_chain<EMIT, CS, kWide>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_ctx, pend_t, lane, hr, newest_end, n_true);
         pend_on = false;
     };
 
@@ -694,7 +721,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             if (base - last_push_base >= (1ull << 30)) {
                 last_push_base = base;
                 flush_slots();
-                if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true);  // 32-bit positions too
+                if (hr.count) drain_hits<EMIT, kWide>(P, hr, newest_end, lane, n_true);  // 32-bit positions too
                 if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
             }
 #pragma unroll 1
@@ -808,7 +835,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // drain what is left in this wave's slots and rings
     flush_slots();
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
-    if (hr.count) drain_hits<EMIT>(P, hr, newest_end, lane, n_true);
+    if (hr.count) drain_hits<EMIT, kWide>(P, hr, newest_end, lane, n_true);
     if constexpr (EMIT) flush_stage(P, hr, lane);
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
