@@ -306,6 +306,11 @@ def main():
         if w[mk.MK_SUM_RECORDS]:
             seen = int(w[mk.MK_SUM_RECORDS_HIT]) * 1000 // int(w[mk.MK_SUM_RECORDS])
             mk._check(lib.mk_matcher_hint_hit_density(m.handle, seen if args.density_hint < 0 else args.density_hint))
+    # warm-up of the collective as well: the first all-reduce on a new communicator sets up its
+    # channels (tens of ms), which belongs to the warm-up like the first launches do; the vector is
+    # cleared afterwards, the timed job reduces its own counters once
+    reduce_counters()
+    torch.cuda.synchronize()
     d_cnt.zero_()
     m.enable_timing(args.steps * n_mates)
     barrier()
