@@ -3,7 +3,7 @@
     python -m merkurio_amd.build [--force] [--tag NAME --flags "-DMK_ABLATE=1 ..."]
 
 hipcc cross-compiles for gfx950 without a GPU; the built .so travels to the GPU box with the
-repository snapshot (it is git-ignored, not gpurun-ignored).  The scan kernel has ~60 template
+repository snapshot (it is git-ignored, not gpurun-ignored).  The scan kernel has ~80 template
 variants; they are compiled as independent translation units (scan_variants.hip with
 -DMK_TU=n) in parallel and linked into one library.
 
@@ -21,7 +21,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmerkurio_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "merkurio")
 
-N_VARIANT_TUS = 7
+N_VARIANT_TUS = 9
 HOST_SOURCES = ["matcher.cpp", "host_patterns.cpp", "host_loops.cpp", "reduce.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]

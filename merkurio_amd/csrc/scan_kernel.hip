@@ -160,11 +160,27 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
     }
     // k-mer sizes with their own kernels (q fixed at compile time): the 31-mer family
     // (q = 32 - S) and the 21-mer family (q = 22 - S, S <= 4)
-    if (plain_loads) {  // hit-dense text: cacheable stream loads
+    if (plain_loads) {  // hit-dense text: cacheable stream loads, 16-byte loads at level 3
         if (S == 16 && p.q == 16) MK_VARIANT_PLAIN(16, 16);
         if (S == 8 && p.q == 24) MK_VARIANT_PLAIN(8, 24);
         if (S == 4 && p.q == 28) MK_VARIANT_PLAIN(4, 28);
         if (S == 4 && p.q == 18) MK_VARIANT_PLAIN(4, 18);
+        if (wide) switch (S) {
+                case 1: MK_VARIANT_PLAIN(1, -1);
+                case 2: MK_VARIANT_PLAIN(2, -1);
+                case 4: MK_VARIANT_PLAIN(4, -1);
+                case 8: MK_VARIANT_PLAIN(8, -1);
+                case 16: MK_VARIANT_PLAIN(16, -1);
+                default: return nullptr;
+            }
+        switch (S) {
+            case 1: MK_VARIANT_PLAIN(1, 0);
+            case 2: MK_VARIANT_PLAIN(2, 0);
+            case 4: MK_VARIANT_PLAIN(4, 0);
+            case 8: MK_VARIANT_PLAIN(8, 0);
+            case 16: MK_VARIANT_PLAIN(16, 0);
+            default: return nullptr;
+        }
     }
     if (S == 16 && p.q == 16) MK_VARIANT(16, 16, false);
     if (S == 8 && p.q == 24) MK_VARIANT(8, 24, false);

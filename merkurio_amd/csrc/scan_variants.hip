@@ -1,11 +1,11 @@
 // scan_variants.hip -- instantiates the scan kernel (scan_kernel_impl.hpp) for one GROUP of variants.
 // Compiled once per group with -DMK_TU=<n> (merkurio_amd/build.py runs the groups in parallel: the
-// ~60 variants take minutes in one translation unit).  S = sampling stride, QC = q-gram length
+// ~80 variants take minutes in one translation unit).  S = sampling stride, QC = q-gram length
 // (> 0 fixed at compile time, 0 runtime q <= 16, -1 runtime q in 17..32), GF = filter in global memory.
 #include "scan_kernel_impl.hpp"
 
 #ifndef MK_TU
-#error "compile with -DMK_TU=0..6"
+#error "compile with -DMK_TU=0..8"
 #endif
 
 namespace mk {
@@ -34,6 +34,18 @@ MK_INST_PLAIN(16, 16, false);
 MK_INST_PLAIN(8, 24, false);
 MK_INST_PLAIN(4, 28, false);
 MK_INST_PLAIN(4, 18, false);
+#elif MK_TU == 7  // plain stream loads, runtime q <= 16
+MK_INST_PLAIN(1, 0, false);
+MK_INST_PLAIN(2, 0, false);
+MK_INST_PLAIN(4, 0, false);
+MK_INST_PLAIN(8, 0, false);
+MK_INST_PLAIN(16, 0, false);
+#elif MK_TU == 8  // plain stream loads, runtime q in 17..32
+MK_INST_PLAIN(1, -1, false);
+MK_INST_PLAIN(2, -1, false);
+MK_INST_PLAIN(4, -1, false);
+MK_INST_PLAIN(8, -1, false);
+MK_INST_PLAIN(16, -1, false);
 #elif MK_TU == 1  // LDS filter, runtime q <= 16
 MK_INST(1, 0, false);
 MK_INST(2, 0, false);

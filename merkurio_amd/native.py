@@ -370,6 +370,10 @@ class Matcher:
         _check(load().mk_matcher_filter_mode(self._h, C.byref(lds), C.byref(fb)))
         return {"in_lds": bool(lds.value), "filter_bytes": fb.value}
 
+    def hint_hit_density(self, records_hit_per_1000):
+        """performance hint for the next scan (never changes results): picks the load flavour of the kernel"""
+        _check(load().mk_matcher_hint_hit_density(self._h, int(records_hit_per_1000)))
+
     # ---- batched scan, host buffers
     def scan(self, seqs, mode=MK_MODE_HITS, hits_cap=None):
         """-> (flags: np.bool_[n], hits: structured array in reference emission order)"""

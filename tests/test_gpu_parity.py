@@ -348,6 +348,54 @@ def test_occurrences_across_chunk_and_tile_borders(mk, k, options):
     assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp
 
 
+_LENS31 = [31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 100, 257]
+
+
+@pytest.mark.parametrize("lens,options", [
+    (_LENS31, dict(force_stride=16)), (_LENS31, dict(force_stride=8)), (_LENS31, dict(force_stride=4)),
+    ([21, 23, 24, 25, 31, 32, 33, 48, 70], dict(force_stride=4)),
+    ([8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 65], None),          # runtime q <= 16
+    ([8, 9, 15, 16, 17, 31, 32, 33, 65], dict(force_stride=2)),
+    ([25, 26, 31, 32, 33, 40, 48, 49, 65], dict(force_stride=4)),                 # runtime q in 17..32
+    ([27, 31, 32, 33, 64, 65, 100], dict(force_stride=1)),
+], ids=["16x16", "8x24", "4x28", "4x18", "rt-narrow", "rt-narrow-s2", "rt-wide-s4", "rt-wide-s1"])
+def test_sparse_and_dense_kernel_variants_agree(mk, lens, options):
+    """the kernel variant for hit-dense text (plain stream loads, 16-byte loads in the exact comparison) and
+    the one for sparse hits give the same result set as the oracle, for pattern lengths around the 16- and
+    32-byte edges of the comparison, near misses at every byte class, occurrences that end on the last byte of
+    a record and of the text; every kernel family with the filter in LDS"""
+    rnd = random.Random(4242)
+    raw = [_rand_seq(rnd, n, b"ACGT") for n in lens for _ in range(3)]
+    near = []  # near misses: one byte off at every position class of the comparison
+    for p in raw[::3]:
+        for k in (0, 7, 8, 15, 16, 31, 32, len(p) // 2, len(p) - 33, len(p) - 17, len(p) - 16, len(p) - 9, len(p) - 8, len(p) - 1):
+            if 0 <= k < len(p):
+                near.append(p[:k] + (b"A" if p[k:k + 1] != b"A" else b"C") + p[k + 1:])
+    recs = []
+    for i in range(1500):
+        s = bytearray(_rand_seq(rnd, rnd.choice([60, 150, 300, 700]), b"ACGT"))
+        for _ in range(rnd.choice([0, 1, 1, 2, 3])):
+            p = rnd.choice(raw if rnd.random() < 0.7 else near)
+            if len(p) <= len(s):
+                k = rnd.choice([0, len(s) - len(p), rnd.randrange(0, len(s) - len(p) + 1)])
+                s[k:k + len(p)] = p
+        recs.append(bytes(s))
+    patterns = mk.parse_pattern_list(kmer_seq=raw)
+    exp, c_exp, found_exp = _oracle_hits(patterns, True, recs)
+    assert len(exp) > 600
+    m = mk.Matcher(patterns, algo=mk.MK_ALGO_AC, options=options)
+    names = set()
+    for density in (0, 1000):
+        for mode in (mk.MK_MODE_HITS, mk.MK_MODE_ANY):
+            m.hint_hit_density(density)  # mk_scan_batch replaces it with what the batch showed: set before each scan
+            flags, hits = m.scan(recs, mode, hits_cap=len(exp) + 16)  # one launch: no capacity retry
+            names.add(m.kernel_name)
+            assert flags.tolist() == [bool(f) for f in found_exp], (density, mode)
+            if mode == mk.MK_MODE_HITS:
+                assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp, density
+    assert len(names) == 4 and sum(n.endswith("plain>") for n in names) == 2, names
+
+
 def test_device_out_of_memory_is_an_error_code(mk):
     """hipErrorOutOfMemory comes back across the C ABI as MK_E_NOMEM (not MK_E_HIP, not an abort), and the
     handle stays usable"""
