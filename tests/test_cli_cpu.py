@@ -77,6 +77,11 @@ def test_clustered_short_flags_parse_like_clap(golden):
     assert rc("extract", "-i", fa, "-s", "A", "-rx")[0] == 2                 # unknown flag inside a cluster
 
 
+# MERKURIO_TEST_SANITIZE=1: build the host-code harnesses with AddressSanitizer + UBSan (CPU only)
+_HARNESS_FLAGS = (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+                  if os.environ.get("MERKURIO_TEST_SANITIZE") else ["-O1"])
+
+
 def test_bz2_xz_zstd_decoders(tmp_path, golden):
     """needletail reads .gz/.bz2/.xz (zstd with the same feature); the CLI binds libbz2 / liblzma /
     libzstd at run time.  Harness around the CLI's decoder file: reference samples, multi-stream
@@ -85,7 +90,7 @@ def test_bz2_xz_zstd_decoders(tmp_path, golden):
     import ctypes
     import lzma
     exe = str(tmp_path / "dz")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-DMK_DECOMPRESS_HARNESS", "-I", os.path.join(ROOT, "merkurio_amd/csrc/cli"), "-o", exe,
+    subprocess.run(["g++", "-std=c++17", *_HARNESS_FLAGS, "-DMK_DECOMPRESS_HARNESS", "-I", os.path.join(ROOT, "merkurio_amd/csrc/cli"), "-o", exe,
                     os.path.join(ROOT, "tests/helpers/decompress_harness.cpp"),
                     os.path.join(ROOT, "merkurio_amd/csrc/cli/decompress.cpp"), "-ldl"], check=True)
 
@@ -134,7 +139,7 @@ def test_windowed_fastx_reader(tmp_path):
     import zlib
     cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
     exe = str(tmp_path / "fs")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/fastx_stream_harness.cpp"),
+    subprocess.run(["g++", "-std=c++17", *_HARNESS_FLAGS, "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/fastx_stream_harness.cpp"),
                     os.path.join(cli_dir, "io.cpp"), os.path.join(cli_dir, "decompress.cpp"), os.path.join(cli_dir, "util.cpp"),
                     "-lz", "-ldl", "-lpthread"], check=True)
 
@@ -183,7 +188,7 @@ def test_windowed_sam_bam_reader(tmp_path, golden):
     import zlib
     cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
     exe = str(tmp_path / "ss")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/sam_stream_harness.cpp"),
+    subprocess.run(["g++", "-std=c++17", *_HARNESS_FLAGS, "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/sam_stream_harness.cpp"),
                     os.path.join(cli_dir, "io.cpp"), os.path.join(cli_dir, "decompress.cpp"), os.path.join(cli_dir, "util.cpp"),
                     "-lz", "-ldl", "-lpthread"], check=True)
     rnd = random.Random(9)
