@@ -28,7 +28,7 @@ with open(sam, "wb") as f:
     rec.tofile(f)
 open(km, "wb").write(b"\n".join(p.tobytes() for p in pats) + b"\n")
 print(f"generated {n} records ({os.path.getsize(sam) / 1e6:.0f} MB SAM) in {time.time() - t0:.1f} s", flush=True)
-binp = os.path.join(ROOT, "merkurio_amd", "lib", "merkurio")
+binp = os.environ.get("MERKURIO_BIN") or os.path.join(ROOT, "merkurio_amd", "lib", "merkurio")
 bam0, out = os.path.join(tmp, "e2e_in.bam"), os.path.join(tmp, "e2e_out")
 for label, args in (("SAM -> SAM", ["-i", sam, "-o", out + ".sam"]), ("SAM -> BAM", ["-i", sam, "-o", bam0]),
                     ("BAM -> BAM, -m", ["-i", bam0, "-o", out + ".bam", "-m"]), ("BAM -> BAM", ["-i", bam0, "-o", out + "3.bam"]), ("BAM -> SAM", ["-i", bam0, "-o", out + "2.sam"])):
