@@ -9,7 +9,7 @@ namespace mk {
 
 // number of records with rec_flags != 0 -> counters[n_pat + MK_SUM_RECORDS_HIT]
 // (flag bytes are 0 or 1; 16-byte loads over the 16-byte aligned middle, bytes at both ends)
-__global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint8_t *__restrict__ flags, uint64_t n_rec,
+__global__ __launch_bounds__(1024) void mk_count_flags_kernel(const uint8_t *__restrict__ flags, uint64_t n_rec,
                                                              unsigned long long *__restrict__ out) {
     const uint64_t head = std::min<uint64_t>(n_rec, (16 - ((uintptr_t)flags & 15)) & 15);
     const uint64_t n16 = (n_rec - head) / 16;
@@ -30,21 +30,23 @@ __global__ __launch_bounds__(256) void mk_count_flags_kernel(const uint8_t *__re
         for (uint64_t r = 0; r < head; ++r) c += flags[r] != 0;
         for (uint64_t r = head + n16 * 16; r < n_rec; ++r) c += flags[r] != 0;
     }
-    // one atomic per block (a single address takes ~11 ns per atomic: 8192 wave atomics cost 90 us)
-    __shared__ unsigned long long part[4];
+    // one atomic per block, one block per CU (a single address takes ~11 ns per atomic: 8192 wave
+    // atomics cost 90 us, 1024 block atomics 11 of this kernel's 26 us)
+    __shared__ unsigned long long part[16];
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        unsigned long long t = 0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) t += part[w];
         if (t) atomicAdd(out, t);
     }
 }
 
 void launch_count_flags(const ScanParams &p, hipStream_t st) {
     const uint64_t n16 = p.n_rec / 16;
-    const int blocks = (int)std::min<uint64_t>(1024, std::max<uint64_t>(1, (n16 + 1023) / 1024));
-    hipLaunchKernelGGL(mk_count_flags_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const uint8_t *>(p.rec_flags32),
+    const int blocks = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, (n16 + 4095) / 4096));
+    hipLaunchKernelGGL(mk_count_flags_kernel, dim3(blocks), dim3(1024), 0, st, reinterpret_cast<const uint8_t *>(p.rec_flags32),
                        p.n_rec, p.counters + p.n_pat + MK_SUM_RECORDS_HIT);
 }
 
