@@ -190,8 +190,8 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
  * d_rec_flags 4-byte aligned with its allocation padded to a multiple of 4 bytes.
  * The call enqueues on `stream` (a hipStream_t, NULL = default stream): clear of
  * d_rec_flags[0..n_rec) and of *d_n_hits, then the scan kernel.  d_hits may be NULL in
- * MK_MODE_ANY.  Hits are written UNORDERED (order them with mk_order_hits after copying
- * back); in MK_MODE_HITS *d_n_hits counts every occurrence even beyond hits_cap (0 in MK_MODE_ANY).
+ * MK_MODE_ANY.  Hits are written UNORDERED (order them with mk_order_hits_device, or with
+ * mk_order_hits after copying back); in MK_MODE_HITS *d_n_hits counts every occurrence even beyond hits_cap (0 in MK_MODE_ANY).
  * d_counters (may be NULL): uint64[n_pat + MK_NUM_SUMMARY] accumulated (+=) by the scan:
  *   [0, n_pat)            occurrences per pattern (the AC meaning of pattern_hit_counts,
  *                         src/cmd_extract.rs:353).  MK_MODE_HITS only, counted from the stored tuples
@@ -223,8 +223,16 @@ int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000);
  * position, which is exact for equal lengths and merely slower otherwise.  mk_scan_batch decides by itself. */
 int mk_matcher_hint_record_lengths(mk_matcher *m, int equal_lengths);
 
-/* Sort hits (host memory) into the reference's emission order for this matcher. */
+/* Sort hits (host memory) into the reference's emission order for this matcher:
+ * Aho-Corasick find_overlapping_iter (src/cmd_extract.rs:332, src/cmd_tag.rs:393-396) per record end
+ * ascending, longer pattern first, pattern id; BNDMq driver loop (src/cmd_extract.rs:365-384) per record
+ * pattern-major, positions ascending. */
 int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);
+/* The same order for tuples still on the device (d_hits as written by mk_scan_device, n_hits <= hits_cap of
+ * them), sorted in place on `stream` -- a device merge sort: ~10^8 tuples in tens of milliseconds where one
+ * host thread needs ten seconds.  mk_scan_batch uses it by itself.  The scratch buffer lives in the handle
+ * (growing it synchronises the device; one call in flight per handle). */
+int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream);
 
 /* name of the scan kernel variant the last mk_scan_device on this handle launched, and its
  * launch geometry (for profiling / roofline bookkeeping) */

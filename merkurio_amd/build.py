@@ -47,6 +47,7 @@ def _units():
     """(object name, source file, extra flags) of every translation unit of the library"""
     units = [("scan_tu%d.o" % n, "scan_variants.hip", ["-DMK_TU=%d" % n]) for n in range(N_VARIANT_TUS)]
     units.append(("scan_kernel.o", "scan_kernel.hip", []))
+    units.append(("order_hits.o", "order_hits.hip", []))
     units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     return units
 

@@ -311,7 +311,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_stage, (void *)m->d_rec_index})
+                    (void *)m->d_stage, (void *)m->d_rec_index, m->d_sort_tmp})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -475,6 +475,25 @@ int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t 
     return MK_OK;
 }
 
+// Tuples still on the device, sorted in place into the reference's emission order (order_hits.hip).
+// Enqueued on `stream`; the scratch buffer lives in the handle and growing it synchronises the device,
+// like every other workspace of the handle.
+int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (n_hits < 2) return MK_OK;
+    if (!d_hits) return fail(MK_E_INVALID_ARG, "null buffer");
+    MK_ABI_BEGIN
+    MK_HIP(hipSetDevice(m->device));
+    const bool ac = m->algo == MK_ALGO_AC;
+    size_t need = 0;
+    MK_HIP(order_hits_device((mk_hit *)d_hits, n_hits, ac, m->d_pat_off, m->uniform_len, nullptr, &need, (hipStream_t)stream));
+    int rc = ensure(&m->d_sort_tmp, &m->d_sort_tmp_cap, need ? need : 16);
+    if (rc) return rc;
+    MK_HIP(order_hits_device((mk_hit *)d_hits, n_hits, ac, m->d_pat_off, m->uniform_len, m->d_sort_tmp, &need, (hipStream_t)stream));
+    return MK_OK;
+    MK_ABI_END
+}
+
 int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     if (m->algo == MK_ALGO_AC) {
@@ -559,8 +578,13 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
             return fail(MK_E_CAPACITY, "hits buffer too small: %llu occurrences, capacity %llu", found,
                         (unsigned long long)hits_cap);
         if (found) {
-            MK_HIP(hipMemcpy(hits, m->d_hits, found * sizeof(mk_hit), hipMemcpyDeviceToHost));
-            mk_order_hits(m, hits, found);
+            // emission order: on the device for anything but a handful of tuples (one host thread sorts
+            // ~8 M tuples/s; a batch where every read hits would spend 1000x its scan time there)
+            constexpr uint64_t kSortOnDevice = 4096;
+            if (found >= kSortOnDevice && (rc = mk_order_hits_device(m, m->d_hits, found, m->stream))) return rc;
+            MK_HIP(hipMemcpyAsync(hits, m->d_hits, found * sizeof(mk_hit), hipMemcpyDeviceToHost, m->stream));
+            MK_HIP(hipStreamSynchronize(m->stream));
+            if (found < kSortOnDevice) mk_order_hits(m, hits, found);
         }
     }
     return MK_OK;

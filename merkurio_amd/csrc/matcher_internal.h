@@ -47,6 +47,8 @@ struct mk_matcher {
     size_t d_hits_cap = 0;
     unsigned long long *d_nhits = nullptr;
     mk_hit *d_stage = nullptr;  // EMIT kernels: per-wave staging of hit tuples
+    void *d_sort_tmp = nullptr;  // scratch of mk_order_hits_device (order_hits.hip)
+    size_t d_sort_tmp_cap = 0;
     const char *kernel_name = "";
     int last_grid = 0;
     // optional per-launch kernel timing (hipEvents recorded on the launch stream, tightly

@@ -65,6 +65,9 @@ void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t stream);
 // per entry; records of unequal length only)
 constexpr uint32_t kRecIndexShift = 16;
 void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream);
+// order_hits.hip: device tuples sorted in place into the reference's emission order; tmp == nullptr only sets *tmp_bytes
+hipError_t order_hits_device(mk_hit *d_hits, size_t n, bool ac, const uint32_t *d_pat_off, uint32_t uniform_len, void *tmp,
+                             size_t *tmp_bytes, hipStream_t stream);
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

@@ -469,3 +469,62 @@ def test_device_counters_and_synth(mk):
     assert s[mk.MK_SUM_HITS] == nh and s[mk.MK_SUM_RECORDS_HIT] == c_exp["records_hit"][0]
     assert s[mk.MK_SUM_RECORDS] == n_rec and s[mk.MK_SUM_BASES] == n_rec * L
     assert d_flags[:n_rec].cpu().numpy().astype(bool).tolist() == [bool(f) for f in found]
+
+
+@pytest.mark.parametrize("algo", ["ac", "bndmq"])
+def test_emission_order_on_the_device(mk, algo):
+    """mk_order_hits_device (what mk_scan_batch uses from 4096 tuples up) == mk_order_hits on the host == the
+    oracle's emission order: nested patterns that end on the same byte (AC: longer first), the same pattern
+    set pattern-major under BNDMq, tens of thousands of tuples over short and long records"""
+    torch = pytest.importorskip("torch")
+    rnd = random.Random(77)
+    core = _rand_seq(rnd, 40, b"ACGT")
+    # suffixes / infixes of one another: many ties on the end position
+    raw = [core, core[8:], core[20:], core[30:], core[5:25], core[5:17], b"ACGT", b"CGTA", b"GT"] + \
+          [_rand_seq(rnd, n, b"ACGT") for n in (3, 4, 5, 9, 21, 31)]
+    if algo == "bndmq":
+        raw = raw[:13]  # BNDMq domain: < 14 patterns, each <= 64 bytes
+    patterns = mk.parse_pattern_list(kmer_seq=raw)
+    m = mk.Matcher(patterns, algo=mk.MK_ALGO_AC if algo == "ac" else mk.MK_ALGO_BNDMQ)
+    recs = []
+    for i in range(4000):
+        s = bytearray(_rand_seq(rnd, rnd.choice([0, 3, 50, 150, 400]), b"ACGT"))
+        if len(s) >= 40 and i % 3 == 0:
+            k = rnd.randrange(0, len(s) - 40 + 1)
+            s[k:k + 40] = core
+        recs.append(bytes(s))
+    exp, _, _ = _oracle_hits(patterns, algo == "ac", recs)
+    assert len(exp) > 30_000
+    # through mk_scan_batch (device sort inside)
+    flags, hits = m.scan(recs, mk.MK_MODE_HITS, hits_cap=len(exp) + 16)
+    assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp
+    # the two entry points on the same unordered tuples
+    lib = mk.load()
+    dev = torch.device("cuda", 0)
+    data, off = mk.pack_records(recs)
+    n_bytes = int(off[-1])
+    d_seq = torch.zeros(n_bytes + 64, dtype=torch.uint8, device=dev)
+    d_seq[:n_bytes] = torch.from_numpy(data[:n_bytes].copy()).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_flags = torch.zeros(len(recs) + 8, dtype=torch.uint8, device=dev)
+    cap = len(exp) + 16
+    d_hits = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), len(recs), mk.MK_MODE_HITS, d_flags.data_ptr(),
+                              d_hits.data_ptr(), cap, d_nh.data_ptr(), None, st) == 0, lib.mk_last_error()
+    torch.cuda.synchronize()
+    nh = int(d_nh.item())
+    assert nh == len(exp)
+    host = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)[:nh].copy()
+    assert lib.mk_order_hits(m.handle, host.ctypes.data, nh) == 0
+    assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), nh, st) == 0, lib.mk_last_error()
+    torch.cuda.synchronize()
+    devs = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)[:nh]
+    assert np.array_equal(devs, host)
+    assert list(zip(host["rec"].tolist(), host["pat"].tolist(), host["pos"].tolist())) == exp
+    # degenerate sizes and arguments
+    assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), 0, st) == 0
+    assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), 1, st) == 0
+    assert lib.mk_order_hits_device(m.handle, None, 5, st) == mk.MK_E_INVALID_ARG
+    assert lib.mk_order_hits_device(None, d_hits.data_ptr(), 5, st) == mk.MK_E_INVALID_ARG
