@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """End-to-end wall time of `merkurio tag` on synthetic SAM / BAM (host codec + PCIe + scan + write).
-usage: tools/e2e_tag.py [n_records] [n_patterns]"""
+usage: tools/e2e_tag.py [n_records] [n_patterns] [one record in N carries a k-mer, default 100]"""
 import os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 npat = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+every = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 L = 150
 rng = np.random.default_rng(2)
 tmp = os.environ.get("TMPDIR", "/tmp")
@@ -13,8 +14,11 @@ sam, km = os.path.join(tmp, "e2e.sam"), os.path.join(tmp, "e2e_kmers.txt")
 t0 = time.time()
 bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))]
 pats = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(npat, 31))]
-for i in range(0, n, 100):  # 1 % of the records carry a k-mer
-    bases[i, 7:38] = pats[i % npat]
+if every == 1:  # every record carries a k-mer
+    bases[:, 7:38] = pats[np.arange(n) % npat]
+else:
+    for i in range(0, n, every):  # 1 % of the records by default
+        bases[i, 7:38] = pats[i % npat]
 pre = np.array([f"r{i:010d}\t0\tchr1\t{i % 1000000 + 1:07d}\t60\t{L}M\t*\t0\t0\t" for i in range(n)], dtype="S41")
 P = pre.dtype.itemsize
 rec = np.empty((n, P + L + 1 + L + 1), dtype=np.uint8)
