@@ -184,6 +184,52 @@ def test_headline_full_size_properties(mk):
         assert int(sel.sum()) == c["hits"][0]
 
 
+def test_every_read_hits_full_size(mk):
+    """100 M x 150 bp with a k-mer planted in EVERY read (tag on already extracted reads, at the headline
+    size): the kernel variant for hit-dense text and the one for sparse hits flag the same records, the
+    tuple count equals the counters, and 10^8 tuples sorted on the device (mk_order_hits_device) come out in
+    emission order -- records ascending, positions ascending inside a record, every record present."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    lib = mk.load()
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(10_000, 31, 6))
+    npat = len(patterns)
+    m = mk.Matcher(patterns)
+    n_rec, L, seed = 100_000_000, 150, 0xD0D0
+    st = torch.cuda.current_stream().cuda_stream
+    d_seq = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    assert lib.mk_synth_reads_device(m.handle, seed, n_rec, L, 1, d_seq.data_ptr(), d_off.data_ptr(), st) == 0
+    cap = n_rec + (1 << 20)
+    d_hits = torch.empty(2 * cap, dtype=torch.int64, device=dev)
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    flags, names = {}, {}
+    for density in (1000, 0):
+        f = torch.empty(n_rec + 8, dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(npat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        assert lib.mk_matcher_hint_hit_density(m.handle, density) == 0
+        mode = mk.MK_MODE_HITS if density else mk.MK_MODE_ANY
+        assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_rec * L, d_off.data_ptr(), n_rec, mode, f.data_ptr(),
+                                  d_hits.data_ptr(), cap if density else 0, d_nh.data_ptr(), cnt.data_ptr(), st) == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        flags[density], names[density] = f[:n_rec], m.kernel_name
+        if density:
+            nh = int(d_nh.item())
+            c = cnt.cpu().numpy()
+    assert names[1000].endswith("plain>") and not names[0].endswith("plain>")
+    assert torch.equal(flags[1000], flags[0]) and bool(flags[0].all())
+    assert n_rec <= nh <= cap and c[npat + mk.MK_SUM_HITS] == nh == int(c[:npat].sum()) and c[npat + mk.MK_SUM_RECORDS_HIT] == n_rec
+    assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), nh, st) == 0, lib.mk_last_error()
+    torch.cuda.synchronize()
+    t = d_hits[:2 * nh].view(nh, 2)  # [rec, pat | pos << 32]
+    rec, pos = t[:, 0], t[:, 1] >> 32
+    d_rec = rec[1:] - rec[:-1]
+    assert bool((d_rec >= 0).all())
+    assert bool(((d_rec > 0) | (pos[1:] >= pos[:-1])).all())  # equal-length patterns: end order == start order
+    assert int((d_rec > 0).sum().item()) + 1 == n_rec and int(rec[0].item()) == 0 and int(rec[-1].item()) == n_rec - 1
+    assert bool((pos <= L - 31).all()) and bool(((t[:, 1] & 0xFFFFFFFF) < npat).all())
+
+
 @pytest.mark.parametrize("n_pat,every", [(1, 1000), (1, 50), (13, 100000)])
 def test_sparse_candidates_full_size(mk, n_pat, every):
     """few patterns on a 15 GB batch: filter positives are so rare that a wave's ring never fills
