@@ -348,8 +348,8 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     if (mode == MK_MODE_HITS && !d_hits && hits_cap) return fail(MK_E_INVALID_ARG, "d_hits is null");
     hipStream_t st = (hipStream_t)stream;
     MK_HIP(hipSetDevice(m->device));
-    MK_HIP(hipMemsetAsync(d_n_hits, 0, sizeof(unsigned long long), st));
-    if (n_rec) MK_HIP(hipMemsetAsync(d_rec_flags, 0, (n_rec + 3) & ~(uint64_t)3, st));
+    launch_clear((uint32_t *)d_rec_flags, (n_rec + 3) / 4, (unsigned long long *)d_n_hits, st);  // also clears *d_n_hits
+    MK_HIP(hipGetLastError());
     if (n_rec == 0 || n_bytes == 0) return MK_OK;
     ScanParams p;
     memset(&p, 0, sizeof(p));

@@ -64,6 +64,8 @@ void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t stream);
 // rec_index[k] = largest r with rec_off[r] <= k * 64 Ki, for k = 0 .. ceil(n_bytes / 64 Ki) (one binary search
 // per entry; records of unequal length only)
 constexpr uint32_t kRecIndexShift = 16;
+// flags32[0, n_words) = 0 and *n_hits = 0 (the start of every scan)
+void launch_clear(uint32_t *flags32, uint64_t n_words, unsigned long long *n_hits, hipStream_t stream);
 void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream);
 // order_hits.hip: device tuples sorted in place into the reference's emission order; tmp == nullptr only sets *tmp_bytes
 hipError_t order_hits_device(mk_hit *d_hits, size_t n, bool ac, const uint32_t *d_pat_off, uint32_t uniform_len, void *tmp,
