@@ -528,3 +528,37 @@ def test_emission_order_on_the_device(mk, algo):
     assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), 1, st) == 0
     assert lib.mk_order_hits_device(m.handle, None, 5, st) == mk.MK_E_INVALID_ARG
     assert lib.mk_order_hits_device(None, d_hits.data_ptr(), 5, st) == mk.MK_E_INVALID_ARG
+
+
+def test_flag_clear_respects_alignment_and_bounds(mk):
+    """every scan starts by clearing d_rec_flags[0, n_rec rounded up to 4) and *d_n_hits in one kernel: any
+    4-byte-aligned flag pointer, any record count; bytes in front of and behind that range stay untouched"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    lib = mk.load()
+    pat = b"ACGTTGCAACGTTGCAACGTTGCAACGTTGC"
+    m = mk.Matcher([pat])
+    st = torch.cuda.current_stream().cuda_stream
+    base = torch.empty(4096, dtype=torch.uint8, device=dev)
+    d_nh = torch.empty(1, dtype=torch.int64, device=dev)
+    for shift in (0, 4, 8, 12, 20):
+        for n_rec in (1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 64, 67, 1000):
+            recs = [pat if i % 3 == 0 else b"G" * 40 for i in range(n_rec)]
+            data, off = mk.pack_records(recs)
+            n_bytes = int(off[-1])
+            d_seq = torch.zeros(n_bytes + 64, dtype=torch.uint8, device=dev)
+            d_seq[:n_bytes] = torch.from_numpy(data[:n_bytes].copy()).to(dev)
+            d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+            base.fill_(0xEE)
+            d_nh.fill_(-1)
+            flags = base[64 + shift:]
+            assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec, mk.MK_MODE_ANY, flags.data_ptr(),
+                                      None, 0, d_nh.data_ptr(), None, st) == 0, lib.mk_last_error()
+            torch.cuda.synchronize()
+            h = base.cpu().numpy()
+            lo, hi = 64 + shift, 64 + shift + (n_rec + 3) // 4 * 4
+            assert h[lo:lo + n_rec].tolist() == [1 if i % 3 == 0 else 0 for i in range(n_rec)], (shift, n_rec)
+            assert not h[lo + n_rec:hi].any() and (h[:lo] == 0xEE).all() and (h[hi:] == 0xEE).all(), (shift, n_rec)
+            assert int(d_nh.item()) == 0
+    assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec, mk.MK_MODE_ANY, base[66:].data_ptr(),
+                              None, 0, d_nh.data_ptr(), None, st) == mk.MK_E_INVALID_ARG
