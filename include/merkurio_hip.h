@@ -189,7 +189,8 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
  * d_seq_off[0] must be 0 (offsets relative to d_seq);
  * d_rec_flags 4-byte aligned with its allocation padded to a multiple of 4 bytes.
  * The call enqueues on `stream` (a hipStream_t, NULL = default stream): clear of
- * d_rec_flags[0..n_rec) and of *d_n_hits, then the scan kernel.  d_hits may be NULL in
+ * d_rec_flags[0..n_rec) and of *d_n_hits, then the scan kernel (and, behind it, a small kernel that sets
+ * the flag bytes of the records the scan has listed).  d_hits may be NULL in
  * MK_MODE_ANY.  Hits are written UNORDERED (order them with mk_order_hits_device, or with
  * mk_order_hits after copying back); in MK_MODE_HITS *d_n_hits counts every occurrence even beyond hits_cap (0 in MK_MODE_ANY).
  * d_counters (may be NULL): uint64[n_pat + MK_NUM_SUMMARY] accumulated (+=) by the scan:
@@ -212,7 +213,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
                    void *d_counters, void *stream);
 
 /* Performance hint for mk_scan_device (never changes results): how many of 1000 records the caller
- * expects to contain a pattern.  Dense text (>= 95) is streamed with cacheable loads, because the
+ * expects to contain a pattern.  Dense text (>= 120) is streamed with cacheable loads, because the
  * exact verification re-reads every hit window; sparse text with non-temporal loads.  mk_scan_batch
  * and the driver-loop entry points maintain the value themselves from the batch they have just scanned. */
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000);

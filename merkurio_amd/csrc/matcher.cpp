@@ -293,6 +293,8 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     // staging of verified occurrences for the hit-tuple kernels, kHitStage tuples per scan wave.
     // Allocated here, not by the first MK_MODE_HITS scan: mk_scan_device only enqueues.
     MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * (kBlockThreads / 64) * kHitStage * sizeof(mk_hit)));
+    MK_HIP(hipMalloc((void **)&m->d_flag_list, (size_t)m->num_cus * (kBlockThreads / 64) * kFlagListCap * sizeof(uint32_t)));
+    MK_HIP(hipMalloc((void **)&m->d_flag_counts, (size_t)m->num_cus * (kBlockThreads / 64) * sizeof(uint32_t)));
     MK_HIP(hipMemcpy(m->d_bloom, bloom.data(), bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
@@ -311,7 +313,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_stage, (void *)m->d_rec_index, m->d_sort_tmp})
+                    (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -397,19 +399,30 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const size_t slots = m->ev_start.size();
     const size_t slot = slots ? (size_t)(m->timed_launches % slots) : 0;
     if (slots) MK_HIP(hipEventRecord(m->ev_start[slot], st));
-    // hit-dense text (tag on already extracted reads: every other record hits): level 3 re-reads each
+    // Two kernel flavours (scan_kernel_impl.hpp), picked from the hit density the matcher has last seen.
+    // Hit-dense text (tag on already extracted reads: every other record hits): level 3 re-reads each
     // verified window, so the stream is read with cacheable loads and the re-read finds it in L2 / MALL,
-    // and level 3 itself uses 16-byte loads (scan_kernel_impl.hpp: resolve_one).  Every read hitting:
-    // 8.9 -> 6.0 ms per 15 GB; text without hits is 16 % faster non-temporal; the two variants cross at
-    // 10 % of the records (profiles/r02_cmp16_crossover.txt)
-    constexpr uint32_t kDensePerMille = 95;
+    // level 3 itself uses 16-byte loads, and flags are stored directly.  Every read hitting: 9.1 -> 6.0 ms
+    // per 15 GB.  Everything else: non-temporal stream (16 % faster without hits), 8-byte compare loads,
+    // flagged records listed per wave and their bytes set by a small kernel afterwards.  The flavours cross
+    // at 12 % of the records (profiles/r02_crossover2.txt).
+    constexpr uint32_t kDensePerMille = 120;
     const bool plain_loads = m->hit_density_pm >= kDensePerMille;
+    // the flag-only kernels for sparse hits list the records they flag (one list per scan wave) and a small
+    // kernel sets the flag bytes afterwards (scan_kernel_impl.hpp: drain_hits); record indices in the lists are
+    // 32 bits.  (Their tuple-emitting twins set the flags from the tuples they stage.)
+    const bool listed = !(plain_loads && m->gbloom_blocks == 0) && mode != MK_MODE_HITS && n_rec < (1ull << 32);
+    p.flag_list = listed ? m->d_flag_list : nullptr;
+    p.flag_counts = m->d_flag_counts;
+    p.flag_cap = kFlagListCap;
     const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, plain_loads, (int)blocks, st);
     if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);
     if (slots) {
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));
         m->timed_launches++;
     }
+    if (listed)
+        launch_flag_scatter(m->d_flag_list, m->d_flag_counts, kFlagListCap, (uint32_t)(blocks * waves_per_block), (uint8_t *)d_rec_flags, st);
     if (d_counters) {
         launch_count_flags(p, st);
         if (mode == MK_MODE_HITS && p.hits && p.hits_cap) launch_hist_hits(p, m->num_cus, st);

@@ -47,6 +47,9 @@ struct mk_matcher {
     size_t d_hits_cap = 0;
     unsigned long long *d_nhits = nullptr;
     mk_hit *d_stage = nullptr;  // EMIT kernels: per-wave staging of hit tuples
+    // kernels for sparse hits: per-scan-wave lists of flagged records (scan_kernel.h: flag_list)
+    uint32_t *d_flag_list = nullptr;
+    uint32_t *d_flag_counts = nullptr;
     void *d_sort_tmp = nullptr;  // scratch of mk_order_hits_device (order_hits.hip)
     size_t d_sort_tmp_cap = 0;
     const char *kernel_name = "";

@@ -9,6 +9,7 @@
 namespace mk {
 
 constexpr uint32_t kHitStage = 1024;  // tuples a wave stages before it reserves output slots
+constexpr uint32_t kFlagListCap = 2048;  // flagged records a scan wave can list (sparse-hit kernels); beyond: direct stores
 
 struct ScanParams {
     // text: concatenated records
@@ -38,6 +39,12 @@ struct ScanParams {
     mk_hit *stage;
     // outputs
     uint32_t *rec_flags32;  // rec_flags viewed as 32-bit words (byte r = record r)
+    // kernels for sparse hits: a wave appends the records it flags to its own list (flag_cap entries per
+    // scan wave, its fill in flag_counts[wave]) instead of storing into rec_flags; launch_flag_scatter sets
+    // the bytes afterwards.  null: flags are stored directly (also what a wave does once its list is full).
+    uint32_t *flag_list;
+    uint32_t *flag_counts;
+    uint32_t flag_cap;
     mk_hit *hits;           // may be null when !EMIT
     uint64_t hits_cap;
     unsigned long long *n_hits;    // device counter (every occurrence, even beyond hits_cap)
@@ -66,6 +73,9 @@ void launch_hist_hits(const ScanParams &p, int grid_blocks, hipStream_t stream);
 constexpr uint32_t kRecIndexShift = 16;
 // flags32[0, n_words) = 0 and *n_hits = 0 (the start of every scan)
 void launch_clear(uint32_t *flags32, uint64_t n_words, unsigned long long *n_hits, hipStream_t stream);
+// rec_flags[list entry] = 1 for every entry the scan waves appended (n_waves lists of flag_cap entries)
+void launch_flag_scatter(const uint32_t *flag_list, const uint32_t *flag_counts, uint32_t flag_cap, uint32_t n_waves, uint8_t *rec_flags,
+                         hipStream_t stream);
 void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream);
 // order_hits.hip: device tuples sorted in place into the reference's emission order; tmp == nullptr only sets *tmp_bytes
 hipError_t order_hits_device(mk_hit *d_hits, size_t n, bool ac, const uint32_t *d_pat_off, uint32_t uniform_len, void *tmp,

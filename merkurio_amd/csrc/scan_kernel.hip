@@ -72,6 +72,23 @@ void launch_clear(uint32_t *flags32, uint64_t n_words, unsigned long long *n_hit
     hipLaunchKernelGGL(mk_clear_kernel, dim3(blocks), dim3(1024), 0, st, flags32, n_words, n_hits);
 }
 
+// ---- end of a scan by a sparse-hit kernel: the records the scan waves listed get their flag bytes -----
+// One wave here per scan wave's list; nothing waits for these scattered byte stores.
+__global__ __launch_bounds__(1024) void mk_flag_scatter_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ counts,
+                                                              uint32_t cap, uint32_t n_waves, uint8_t *__restrict__ flags) {
+    const uint32_t w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (w >= n_waves) return;
+    const uint32_t n = counts[w] < cap ? counts[w] : cap;
+    const uint32_t *__restrict__ l = list + (uint64_t)w * cap;
+    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) flags[l[i]] = 1;
+}
+
+void launch_flag_scatter(const uint32_t *flag_list, const uint32_t *flag_counts, uint32_t flag_cap, uint32_t n_waves, uint8_t *rec_flags,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(mk_flag_scatter_kernel, dim3((n_waves + 15) / 16), dim3(1024), 0, st, flag_list, flag_counts, flag_cap, n_waves,
+                       rec_flags);
+}
+
 // ---- occurrences per pattern from the emitted tuples (MK_MODE_HITS with a counter vector) ------------
 // counters[pat] += 1 for every stored tuple.  Workgroups take slabs of >= 64 Ki tuples; a slab is
 // histogrammed in LDS (pattern sets up to 36 Ki patterns: 144 KiB of u32 bins) and flushed with one

@@ -6,7 +6,7 @@
 //   BNDMq::find_match / find_iter        src/pattern_matching.rs:82-209
 //   AhoCorasick::find_overlapping_iter   src/cmd_extract.rs:332,480,507; src/cmd_tag.rs:393-396
 // Result set = every (record, pattern, start) occurrence + per-record any-hit flags
-// (bit-exact vs the oracle); emission ORDER is restored on the host (matcher.cpp).
+// (bit-exact vs the oracle); emission ORDER is restored afterwards (order_hits.hip, matcher.cpp).
 //
 // Shape of the work (integer, HBM-streaming; no MFMA -- DESIGN.md §3/§4):
 //   * one persistent 1024-thread workgroup per CU (16 waves); level 1, the 128 KiB blocked
@@ -24,7 +24,8 @@
 //     fills, 64 candidates at a time go through level 2 (bucketised exact table in L2, loads
 //     issued at the end of one group and consumed at the top of the next) and level 3
 //     (byte-exact compare, record lookup, boundary check) with all 64 lanes busy;
-//   * results: one byte store per hit record (flags), optional (record, pattern, position) tuples
+//   * results: the flag byte of a hit record (stored directly by the kernels for hit-dense text, via a
+//     per-wave list of flagged records + a small kernel otherwise), optional (record, pattern, position) tuples
 //     staged through a per-wave buffer so the output cursor sees one atomic per ~1000 hits, summary
 //     counters summed per workgroup (one global atomic per workgroup and counter); occurrences per
 //     pattern are counted from the tuples afterwards (mk_hist_hits_kernel, scan_kernel.hip);
@@ -210,18 +211,17 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
         rend = P.rec_off[lo + 1];
     }
     if (p + len > rend) return false;  // occurrence would cross a record boundary
-    // ---- a true occurrence.  The flag is a plain byte store (idempotent; nothing waits for it);
-    // flagged records are counted afterwards by mk_count_flags_kernel when counters are wanted.
+    // ---- a true occurrence.  Its record is flagged by the caller (drain_hits); flagged records are
+    // counted afterwards by mk_count_flags_kernel when counters are wanted.
     if constexpr ((MK_ABLATE & 32) != 0) {
         n_true++;
         return false;
     }
-    if constexpr ((MK_ABLATE & 256) == 0) reinterpret_cast<uint8_t *>(P.rec_flags32)[lo] = 1;
     n_true++;
     // (occurrences per pattern are counted from the emitted tuples by mk_hist_hits_kernel after the
     // scan: an atomic per occurrence in here cost 0.65 ms per 10 M occurrences, r02_hitrate_sweep)
+    out.rec = lo;
     if (EMIT) {  // the caller stages the tuple (HitStage)
-        out.rec = lo;
         out.pat = pat;
         out.pos = (uint32_t)(p - rstart);
     }
@@ -246,9 +246,15 @@ struct HitRing {
     // occurrences/s (every read hitting: 20.8 ms per 100 M reads instead of 10.2 without tuples).
     mk_hit *stage;
     uint32_t staged;  // wave-uniform
+    // kernels for sparse hits: this wave's list of flagged records (global memory) and its fill
+    uint32_t *flist;
+    uint32_t nflag;  // wave-uniform
 };
 
-// move this wave's staged tuples to the output array: one cursor atomic for all of them
+// move this wave's staged tuples to the output array: one cursor atomic for all of them.
+// FLAGS: the records of the tuples get their flag bytes here (tuple kernels for sparse hits: once per
+// ~1000 occurrences instead of once per drain, see drain_hits)
+template <bool FLAGS>
 __device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, uint32_t lane) {
     const uint32_t n = hr.staged;
     if (n == 0) return;
@@ -263,6 +269,8 @@ __device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, ui
     for (uint32_t i = lane; i < n; i += 64) {
         const uint4 v = reinterpret_cast<const uint4 *>(hr.stage)[i];
         if (base + i < P.hits_cap) reinterpret_cast<uint4 *>(P.hits)[base + i] = v;
+        if constexpr (FLAGS && (MK_ABLATE & 256) == 0)
+            reinterpret_cast<uint8_t *>(P.rec_flags32)[((uint64_t)v.y << 32) | v.x] = 1;  // mk_hit.rec
     }
     // the next tuples staged must not overtake these reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -285,16 +293,31 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
         hit = resolve_one<EMIT, WIDE>(P, e.y, p, n_true, out);
     }
     hr.count = 0;
+    // The record's flag.  A byte stored into the 100 MB flag array is a partial write to a line that is
+    // cached nowhere, and on gfx9 the wave's next s_waitcnt vmcnt -- the one its stream loads wait on --
+    // also waits for that store to be acknowledged: on the boxes of the pool where that takes long, 1 % of
+    // the reads hitting cost 0.17 ms per launch in flag stores alone (MK_ABLATE=256, r02_flag_target).
+    // The kernels for sparse hits therefore append the record index to a per-wave list (one coalesced
+    // store per drain) and a small kernel sets the bytes afterwards, where nothing waits for them; a wave
+    // whose list is full stores directly.  With hit-dense text every list would overflow: those kernels
+    // (WIDE) store directly.
+    const uint64_t mm = __ballot(hit);
+    if (mm == 0) return;
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+    const uint32_t n_hit = (uint32_t)__popcll(mm);
     if constexpr (EMIT) {
-        const uint64_t mm = __ballot(hit);
-        if (mm) {
-            if (hit) {
-                const uint32_t below =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                hr.stage[hr.staged + below] = out;
-            }
-            hr.staged += (uint32_t)__popcll(mm);
-            if (hr.staged > kHitStage - 64) flush_stage(P, hr, lane);  // no room for another full round
+        // tuple kernels for sparse hits: the flags are set from the staged tuples when those are flushed
+        if constexpr (WIDE && (MK_ABLATE & 256) == 0)
+            if (hit) reinterpret_cast<uint8_t *>(P.rec_flags32)[out.rec] = 1;
+        if (hit) hr.stage[hr.staged + below] = out;
+        hr.staged += n_hit;
+        if (hr.staged > kHitStage - 64) flush_stage<!WIDE>(P, hr, lane);  // no room for another full round
+    } else if constexpr ((MK_ABLATE & 256) == 0) {
+        if (!WIDE && hr.flist && hr.nflag + n_hit <= P.flag_cap) {
+            if (hit) hr.flist[hr.nflag + below] = (uint32_t)out.rec;
+            hr.nflag += n_hit;
+        } else if (hit) {
+            reinterpret_cast<uint8_t *>(P.rec_flags32)[out.rec] = 1;
         }
     }
 }
@@ -466,6 +489,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     hr.count = 0;
     hr.stage = EMIT ? P.stage + wave_id * (uint64_t)kHitStage : nullptr;
     hr.staged = 0;
+    hr.flist = (!kWide && !EMIT && P.flag_list) ? P.flag_list + wave_id * (uint64_t)P.flag_cap : nullptr;
+    hr.nflag = 0;
     uint32_t n_true = 0;  // per lane: occurrences found
     uint32_t abl_acc = 0;              // ablation builds only
 
@@ -836,7 +861,8 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     flush_slots();
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
     if (hr.count) drain_hits<EMIT, kWide>(P, hr, newest_end, lane, n_true);
-    if constexpr (EMIT) flush_stage(P, hr, lane);
+    if constexpr (EMIT) flush_stage<!kWide>(P, hr, lane);
+    if (hr.flist && lane == 0) P.flag_counts[wave_id] = hr.nflag;  // every wave of the grid, empty lists too
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;
     if (P.counters) {
         // One global atomic per WORKGROUP and counter: a single address retires an atomic every ~11 ns,
