@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 2
+#define MK_ABI_VERSION 3
 
 /* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
 #define MK_OK 0
@@ -230,10 +230,20 @@ int mk_matcher_hint_record_lengths(mk_matcher *m, int equal_lengths);
  * pattern-major, positions ascending. */
 int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);
 /* The same order for tuples still on the device (d_hits as written by mk_scan_device, n_hits <= hits_cap of
- * them), sorted in place on `stream` -- a device merge sort: ~10^8 tuples in tens of milliseconds where one
- * host thread needs ten seconds.  mk_scan_batch uses it by itself.  The scratch buffer lives in the handle
- * (growing it synchronises the device; one call in flight per handle). */
+ * them, 16-byte aligned), sorted in place on `stream` by hand-written kernels: tuples are counted into bins of
+ * consecutive records, stored into their bin as 8-byte keys and each bin is sorted in LDS -- two passes over the
+ * tuples and one over the keys (order_hits.hip).  The call waits ONCE for the stream (32 bytes of histogram
+ * statistics fix the key layout; the caller has just read n_hits the same way) and returns with the rest enqueued.
+ * Bins use the record count of the handle's last mk_scan_device; tuples of another batch are still ordered
+ * correctly.  Batches that defeat the binning (a bin above 16384 tuples after re-binning on record and position,
+ * more than 2^32 - 1 tuples, or record / end / pattern fields that do not fit 64 bits together) are ordered by a
+ * library merge sort instead.  mk_scan_batch uses this by itself.  The scratch buffer (8 bytes per tuple) lives in
+ * the handle (growing it synchronises the device; one call in flight per handle). */
 int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream);
+/* what the last mk_order_hits_device on this handle did: *path = 0 nothing (fewer than two tuples), 1 bins of
+ * consecutive records, 2 bins on the top bits of (record, end | pattern), 3 library merge sort; the number of
+ * bins and the largest bin (paths 1 and 2) */
+int mk_matcher_order_info(const mk_matcher *m, uint32_t *path, uint32_t *n_bins, uint32_t *max_bin);
 
 /* name of the scan kernel variant the last mk_scan_device on this handle launched, and its
  * launch geometry (for profiling / roofline bookkeeping) */

@@ -48,6 +48,7 @@ def _units():
     units = [("scan_tu%d.o" % n, "scan_variants.hip", ["-DMK_TU=%d" % n]) for n in range(N_VARIANT_TUS)]
     units.append(("scan_kernel.o", "scan_kernel.hip", []))
     units.append(("order_hits.o", "order_hits.hip", []))
+    units.append(("order_hits_fallback.o", "order_hits_fallback.hip", []))
     units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     return units
 

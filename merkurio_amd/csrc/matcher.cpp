@@ -299,6 +299,20 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     MK_HIP(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (use == MK_ALGO_AC && !m->uniform_len) {
+        // matches that end on one byte are emitted longest first, then by pattern id (aho-corasick's overlapping
+        // DFA walk, src/cmd_extract.rs:332-351): that tie order as a rank the device sort can use as a key field
+        std::vector<uint32_t> unrank(n_pat), rank(n_pat);
+        for (uint32_t i = 0; i < n_pat; ++i) unrank[i] = i;
+        std::stable_sort(unrank.begin(), unrank.end(), [pat_off](uint32_t a, uint32_t b) {
+            return pat_off[a + 1] - pat_off[a] > pat_off[b + 1] - pat_off[b];
+        });
+        for (uint32_t r = 0; r < n_pat; ++r) rank[unrank[r]] = r;
+        MK_HIP(hipMalloc((void **)&m->d_pat_rank, n_pat * sizeof(uint32_t)));
+        MK_HIP(hipMalloc((void **)&m->d_pat_unrank, n_pat * sizeof(uint32_t)));
+        MK_HIP(hipMemcpy(m->d_pat_rank, rank.data(), n_pat * sizeof(uint32_t), hipMemcpyHostToDevice));
+        MK_HIP(hipMemcpy(m->d_pat_unrank, unrank.data(), n_pat * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     *out = owner.release();
     return MK_OK;
     MK_ABI_END
@@ -313,7 +327,8 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
-                    (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp})
+                    (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp,
+                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -352,6 +367,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     MK_HIP(hipSetDevice(m->device));
     launch_clear((uint32_t *)d_rec_flags, (n_rec + 3) / 4, (unsigned long long *)d_n_hits, st);  // also clears *d_n_hits
     MK_HIP(hipGetLastError());
+    m->last_n_rec = n_rec;
     if (n_rec == 0 || n_bytes == 0) return MK_OK;
     ScanParams p;
     memset(&p, 0, sizeof(p));
@@ -488,23 +504,120 @@ int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t 
     return MK_OK;
 }
 
-// Tuples still on the device, sorted in place into the reference's emission order (order_hits.hip).
-// Enqueued on `stream`; the scratch buffer lives in the handle and growing it synchronises the device,
-// like every other workspace of the handle.
-int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream) {
-    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
-    if (n_hits < 2) return MK_OK;
-    if (!d_hits) return fail(MK_E_INVALID_ARG, "null buffer");
-    MK_ABI_BEGIN
-    MK_HIP(hipSetDevice(m->device));
+// Tuples still on the device, sorted in place into the reference's emission order (order_hits.hip): histogram of
+// the tuples over bins of consecutive records, one 32-byte read-back that fixes the key layout, scatter into the
+// bins as 8-byte keys, one LDS sort per bin.  The scratch buffer lives in the handle and growing it synchronises
+// the device, like every other workspace of the handle.
+static uint32_t bits_of(uint64_t v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
+
+static int order_library(mk_matcher *m, mk_hit *d_hits, uint64_t n, hipStream_t st) {
     const bool ac = m->algo == MK_ALGO_AC;
     size_t need = 0;
-    MK_HIP(order_hits_device((mk_hit *)d_hits, n_hits, ac, m->d_pat_off, m->uniform_len, nullptr, &need, (hipStream_t)stream));
+    MK_HIP(order_hits_library(d_hits, n, ac, m->d_pat_off, m->uniform_len, nullptr, &need, st));
     int rc = ensure(&m->d_sort_tmp, &m->d_sort_tmp_cap, need ? need : 16);
     if (rc) return rc;
-    MK_HIP(order_hits_device((mk_hit *)d_hits, n_hits, ac, m->d_pat_off, m->uniform_len, m->d_sort_tmp, &need, (hipStream_t)stream));
+    MK_HIP(order_hits_library(d_hits, n, ac, m->d_pat_off, m->uniform_len, m->d_sort_tmp, &need, st));
+    m->order_path = 3;
+    return MK_OK;
+}
+
+int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    m->order_path = 0;
+    if (n_hits < 2) return MK_OK;
+    if (!d_hits) return fail(MK_E_INVALID_ARG, "null buffer");
+    if (((uintptr_t)d_hits & 15) != 0) return fail(MK_E_INVALID_ARG, "d_hits must be 16-byte aligned");
+    MK_ABI_BEGIN
+    MK_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    mk_hit *hits = (mk_hit *)d_hits;
+    const uint64_t n = n_hits;
+    if (n >= (1ull << 32)) return order_library(m, hits, n, st);  // bin cursors are 32 bits
+    if (!m->order_prepared) {  // once per handle (function attributes are per device)
+        MK_HIP(order_kernels_prepare());
+        m->order_prepared = true;
+    }
+    // bins: ~2048 tuples each, at most kOrderMaxBins, a power of two
+    uint32_t log_bins = 0;
+    while (log_bins < 15 && ((uint64_t)2048 << log_bins) < n) ++log_bins;
+    // scratch: stats | counts | starts | cursors | keys
+    const size_t head = 64 + (size_t)(3 * kOrderMaxBins + 16) * sizeof(uint32_t);
+    int rc = ensure(&m->d_sort_tmp, &m->d_sort_tmp_cap, head + n * sizeof(uint64_t));
+    if (rc) return rc;
+    OrderScratch S;
+    S.stats = (unsigned long long *)m->d_sort_tmp;
+    S.g_cnt = (uint32_t *)((char *)m->d_sort_tmp + 64);
+    S.bin_start = S.g_cnt + kOrderMaxBins;
+    S.cursor = S.bin_start + kOrderMaxBins + 8;
+    S.keys = (uint64_t *)((char *)m->d_sort_tmp + head);
+    OrderKey L;
+    memset(&L, 0, sizeof(L));
+    L.pat_off = m->d_pat_off;
+    L.uniform_len = m->uniform_len;
+    L.rank = m->d_pat_rank;
+    L.unrank = m->d_pat_unrank;
+    L.ac = m->algo == MK_ALGO_AC ? 1 : 0;
+    // first attempt: bins of 2^s consecutive records, s from the record count of the handle's last scan
+    uint64_t rec_bound = m->last_n_rec ? m->last_n_rec : (1ull << 32);
+    unsigned long long stats[4] = {0, 0, 0, 0};
+    uint32_t s = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        s = bits_of(rec_bound - 1) > log_bins ? bits_of(rec_bound - 1) - log_bins : 0;
+        L.bits_a = 0;
+        L.bits_b = 1;
+        L.shift = s;
+        L.n_bins = 1u << log_bins;
+        MK_HIP(hipMemsetAsync(m->d_sort_tmp, 0, 64 + (size_t)L.n_bins * sizeof(uint32_t), st));
+        launch_order_hist(hits, n, L, S, m->num_cus, st);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipMemcpyAsync(stats, S.stats, sizeof(stats), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        // done unless a record lies beyond the bound (tuples of another batch than the handle's last scan), or a
+        // bin overflows while the bound is at least twice the largest record seen (the bins are coarser than they
+        // need be): once more with the exact bound
+        const bool beyond = (stats[0] >> s) >= L.n_bins;
+        const bool loose = stats[3] > kOrderLeafMax && bits_of(stats[0]) < bits_of(rec_bound - 1);
+        if (!beyond && !loose) break;
+        rec_bound = stats[0] + 1;
+    }
+    const uint32_t bits_rec = bits_of(stats[0]);
+    const uint32_t bits_a = std::max(1u, bits_of(stats[1])), bits_b = std::max(1u, bits_of(stats[2]));
+    if (bits_rec + bits_a + bits_b > 64) return order_library(m, hits, n, st);  // the triple does not fit one 64-bit key
+    if (s + bits_a > 63) return order_library(m, hits, n, st);  // (cannot happen below 2^31 records)
+    L.bits_a = bits_a;
+    L.bits_b = bits_b;
+    m->order_path = 1;
+    if (stats[3] > kOrderLeafMax || (stats[0] >> s) >= L.n_bins) {
+        // a bin overflows its LDS sort (few huge records, or hits clustered in one stretch of the batch): bin on the
+        // top bits of (record, A) instead, with as many bins as the histogram kernel can hold
+        const uint32_t total = bits_rec + bits_a;
+        const uint32_t lb = std::min(15u, log_bins + 3);  // ~256 tuples per bin on average: room for skew
+        L.shift = total > lb ? total - lb : 0;
+        L.n_bins = 1u << std::min(lb, total);
+        MK_HIP(hipMemsetAsync(m->d_sort_tmp, 0, 64 + (size_t)L.n_bins * sizeof(uint32_t), st));
+        launch_order_hist(hits, n, L, S, m->num_cus, st);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipMemcpyAsync(stats, S.stats, sizeof(stats), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        if (stats[3] > kOrderLeafMax) return order_library(m, hits, n, st);
+        m->order_path = 2;
+    } else {
+        L.shift = s + bits_a;  // ((rec << bits_a) | A) >> (s + bits_a) == rec >> s: the bins just counted
+    }
+    m->order_bins = L.n_bins;
+    m->order_max_bin = (uint32_t)stats[3];
+    launch_order_scatter_leaf(hits, n, L, S, (uint32_t)stats[3], m->num_cus, st);
+    MK_HIP(hipGetLastError());
     return MK_OK;
     MK_ABI_END
+}
+
+int mk_matcher_order_info(const mk_matcher *m, uint32_t *path, uint32_t *n_bins, uint32_t *max_bin) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (path) *path = m->order_path;
+    if (n_bins) *n_bins = m->order_bins;
+    if (max_bin) *max_bin = m->order_max_bin;
+    return MK_OK;
 }
 
 int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits) {

@@ -52,6 +52,14 @@ struct mk_matcher {
     uint32_t *d_flag_counts = nullptr;
     void *d_sort_tmp = nullptr;  // scratch of mk_order_hits_device (order_hits.hip)
     size_t d_sort_tmp_cap = 0;
+    // AC with patterns of unequal length: rank of a pattern in (length descending, index ascending) order and
+    // its inverse -- the tie order of matches that end on the same byte (order_hits.hip)
+    uint32_t *d_pat_rank = nullptr;
+    uint32_t *d_pat_unrank = nullptr;
+    uint64_t last_n_rec = 0;  // records of the last mk_scan_device: the binning bound of mk_order_hits_device
+    // what the last mk_order_hits_device did: 0 nothing, 1 record bins, 2 (record, A) bins, 3 library sort
+    uint32_t order_path = 0, order_bins = 0, order_max_bin = 0;
+    bool order_prepared = false;  // the ordering kernels' dynamic-LDS limit has been raised on this device
     const char *kernel_name = "";
     int last_grid = 0;
     // optional per-launch kernel timing (hipEvents recorded on the launch stream, tightly

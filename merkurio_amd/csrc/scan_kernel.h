@@ -77,9 +77,39 @@ void launch_clear(uint32_t *flags32, uint64_t n_words, unsigned long long *n_hit
 void launch_flag_scatter(const uint32_t *flag_list, const uint32_t *flag_counts, uint32_t flag_cap, uint32_t n_waves, uint8_t *rec_flags,
                          hipStream_t stream);
 void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream);
-// order_hits.hip: device tuples sorted in place into the reference's emission order; tmp == nullptr only sets *tmp_bytes
-hipError_t order_hits_device(mk_hit *d_hits, size_t n, bool ac, const uint32_t *d_pat_off, uint32_t uniform_len, void *tmp,
-                             size_t *tmp_bytes, hipStream_t stream);
+// ---- emission order (order_hits.hip: hand-written bin + LDS-sort kernels; order_hits_fallback.hip: library sort) ----
+// How a tuple maps to its sort key (see order_hits.hip): fields (record, A, B); G = record << bits_a | A;
+// bin = G >> shift; 8-byte key = (G mod 2^shift) << bits_b | B.
+struct OrderKey {
+    const uint32_t *pat_off;  // device: pattern i is pat_off[i+1] - pat_off[i] bytes long
+    uint32_t uniform_len;     // != 0: every pattern has this length (no lookup)
+    const uint32_t *rank;     // AC with mixed lengths: rank[pat] in (length descending, index ascending) order; null = identity
+    const uint32_t *unrank;   // its inverse
+    uint32_t ac;              // 1: Aho-Corasick order, 0: BNDMq order
+    uint32_t bits_a;          // width of A inside G; 0 = histogram on the record alone (field widths not known yet)
+    uint32_t bits_b;          // width of B inside the key (1..63)
+    uint32_t shift;           // bin = G >> shift (<= 63)
+    uint32_t n_bins;          // <= kOrderMaxBins
+};
+struct OrderScratch {
+    unsigned long long *stats;  // [0..2] maxima of record, A, B; [3] largest bin
+    uint32_t *g_cnt;            // n_bins
+    uint32_t *bin_start;        // n_bins + 1
+    uint32_t *cursor;           // n_bins
+    uint64_t *keys;             // n
+};
+constexpr uint32_t kOrderMaxBins = 32768;  // LDS histogram: 128 KiB of u32 bins
+constexpr uint32_t kOrderLeafMax = 16384;  // keys one workgroup sorts in LDS (136 KiB with padding)
+// zeroes nothing: the caller clears stats and g_cnt first.  Enqueues the histogram and the bin-start scan.
+void launch_order_hist(const mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, int num_cus, hipStream_t st);
+// scatter into bins + one LDS sort per bin; the sorted tuples replace d_hits[0, n)
+void launch_order_scatter_leaf(mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, uint32_t max_bin, int num_cus,
+                               hipStream_t st);
+// the kernels above use more than 64 KiB of dynamic LDS: raises their limit once per process
+hipError_t order_kernels_prepare();
+// library fallback (rocPRIM merge sort with the reference's comparator): tmp == nullptr only sets *tmp_bytes
+hipError_t order_hits_library(mk_hit *d_hits, size_t n, bool ac, const uint32_t *d_pat_off, uint32_t uniform_len, void *tmp,
+                              size_t *tmp_bytes, hipStream_t stream);
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

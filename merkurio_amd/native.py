@@ -46,7 +46,7 @@ EXPORTS = [
     "mk_abi_version", "mk_last_error", "mk_device_count", "mk_read_kmers_from_text", "mk_parse_pattern_list",
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
-    "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_kernel_name",
+    "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
@@ -161,6 +161,7 @@ def load(build_if_missing=True):
                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mk_order_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.mk_order_hits_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.mk_matcher_order_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mk_matcher_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mk_matcher_enable_timing.argtypes = [C.c_void_p, C.c_uint32]
     L.mk_matcher_hint_hit_density.argtypes = [C.c_void_p, C.c_uint32]
@@ -352,6 +353,12 @@ class Matcher:
         g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(load().mk_matcher_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)))
         return {"grid_blocks": g.value, "block_threads": b.value, "lds_bytes": l.value}
+
+    def order_info(self):
+        """what the last mk_order_hits_device did: path 0 nothing, 1 record bins, 2 (record, end) bins, 3 library sort"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(load().mk_matcher_order_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"path": a.value, "bins": b.value, "max_bin": c.value}
 
     def enable_timing(self, slots):
         _check(load().mk_matcher_enable_timing(self._h, slots))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Emission order of a hit-dense batch: device merge sort (mk_order_hits_device, what mk_scan_batch uses)
-against the host sort (mk_order_hits, one thread) on the same tuples.  usage: tools/order_hits_bench.py [n_reads]"""
+"""Emission order of a hit-dense batch: the hand-written device ordering (mk_order_hits_device: record bins +
+LDS sort per bin, what mk_scan_batch uses) against the host sort (mk_order_hits, one thread) on the same tuples.
+usage: tools/order_hits_bench.py [n_reads]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,5 +48,7 @@ for plant_every in (1, 10):
         ts.append(time.perf_counter() - t0)
     devs = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)[:nh]
     assert np.array_equal(devs, host)
+    info = m.order_info()
     print(f"{n_rec} reads x {L} bp, 1 in {plant_every} hits: {nh} tuples; host sort (1 thread) {t_host * 1e3:.1f} ms, "
-          f"device sort {min(ts) * 1e3:.2f} ms (same order: yes)", flush=True)
+          f"device order {min(ts) * 1e3:.3f} ms min / {np.median(ts) * 1e3:.3f} ms median (same order: yes; path {info['path']}, "
+          f"{info['bins']} bins, largest {info['max_bin']})", flush=True)
