@@ -112,8 +112,11 @@ def parse_args(argv=None):
                          "(trimmed reads: the record lookup of a verified occurrence can no longer guess its index)")
     ap.add_argument("--density-hint", type=int, default=-1,
                     help="diagnostic: records hit per 1000 told to the library instead of what the warm-up saw")
+    ap.add_argument("--with-offsets", action="store_true",
+                    help="diagnostic: do not tell the library that all reads have one length (the record of an occurrence is looked up in the offsets)")
     ap.add_argument("--no-rec-index", action="store_true", help="diagnostic with --ragged: do not tell the library that lengths vary")
     ap.add_argument("--no-counters", action="store_true", help="diagnostic: scan without the device counter vector")
+    ap.add_argument("--no-order", action="store_true", help="diagnostic with --mode hits: leave the tuples unordered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     # filter-geometry tuning hooks (mk_matcher_options; results never depend on them)
@@ -192,6 +195,11 @@ def main():
     lib = mk.load()
     if args.ragged and not args.no_rec_index:
         mk._check(lib.mk_matcher_hint_record_lengths(m.handle, 0))
+    if not args.ragged and not args.with_offsets:
+        # the synthetic reads all have --read-len bases: fixed-length batches (what mk_scan_batch finds out by
+        # itself from a FASTQ of untrimmed reads); the offsets array is still built and still counted in the
+        # algorithmic bytes, the kernel just has no use for it
+        mk._check(lib.mk_matcher_set_fixed_record_length(m.handle, args.read_len))
 
     # ---- this rank's shard of the job: contiguous range of records (pairs), in units of 16 so
     # that every shard starts on a block of the counter-based generator
@@ -239,6 +247,8 @@ def main():
     hits_cap = max(1 << 20, 4 * n_rec // max(1, args.plant_every)) if emit else 0
     d_hits = torch.empty(2 * hits_cap, dtype=torch.int64, device=dev) if emit else None
 
+    order_s = []  # hits mode: wall time of every emission-order call (it waits for the stream once by itself)
+
     def step():
         for d_seq, d_off, d_flags in mates:
             rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec,
@@ -247,6 +257,16 @@ def main():
                                     None if args.no_counters else d_cnt.data_ptr(), st)
             if rc != 0:
                 raise RuntimeError(lib.mk_last_error().decode())
+            if emit and not args.no_order:
+                # the tuples in the reference's emission order (src/cmd_extract.rs:338-351): part of the step --
+                # the host reads the tuple count, then the device bins and sorts the tuples in place
+                nh = int(d_nh.item())
+                if nh > hits_cap:
+                    raise RuntimeError(f"{nh} tuples do not fit the buffer of {hits_cap}")
+                t_o = time.perf_counter()
+                mk._check(lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), nh, st))
+                torch.cuda.synchronize()
+                order_s.append(time.perf_counter() - t_o)
         if args.paired:  # a pair is kept if either mate hits (src/cmd_extract.rs:600-606)
             torch.bitwise_or(mates[0][2], mates[1][2], out=d_keep)
 
@@ -313,6 +333,7 @@ def main():
     torch.cuda.synchronize()
     d_cnt.zero_()
     m.enable_timing(args.steps * n_mates)
+    del order_s[:]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -358,6 +379,7 @@ def main():
                 "patterns": len(patterns), "k": args.k,
                 "sharding": f"contiguous record ranges x{world}" + (", pairs unsplit" if args.paired else ""),
                 "counter_reduction": reduce_via, "kernel": m.kernel_name, "filter": info,
+                "record_lookup": "offsets array" if (args.ragged or args.with_offsets) else "fixed record length (computed)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -379,6 +401,13 @@ def main():
                         "records": int(summ[mk.MK_SUM_RECORDS]), "bases": int(summ[mk.MK_SUM_BASES]),
                         "filter_candidates": int(summ[mk.MK_SUM_CANDIDATES])},
         }
+        if emit and order_s:
+            o_ms = float(np.mean(order_s)) * 1e3
+            out["roofline"]["order_ms_avg"] = round(o_ms, 4)
+            out["roofline"]["order"] = dict(m.order_info(), tuples_per_launch=int(d_nh.item()),
+                                            note="mk_order_hits_device: histogram + scatter + LDS sort per bin, inside the timed step")
+            # the scan and the ordering together against the same algorithmic bytes
+            out["roofline"]["frac_scan_plus_order"] = round(algo_bytes / ((k_avg_ms + o_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if rehearsal:
             out["rehearsal"] = True
             out["rehearsal_note"] = f"{world} ranks share {n_dev} GPU(s): functional check, not a scaling measurement"

@@ -67,7 +67,9 @@ typedef struct mk_matcher mk_matcher;
  * `pos` (0-based) of record `rec`.  == (mat.pattern().as_usize(), mat.start()) of
  * src/cmd_extract.rs:341-342 and the `o` of BNDMq::find_iter (src/cmd_extract.rs:367).
  * Limits of this build: a single record shorter than 4 GiB (`pos` is 32 bits; a batch may hold
- * any number of bytes and records), at most 2^27 - 2 patterns. */
+ * any number of bytes and records), at most 2^27 - 2 patterns and at most 2^26 exact-table entries
+ * (patterns x sampling stride, the stride being 1..16 as mk_matcher_filter_info reports it):
+ * larger sets fail at create time with MK_E_UNSUPPORTED. */
 typedef struct {
     uint64_t rec;
     uint32_t pat;
@@ -217,6 +219,14 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
  * exact verification re-reads every hit window; sparse text with non-temporal loads.  mk_scan_batch
  * and the driver-loop entry points maintain the value themselves from the batch they have just scanned. */
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000);
+
+/* Fixed-length batches (not a hint -- a statement about the data): with record_length > 0 every following
+ * mk_scan_device on this handle takes record i to be d_seq[i * record_length, (i + 1) * record_length):
+ * n_bytes must equal n_rec * record_length (else MK_E_INVALID_ARG) and d_seq_off is NOT read (it may be NULL --
+ * 8 bytes per record the caller need not build).  The record of a verified occurrence is then computed instead
+ * of looked up: one random memory transaction fewer per occurrence.  0 (the default) returns to offsets.
+ * mk_scan_batch and the driver-loop entry points check their host offsets and do this by themselves. */
+int mk_matcher_set_fixed_record_length(mk_matcher *m, uint32_t record_length);
 
 /* Second hint for mk_scan_device: do the records of the batches differ in length (trimmed reads)?  With
  * equal_lengths == 0 every scan first builds a coarse record index (one entry per 64 KiB of text) for the

@@ -21,7 +21,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmerkurio_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "merkurio")
 
-N_VARIANT_TUS = 9
+N_VARIANT_TUS = 10
 HOST_SOURCES = ["matcher.cpp", "host_patterns.cpp", "host_loops.cpp", "reduce.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
@@ -57,6 +57,60 @@ def _deps():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + _headers()
 
 
+def _parse_resource_remarks(stderr):
+    """-Rpass-analysis=kernel-resource-usage -> rows (kernel, vgprs, agprs, sgprs, scratch bytes/lane, LDS
+    bytes/block, waves/SIMD) and the rest of the compiler's output (real warnings and errors)"""
+    import re
+    rows, cur, rest = [], None, []
+    for line in stderr.splitlines():
+        if "[-Rpass-analysis=kernel-resource-usage]" not in line:
+            rest.append(line)
+            continue
+        m = re.search(r"remark:\s+(.*?)\s*\[-Rpass", line)
+        if not m:
+            continue
+        k, _, v = m.group(1).partition(":")
+        k, v = k.strip(), v.strip()
+        if k == "Function Name":
+            cur = {"name": v}
+            rows.append(cur)
+        elif cur is not None:
+            cur[k] = v
+    out = []
+    for r in rows:
+        name = r["name"]
+        try:  # readable names where binutils is installed; the mangled one otherwise
+            name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        except OSError:
+            pass
+        out.append((name, r.get("VGPRs", "?"), r.get("AGPRs", "?"), r.get("TotalSGPRs", r.get("SGPRs", "?")),
+                    r.get("ScratchSize [bytes/lane]", "?"), r.get("LDS Size [bytes/block]", "?"), r.get("Occupancy [waves/SIMD]", "?")))
+    return out, "\n".join(rest) + ("\n" if rest else "")
+
+
+def isa_resources(obj_dir, out_file):
+    """Collects the per-kernel resource records of every device translation unit into one table and
+    REFUSES a build in which a kernel spills: the scan kernel's design rests on "no scratch" (a
+    spilled variant reaches its LDS rings through flat instructions: 3x slower)."""
+    rows = []
+    for f in sorted(os.listdir(obj_dir)):
+        if f.endswith(".isa.txt"):
+            with open(os.path.join(obj_dir, f)) as fh:
+                rows += [line.rstrip("\n").split("\t") for line in fh if line.strip()]
+    if not rows:
+        return None
+    rows.sort(key=lambda r: r[0])
+    with open(out_file, "w") as f:
+        f.write("# kernel\tVGPRs\tAGPRs\tSGPRs\tscratch bytes/lane\tLDS bytes/block (static)\twaves/SIMD\n")
+        for r in rows:
+            f.write("\t".join(r) + "\n")
+    # (the library sort of the fallback path, rocPRIM's merge sort, spills by itself: recorded, not refused)
+    spilled = [r[0] for r in rows if r[4] not in ("0", "?") and "rocprim::" not in r[0]]
+    if spilled:
+        raise RuntimeError("kernels with scratch memory (register spills): " + "; ".join(spilled))
+    return out_file
+
+
 def _compile_lib(out_path, extra_flags, obj_dir, force, verbose):
     os.makedirs(obj_dir, exist_ok=True)
     headers = _headers()
@@ -72,11 +126,26 @@ def _compile_lib(out_path, extra_flags, obj_dir, force, verbose):
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
+        if cmd[-1].endswith(".hip") and "-c" in cmd:
+            # device code: keep the compiler's per-kernel resource remarks next to the object
+            # (registers, scratch, LDS, occupancy) -- see isa_resources() below
+            r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+            obj = cmd[cmd.index("-o") + 1]
+            rows, rest = _parse_resource_remarks(r.stderr)
+            if rest.strip():
+                sys.stderr.write(rest)
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            with open(obj + ".isa.txt", "w") as f:
+                for row in rows:
+                    f.write("\t".join(str(x) for x in row) + "\n")
+            return
         subprocess.run(cmd, check=True)
 
     if jobs:
         with ThreadPoolExecutor(max(1, JOBS)) as ex:
             list(ex.map(run, jobs))
+    isa_resources(obj_dir, os.path.join(os.path.dirname(out_path), "isa_resources" + os.path.basename(out_path)[len("libmerkurio_hip"):-3] + ".txt"))
     if jobs or force or _stale(out_path, objs):
         tmp = out_path + ".tmp.%d" % os.getpid()
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", tmp, *objs, "-ldl", "-lpthread"])

@@ -126,33 +126,52 @@ static std::pair<size_t, size_t> shard_range(size_t n, size_t parts, size_t d) {
 }
 
 // the scalars of src/cmd_extract.rs:285-290 / src/cmd_tag.rs:360-364 and pattern_hit_counts of every
-// device, summed by the library's RCCL all-reduce (mk_reduce_counters): the job's only collective
+// device, summed by the library's RCCL all-reduce (mk_reduce_counters): the job's only collective.
+// The per-device vectors are host values by the time the job ends (the driver loops keep them per batch), so
+// when RCCL cannot be bound or the collective fails the same sum is taken on the host, with a warning -- a
+// job whose records and log rows are already written must not end without its summary.
 static void reduce_device_counters(const std::vector<mk_matcher *> &ms, const std::vector<int> &devs,
                                    const std::vector<mk_counters> &cs, const std::vector<std::vector<uint32_t>> &counts,
                                    mk_counters &c, std::vector<uint32_t> &total_counts) {
     const size_t n_pat = total_counts.size(), len = n_pat + 8;
-    std::vector<void *> dptr(ms.size(), nullptr);
-    auto hip_ok = [](hipError_t e, const char *what) {
-        if (e != hipSuccess) bail(std::string(what) + ": " + hipGetErrorString(e));
-    };
+    std::vector<std::vector<uint64_t>> vec(ms.size(), std::vector<uint64_t>(len, 0));
     for (size_t d = 0; d < ms.size(); ++d) {
-        std::vector<uint64_t> v(len, 0);
+        std::vector<uint64_t> &v = vec[d];
         for (size_t k = 0; k < n_pat; ++k) v[k] = counts[d][k];
         v[n_pat + 0] = cs[d].nb_records_tot; v[n_pat + 1] = cs[d].nb_bases;
         v[n_pat + 2] = cs[d].nb_hits_tot[0]; v[n_pat + 3] = cs[d].nb_hits_tot[1];
         v[n_pat + 4] = cs[d].nb_records_hit[0]; v[n_pat + 5] = cs[d].nb_records_hit[1];
         v[n_pat + 6] = cs[d].nb_records_extracted;
-        hip_ok(hipSetDevice(devs[d]), "hipSetDevice");
-        hip_ok(hipMalloc(&dptr[d], len * sizeof(uint64_t)), "hipMalloc(counter vector)");
-        hip_ok(hipMemcpy(dptr[d], v.data(), len * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy(counter vector)");
     }
     std::vector<uint64_t> sum(len, 0);
-    const int rc = mk_reduce_counters(ms.data(), (int)ms.size(), dptr.data(), len, sum.data());
-    for (size_t d = 0; d < ms.size(); ++d) {
-        (void)hipSetDevice(devs[d]);
-        (void)hipFree(dptr[d]);
+    std::string why;
+    bool reduced = false;
+    if (mk_comm_available() != MK_OK) {
+        why = mk_last_error();
+    } else {
+        std::vector<void *> dptr(ms.size(), nullptr);
+        bool ok = true;
+        for (size_t d = 0; d < ms.size() && ok; ++d) {
+            ok = hipSetDevice(devs[d]) == hipSuccess && hipMalloc(&dptr[d], len * sizeof(uint64_t)) == hipSuccess &&
+                 hipMemcpy(dptr[d], vec[d].data(), len * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) why = "device buffer for the counter vector: " + std::string(hipGetErrorString(hipGetLastError()));
+        }
+        if (ok) {
+            reduced = mk_reduce_counters(ms.data(), (int)ms.size(), dptr.data(), len, sum.data()) == MK_OK;
+            if (!reduced) why = mk_last_error();
+        }
+        for (size_t d = 0; d < ms.size(); ++d)
+            if (dptr[d]) {
+                (void)hipSetDevice(devs[d]);
+                (void)hipFree(dptr[d]);
+            }
     }
-    mk_check(rc, "Error reducing the per-GPU counters");
+    if (!reduced) {
+        fprintf(stderr, "Warning: per-GPU counters summed on the host (RCCL reduction unavailable: %s)\n", why.c_str());
+        std::fill(sum.begin(), sum.end(), 0);
+        for (auto &v : vec)
+            for (size_t k = 0; k < len; ++k) sum[k] += v[k];
+    }
     for (size_t k = 0; k < n_pat; ++k) total_counts[k] = (uint32_t)sum[k];
     c.nb_records_tot = sum[n_pat + 0]; c.nb_bases = sum[n_pat + 1];
     c.nb_hits_tot[0] = sum[n_pat + 2]; c.nb_hits_tot[1] = sum[n_pat + 3];

@@ -19,11 +19,14 @@ void *open_any(std::initializer_list<const char *> names) {
     return nullptr;
 }
 
-const std::string *g_path = nullptr;  // the file being inflated (error text of the memory check)
-void grow(std::vector<char> &out, size_t used) {
+// the output buffer of an inflater: starts small (at most 64 MiB, whatever the compressed size) and doubles; every
+// doubling beyond 256 MiB first checks that the host has the memory (a clear error instead of the OOM killer)
+constexpr size_t kFirstBuffer = 64u << 20;
+size_t first_buffer(size_t compressed) { return std::min<size_t>(std::max<size_t>(compressed * 4, 1u << 20), kFirstBuffer); }
+void grow(std::vector<char> &out, size_t used, const std::string &path) {
     if (out.size() - used < (1u << 16)) {
         const size_t want = std::max<size_t>(out.size() * 2, 1u << 22);
-        if (g_path && want > (1u << 30)) require_host_memory(out.size() + want, *g_path);
+        if (want > (256u << 20)) require_host_memory(out.size() + want, path);
         out.resize(want);
     }
 }
@@ -49,7 +52,7 @@ void inflate_bz2(const std::string &path, const unsigned char *d, size_t n, std:
     auto end = (int (*)(bz_stream *))dlsym(h, "BZ2_bzDecompressEnd");
     if (!init || !run || !end) bail("libbz2 lacks the BZ2_bzDecompress API: " + path);
     size_t used = 0, pos = 0;
-    out.resize(std::max<size_t>(n * 4, 1u << 20));
+    out.resize(first_buffer(n));
     while (pos < n) {  // concatenated streams are legal (pbzip2 writes them)
         if (n - pos < 4 || memcmp(d + pos, "BZh", 3) != 0) {
             if (pos == 0) bail("Error while decompressing " + path);
@@ -67,7 +70,7 @@ void inflate_bz2(const std::string &path, const unsigned char *d, size_t n, std:
                 s.avail_in = (unsigned)piece;
                 fed += piece;
             }
-            grow(out, used);
+            grow(out, used, path);
             const size_t room = std::min<size_t>(out.size() - used, 1u << 30);
             s.next_out = out.data() + used;
             s.avail_out = (unsigned)room;
@@ -116,9 +119,9 @@ void inflate_xz(const std::string &path, const unsigned char *d, size_t n, std::
     s.next_in = d;
     s.avail_in = n;
     size_t used = 0;
-    out.resize(std::max<size_t>(n * 4, 1u << 20));
+    out.resize(first_buffer(n));
     for (;;) {
-        grow(out, used);
+        grow(out, used, path);
         s.next_out = (uint8_t *)out.data() + used;
         s.avail_out = out.size() - used;
         const size_t room = s.avail_out;
@@ -156,9 +159,9 @@ void inflate_zstd(const std::string &path, const unsigned char *d, size_t n, std
     if (!z) bail("Error while decompressing " + path);
     ZSTD_inBuffer in{d, n, 0};
     size_t used = 0, last = 0;
-    out.resize(std::max<size_t>(n * 4, 1u << 20));
+    out.resize(first_buffer(n));
     while (in.pos < in.size || last != 0) {  // frames may be concatenated; last != 0: a frame is still open
-        grow(out, used);
+        grow(out, used, path);
         ZSTD_outBuffer ob{out.data() + used, out.size() - used, 0};
         const size_t before = in.pos;
         last = run(z, &ob, &in);
@@ -175,7 +178,6 @@ void inflate_zstd(const std::string &path, const unsigned char *d, size_t n, std
 }  // namespace
 
 bool inflate_by_magic(const std::string &path, const unsigned char *d, size_t n, std::vector<char> &out) {
-    g_path = &path;
     if (n >= 3 && !memcmp(d, "BZh", 3)) {
         inflate_bz2(path, d, n, out);
         return true;

@@ -508,11 +508,16 @@ void FastxStream::parse_window(const char *d, uint64_t n, uint64_t from, uint64_
     }
     if (stop <= p) stop = std::min(n, p + 1);
     // split at record starts and parse the pieces on host threads
-    const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)io_threads(), (stop - p) / (16u << 20) + 1));
+    uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)io_threads(), (stop - p) / (16u << 20) + 1));
     std::vector<uint64_t> cut(T + 1);
     cut[0] = p;
     cut[T] = stop;
     for (uint64_t t = 1; t < T; ++t) cut[t] = std::min(stop, std::max(cut[t - 1], next_record_start(d, n, p + (stop - p) * t / T, fastq)));
+    // A record longer than a piece (a chromosome in a FASTA) leaves no record start between the last split
+    // targets and `stop`: those cuts were clamped to `stop`, i.e. to the middle of that record.  Drop the empty
+    // trailing pieces, so that the piece that owns the record is the LAST one: it reports where the window really
+    // ends, and it is the one that may find its record cut off by the end of a compressed buffer.
+    while (T > 1 && cut[T - 1] >= stop) --T;  // cut[T] == stop still holds
     std::vector<std::vector<FastxFile::Rec>> parts(T);
     std::vector<uint64_t> ends(T, 0);
     run_threads((size_t)T, [&](size_t t) {

@@ -238,7 +238,11 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     // HBM-resident anyway, and at load <= 0.25 a lookup all but never has to walk to a second bucket
     uint64_t slots = 64;
     while (slots < (m->gbloom_blocks ? 4 : 2) * m->entries) slots <<= 1;
-    if (slots > (1ull << 27))  // bucket index has 26 bits
+    if (slots > (1ull << 27) && m->gbloom_blocks) {  // the largest sets keep load <= 0.5 rather than being refused
+        slots = 64;
+        while (slots < 2 * m->entries) slots <<= 1;
+    }
+    if (slots > (1ull << 27))  // bucket index has 26 bits: at most 2^26 table entries (patterns x stride)
         return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", (unsigned long long)m->entries);
     m->table_slots = (uint32_t)slots;
     const uint32_t gmask = m->gbloom_blocks;  // number of blocks
@@ -361,7 +365,13 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     if (mode > MK_MODE_HITS) return fail(MK_E_INVALID_ARG, "unknown mode %u", mode);
     if (((uintptr_t)d_seq & 15) != 0) return fail(MK_E_INVALID_ARG, "d_seq must be 16-byte aligned");
     if (((uintptr_t)d_rec_flags & 3) != 0) return fail(MK_E_INVALID_ARG, "d_rec_flags must be 4-byte aligned");
-    if (!d_n_hits || !d_rec_flags || (!d_seq_off && n_rec)) return fail(MK_E_INVALID_ARG, "null device buffer");
+    // records of one length (mk_matcher_set_fixed_record_length, or mk_scan_batch's own check of its offsets):
+    // the offsets array is never read
+    const uint32_t rec_len = m->batch_rec_len ? m->batch_rec_len : m->fixed_rec_len;
+    if (rec_len && n_bytes != n_rec * (uint64_t)rec_len)
+        return fail(MK_E_INVALID_ARG, "fixed record length %u: %llu records are not %llu bytes", rec_len, (unsigned long long)n_rec,
+                    (unsigned long long)n_bytes);
+    if (!d_n_hits || !d_rec_flags || (!d_seq_off && n_rec && !rec_len)) return fail(MK_E_INVALID_ARG, "null device buffer");
     if (mode == MK_MODE_HITS && !d_hits && hits_cap) return fail(MK_E_INVALID_ARG, "d_hits is null");
     hipStream_t st = (hipStream_t)stream;
     MK_HIP(hipSetDevice(m->device));
@@ -406,7 +416,9 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     const uint64_t tiles_per_wave = n_tiles / (blocks * waves_per_block);
     p.tile_run = m->tile_run ? m->tile_run : tiles_per_wave >= 16 ? 4 : tiles_per_wave >= 8 ? 2 : 1;
     p.rec_index = nullptr;
-    if (m->ragged && n_rec < (1ull << 32)) {  // coarse record index: one entry per 64 KiB of text, built per scan
+    p.rec_len = rec_len;
+    p.inv_rec_len = rec_len ? 1.0 / (double)rec_len : 0.0;
+    if (m->ragged && !rec_len && n_rec < (1ull << 32)) {  // coarse record index: one entry per 64 KiB of text, built per scan
         int rc_i = ensure((void **)&m->d_rec_index, &m->d_rec_index_cap, ((n_bytes >> kRecIndexShift) + 2) * sizeof(uint32_t));
         if (rc_i) return rc_i;
         launch_rec_index(p.rec_off, n_rec, n_bytes, m->d_rec_index, st);
@@ -422,8 +434,11 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     // per 15 GB.  Everything else: non-temporal stream (16 % faster without hits), 8-byte compare loads,
     // flagged records listed per wave and their bytes set by a small kernel afterwards.  The flavours cross
     // at 12 % of the records (profiles/r02_crossover2.txt).
-    constexpr uint32_t kDensePerMille = 120;
+    constexpr uint32_t kDensePerMille = 120, kSomePerMille = 20;
     const bool plain_loads = m->hit_density_pm >= kDensePerMille;
+    // between the two: the sparse kernel with 16-byte loads in the exact comparison (6 instead of 10 memory requests
+    // per occurrence; the no-hit scan pays 1.4 % for them, which is why the sparse flavour proper does not)
+    const int flavour = plain_loads ? 0 : (m->hit_density_pm >= kSomePerMille ? 2 : 1);
     // the flag-only kernels for sparse hits list the records they flag (one list per scan wave) and a small
     // kernel sets the flag bytes afterwards (scan_kernel_impl.hpp: drain_hits); record indices in the lists are
     // 32 bits.  (Their tuple-emitting twins set the flags from the tuples they stage.)
@@ -431,7 +446,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.flag_list = listed ? m->d_flag_list : nullptr;
     p.flag_counts = m->d_flag_counts;
     p.flag_cap = kFlagListCap;
-    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, plain_loads, (int)blocks, st);
+    const char *name = launch_scan(p, (int)m->S, m->q > 16, mode == MK_MODE_HITS, m->gbloom_blocks != 0, flavour, (int)blocks, st);
     if (!name) return fail(MK_E_UNSUPPORTED, "no kernel for stride %u", m->S);
     if (slots) {
         MK_HIP(hipEventRecord(m->ev_stop[slot], st));
@@ -452,6 +467,12 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
     m->hit_density_pm = records_hit_per_1000 > 1000 ? 1000 : records_hit_per_1000;
+    return MK_OK;
+}
+
+int mk_matcher_set_fixed_record_length(mk_matcher *m, uint32_t record_length) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    m->fixed_rec_len = record_length;
     return MK_OK;
 }
 
@@ -559,7 +580,7 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
     L.ac = m->algo == MK_ALGO_AC ? 1 : 0;
     // first attempt: bins of 2^s consecutive records, s from the record count of the handle's last scan
     uint64_t rec_bound = m->last_n_rec ? m->last_n_rec : (1ull << 32);
-    unsigned long long stats[4] = {0, 0, 0, 0};
+    unsigned long long stats[5] = {0, 0, 0, 0, 0};
     uint32_t s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         s = bits_of(rec_bound - 1) > log_bins ? bits_of(rec_bound - 1) - log_bins : 0;
@@ -580,7 +601,7 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
         if (!beyond && !loose) break;
         rec_bound = stats[0] + 1;
     }
-    const uint32_t bits_rec = bits_of(stats[0]);
+    uint32_t bits_rec = bits_of(stats[0]);
     const uint32_t bits_a = std::max(1u, bits_of(stats[1])), bits_b = std::max(1u, bits_of(stats[2]));
     if (bits_rec + bits_a + bits_b > 64) return order_library(m, hits, n, st);  // the triple does not fit one 64-bit key
     if (s + bits_a > 63) return order_library(m, hits, n, st);  // (cannot happen below 2^31 records)
@@ -590,6 +611,8 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
     if (stats[3] > kOrderLeafMax || (stats[0] >> s) >= L.n_bins) {
         // a bin overflows its LDS sort (few huge records, or hits clustered in one stretch of the batch): bin on the
         // top bits of (record, A) instead, with as many bins as the histogram kernel can hold
+        L.rec_base = ~stats[4];  // the smallest record: the bins span the records that occur, not [0, largest]
+        bits_rec = bits_of(stats[0] - L.rec_base);
         const uint32_t total = bits_rec + bits_a;
         const uint32_t lb = std::min(15u, log_bins + 3);  // ~256 tuples per bin on average: room for skew
         L.shift = total > lb ? total - lb : 0;
@@ -665,12 +688,25 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
     if ((rc = ensure((void **)&m->d_seq, &m->d_seq_cap, n_bytes + 64))) return rc;
     if ((rc = ensure((void **)&m->d_off, &m->d_off_cap, (n_rec + 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure((void **)&m->d_flags, &m->d_flags_cap, n_rec + 8))) return rc;
-    {  // records of unequal length get a coarse index for the record lookup of verified occurrences
+    uint32_t batch_len = 0;
+    {  // records of unequal length get a coarse index for the record lookup of verified occurrences; records of
+       // ONE length need no lookup at all (the kernel computes the record of an occurrence)
         const uint64_t len0 = seq_off[1] - seq_off[0];
         bool equal = true;
         for (uint64_t i = 1; i < n_rec && equal; ++i) equal = seq_off[i + 1] - seq_off[i] == len0;
         m->ragged = !equal;
+        batch_len = (equal && len0 > 0 && len0 < (1ull << 32)) ? (uint32_t)len0 : 0;
     }
+    struct BatchLen {  // holds for the scans of THIS call only; a length set for device scans does not apply to them
+        mk_matcher *m;
+        uint32_t saved;
+        ~BatchLen() {
+            m->batch_rec_len = 0;
+            m->fixed_rec_len = saved;
+        }
+    } batch_len_guard{m, m->fixed_rec_len};
+    m->fixed_rec_len = 0;
+    m->batch_rec_len = batch_len;
     std::vector<uint64_t> rel;
     const uint64_t *off_src = seq_off;
     if (base != 0) {  // device offsets are relative to the first byte uploaded

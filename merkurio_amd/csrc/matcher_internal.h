@@ -30,6 +30,9 @@ struct mk_matcher {
     // records of unequal length (set by mk_scan_batch from the offsets it is given, or by
     // mk_matcher_hint_record_lengths): every scan then builds a coarse record index first
     bool ragged = false;
+    // > 0: every record of a device scan has this length (mk_matcher_set_fixed_record_length: the caller's
+    // contract) / of the mk_scan_batch call in progress (checked on its host offsets)
+    uint32_t fixed_rec_len = 0, batch_rec_len = 0;
     uint32_t *d_rec_index = nullptr;
     size_t d_rec_index_cap = 0;
     mk::TableEntry *d_table = nullptr;

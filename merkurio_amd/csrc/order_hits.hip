@@ -16,7 +16,7 @@
 //              ascending) order (identity for a k-mer set: all lengths equal) -- "longer pattern first,
 //              then pattern id" at one end IS that rank;
 //       BNDMq: A = pattern, B = pos;
-//   G = record << bits(A) | A;  bin = G >> shift;  key = (G mod 2^shift) << bits(B) | B   (8 bytes).
+//   G = (record - base) << bits(A) | A;  bin = G >> shift;  key = (G mod 2^shift) << bits(B) | B   (8 bytes).
 //
 //   1. mk_order_hist_kernel     reads the tuples once: tuples per bin (LDS histogram per workgroup, one
 //                               global atomic per non-empty bin) and the maxima of record, A and B;
@@ -82,20 +82,22 @@ __device__ __forceinline__ uint64_t wave_max(uint64_t v) {
 __global__ __launch_bounds__(kOrderThreads) void mk_order_hist_kernel(const mk_hit *__restrict__ hits, uint64_t n, uint32_t *__restrict__ g_cnt,
                                                                        unsigned long long *__restrict__ stats, const OrderKey L) {
     extern __shared__ uint32_t lds_cnt[];
-    __shared__ unsigned long long red[3];
+    __shared__ unsigned long long red[4];
     for (uint32_t i = threadIdx.x; i < L.n_bins; i += kOrderThreads) lds_cnt[i] = 0;
-    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    if (threadIdx.x < 4) red[threadIdx.x] = 0;
     __syncthreads();
     // a contiguous slab per workgroup: consecutive tuples share bins, few bins to flush
     uint64_t per = (n + gridDim.x - 1) / gridDim.x;
     per = (per + kOrderThreads - 1) / kOrderThreads * kOrderThreads;
     const uint64_t lo = (uint64_t)blockIdx.x * per, hi = std::min<uint64_t>(n, lo + per);
-    uint64_t mr = 0, ma = 0, mb = 0;
+    uint64_t mr = 0, ma = 0, mb = 0, mn = 0;  // mn = max of ~record: the smallest record, complemented
     const uint4 *__restrict__ hv = reinterpret_cast<const uint4 *>(hits);
     for (uint64_t i = lo + threadIdx.x; i < hi; i += kOrderThreads) {
         uint64_t rec, a, b;
         tuple_fields(L, hv[i], rec, a, b);
         mr = rec > mr ? rec : mr;
+        mn = ~rec > mn ? ~rec : mn;
+        rec -= L.rec_base;
         ma = a > ma ? a : ma;
         mb = b > mb ? b : mb;
         const uint64_t g = L.bits_a ? ((rec << L.bits_a) | a) : rec;
@@ -105,7 +107,9 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_hist_kernel(const mk_h
     mr = wave_max(mr);
     ma = wave_max(ma);
     mb = wave_max(mb);
+    mn = wave_max(mn);
     if ((threadIdx.x & 63) == 0) {
+        atomicMax(&red[3], (unsigned long long)mn);
         atomicMax(&red[0], (unsigned long long)mr);
         atomicMax(&red[1], (unsigned long long)ma);
         atomicMax(&red[2], (unsigned long long)mb);
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_hist_kernel(const mk_h
         if (c) atomicAdd(&g_cnt[i], c);
     }
     if (threadIdx.x < 3 && red[threadIdx.x]) atomicMax(&stats[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x == 3 && red[3]) atomicMax(&stats[4], red[3]);  // stats[3] is the largest bin (scan kernel)
 }
 
 // ---- bin starts (exclusive prefix sum over <= 32768 bins, one workgroup) and the largest bin -------------
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_scatter_kernel(const m
             if (i < n) {
                 uint64_t rec, a, b;
                 tuple_fields(L, hv[i], rec, a, b);
-                const uint64_t g = (rec << L.bits_a) | a;
+                const uint64_t g = ((rec - L.rec_base) << L.bits_a) | a;
                 const uint64_t d = g >> L.shift;
                 bin[k] = d < L.n_bins ? (uint32_t)d : L.n_bins - 1;
                 key[k] = ((g & low_mask) << L.bits_b) | b;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint
     for (uint32_t i = tid; i < cnt; i += T) {
         const uint64_t k = sk[padi(i)];
         const uint64_t g = ((uint64_t)bin << L.shift) | (k >> L.bits_b);
-        const uint64_t b = k & mask_b, a = g & mask_a, rec = g >> L.bits_a;
+        const uint64_t b = k & mask_b, a = g & mask_a, rec = (g >> L.bits_a) + L.rec_base;
         uint32_t pat, pos;
         if (L.ac) {
             pat = L.unrank ? L.unrank[(uint32_t)b] : (uint32_t)b;

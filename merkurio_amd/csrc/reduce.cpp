@@ -13,7 +13,39 @@
 // PyTorch already mapped is the one used): a host that never reduces needs no RCCL at all.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+
+// The handful of RCCL declarations this file needs, written out here: the library builds on hosts that have
+// the ROCm runtime but not the RCCL development headers, and binds librccl at run time or not at all.  The
+// names and values are RCCL's public, stable C ABI (rccl.h: ncclResult_t, ncclDataType_t, ncclRedOp_t,
+// NCCL_UNIQUE_ID_BYTES = 128); where the header is installed the static_asserts below compare them.
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define MK_HAVE_RCCL_H 1
+#endif
+#endif
+#ifndef MK_HAVE_RCCL_H
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
+static_assert(sizeof(ncclUniqueId) == 128 && (int)ncclUint64 == 5 && (int)ncclSum == 0 && (int)ncclSuccess == 0,
+              "RCCL ABI constants differ from the ones declared in reduce.cpp");
 
 #include <algorithm>
 #include <cstring>
@@ -106,7 +138,7 @@ std::map<std::vector<int>, std::vector<ncclComm_t>> g_comm_sets;
 
 }  // namespace
 
-static_assert(MK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+static_assert(MK_COMM_ID_BYTES == sizeof(ncclUniqueId), "id size");
 
 extern "C" {
 

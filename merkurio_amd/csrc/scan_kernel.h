@@ -35,6 +35,10 @@ struct ScanParams {
     // records of unequal length: rec_index[k] = index of the record that contains byte k * 64 Ki (one more
     // entry behind the last); null = equal lengths, the quotient p * rec_per_byte is the record
     const uint32_t *rec_index;
+    // records of ONE length (rec_off[i] == i * rec_len, the caller's contract or mk_scan_batch's own check): the
+    // record of a verified occurrence is computed, rec_off is never read (it may be null)
+    uint32_t rec_len;
+    double inv_rec_len;
     // per-scan-wave staging of verified occurrences (EMIT kernels; kHitStage tuples each)
     mk_hit *stage;
     // outputs
@@ -53,13 +57,13 @@ struct ScanParams {
 
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
-// plain_loads: the stream is read with cacheable loads (hit-dense text); honoured by the k-mer-family
-// kernels of the LDS filter, ignored by the others.
-const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, bool plain_loads, int grid_blocks,
+// flavour: 1 sparse hits, 2 some hits (16-byte compare loads; k-mer families of the LDS filter only, else as 1),
+// 0 hit-dense text (scan_kernel_impl.hpp: FL)
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream);
 
 // host-side launcher of one kernel variant; defined (explicitly instantiated) in scan_variants.hip
-template <int S, int QC, bool EMIT, bool GF, bool NTL>
+template <int S, int QC, bool EMIT, bool GF, int FL>
 void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream);
 
 // static LDS bytes of one scan workgroup (filter + candidate rings + pattern counters)
@@ -85,6 +89,7 @@ struct OrderKey {
     uint32_t uniform_len;     // != 0: every pattern has this length (no lookup)
     const uint32_t *rank;     // AC with mixed lengths: rank[pat] in (length descending, index ascending) order; null = identity
     const uint32_t *unrank;   // its inverse
+    uint64_t rec_base;        // subtracted from every record index (the smallest one when re-binning; else 0)
     uint32_t ac;              // 1: Aho-Corasick order, 0: BNDMq order
     uint32_t bits_a;          // width of A inside G; 0 = histogram on the record alone (field widths not known yet)
     uint32_t bits_b;          // width of B inside the key (1..63)
@@ -92,7 +97,7 @@ struct OrderKey {
     uint32_t n_bins;          // <= kOrderMaxBins
 };
 struct OrderScratch {
-    unsigned long long *stats;  // [0..2] maxima of record, A, B; [3] largest bin
+    unsigned long long *stats;  // [0..2] maxima of record, A, B; [3] largest bin; [4] ~(smallest record)
     uint32_t *g_cnt;            // n_bins
     uint32_t *bin_start;        // n_bins + 1
     uint32_t *cursor;           // n_bins

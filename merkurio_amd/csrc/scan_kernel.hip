@@ -162,9 +162,9 @@ void launch_add_u64(unsigned long long *dst, const unsigned long long *src, size
 
 // the kernel variants are instantiated in groups by scan_variants.hip (one translation unit per
 // group, compiled in parallel); launch_variant<...> is the host-side launcher of one of them
-template <int S, int QC, bool EMIT, bool GF, bool NTL = true>
+template <int S, int QC, bool EMIT, bool GF, int FL = 1>
 static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
-    launch_variant<S, QC, EMIT, GF, NTL>(p, grid, st);
+    launch_variant<S, QC, EMIT, GF, FL>(p, grid, st);
     return name;
 }
 
@@ -173,11 +173,16 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
                 : launch_one<S_, QC_, false, GF_>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false," #GF_ ">")
 
 #define MK_VARIANT_PLAIN(S_, QC_)                                                                                       \
-    return emit ? launch_one<S_, QC_, true, false, false>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,plain>") \
-                : launch_one<S_, QC_, false, false, false>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,plain>")
+    return emit ? launch_one<S_, QC_, true, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,plain>") \
+                : launch_one<S_, QC_, false, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,plain>")
 
-const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, bool plain_loads, int grid_blocks,
+#define MK_VARIANT_MID(S_, QC_)                                                                                    \
+    return emit ? launch_one<S_, QC_, true, false, 2>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,cmp16>") \
+                : launch_one<S_, QC_, false, false, 2>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,cmp16>")
+
+const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream) {
+    const bool plain_loads = flavour == 0;
     if (global_filter) {  // large pattern sets: filter blocks in global memory
         if (S == 8 && p.q == 14) MK_VARIANT(8, 14, true);  // 21-mers
         if (S == 4 && p.q == 18) MK_VARIANT(4, 18, true);
@@ -223,6 +228,12 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
             default: return nullptr;
         }
     }
+    if (flavour == 2) {  // some hits: the k-mer families with 16-byte compare loads (everything else: as sparse)
+        if (S == 16 && p.q == 16) MK_VARIANT_MID(16, 16);
+        if (S == 8 && p.q == 24) MK_VARIANT_MID(8, 24);
+        if (S == 4 && p.q == 28) MK_VARIANT_MID(4, 28);
+        if (S == 4 && p.q == 18) MK_VARIANT_MID(4, 18);
+    }
     if (S == 16 && p.q == 16) MK_VARIANT(16, 16, false);
     if (S == 8 && p.q == 24) MK_VARIANT(8, 24, false);
     if (S == 4 && p.q == 28) MK_VARIANT(4, 28, false);
@@ -247,6 +258,7 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
 }
 #undef MK_VARIANT
 #undef MK_VARIANT_PLAIN
+#undef MK_VARIANT_MID
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
 // byte0 = global position of seq[0] in the synthetic stream (a multiple of 32)

@@ -91,7 +91,10 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 // byte-exact (or ASCII-case-folded) comparison of the whole pattern, record lookup, boundary
 // check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
 // its tuple in `out`.
-template <bool EMIT, bool WIDE>
+// FL = flavour of the kernel variant: 1 sparse hits (non-temporal stream, 8-byte compare loads, flagged records
+// listed), 2 some hits (the same with 16-byte compare loads), 0 hit-dense text (cacheable stream, 16-byte
+// compare loads, flags stored directly)
+template <bool EMIT, int FL>
 __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true, mk_hit &out) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
     if constexpr ((MK_ABLATE & 16) != 0) return false;
@@ -104,38 +107,55 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     // together and costs ONE round trip: the record-offset pair at the interpolated record
     // index (reads are mostly of similar length, so the guess is usually right) and the text /
     // pattern loads of the comparison.
+    constexpr bool WIDE = FL != 1;  // 16-byte loads
     const uint64_t n = P.n_rec;
-    // + 1e-6: with equal-length records the quotient of a record's FIRST byte is an integer, and the rounded
-    // factor n_rec / n_bytes can land it a hair below -- the guess is then one record short and the wave
-    // walks the gallop / bisect path (4-5 dependent memory round trips) for it: 0.8 % of the occurrences,
-    // i.e. 4 of 10 drains of 64.  The nudge is far below 1 / record length and above the rounding error
-    // for up to ~10^10 records.
-    uint64_t lo = (uint64_t)((double)p * P.rec_per_byte + 1e-6);
-    if (P.rec_index) {
-        // records of unequal length: the quotient drifts by thousands of records over a 15 GB batch and the
-        // gallop below would take ~20 dependent memory round trips (+8 % kernel time at 1 % of the reads
-        // hitting, r02_ragged_sweep).  A coarse index -- the record at every 64 Ki-th byte, L2-resident --
-        // and interpolation inside its 64 KiB window land within a record or two.
-        const uint32_t k = (uint32_t)(p >> kRecIndexShift);
-        const uint32_t r0 = P.rec_index[k], r1 = P.rec_index[k + 1];
-        lo = r0 + ((((uint32_t)p & ((1u << kRecIndexShift) - 1u)) * (uint64_t)(r1 - r0 + 1)) >> kRecIndexShift);
-        if (lo > r1) lo = r1;
-    }
-    if (lo >= n) lo = n - 1;
-    // Two forms of the loads below, chosen with the kernel variant (WIDE = the plain-load kernels,
-    // which run when many reads hit).  With every read hitting the kernel is bound by the number of
-    // memory REQUESTS per occurrence, so the record-offset pair is one 16-byte request and a pattern of
-    // 16..32 bytes -- every k-mer -- is compared with two overlapping 16-byte loads a side, [0, 16) and
-    // [len - 16, len): 7.7 -> 5.9 ms per 100 M reads.  In the kernels for sparse hits the same code costs
-    // the scan loop around it 1.4 % (register allocation; r02_cmp16_ab) and gains little, so they keep
-    // 8-byte loads.  (seq_off[0] == 0 is part of the ABI.)
-    uint64_t rstart, rend;
-    if constexpr (WIDE) {
-        uint64_t rpair[2];
-        __builtin_memcpy(rpair, P.rec_off + lo, 16);
-        rstart = rpair[0], rend = rpair[1];
+    uint64_t rstart, rend, lo;
+    if (P.rec_len) {
+        // records of one length: record = floor(p / L), no memory access.  The double product is within one of the
+        // quotient (p < 2^53, 1 / L rounded once); one compare-and-step makes it exact.
+        lo = (uint64_t)((double)p * P.inv_rec_len);
+        rstart = lo * P.rec_len;
+        if (rstart > p) {
+            --lo;
+            rstart -= P.rec_len;
+        } else if (p - rstart >= P.rec_len) {
+            ++lo;
+            rstart += P.rec_len;
+        }
+        rend = rstart + P.rec_len;
     } else {
-        rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];
+        // + 1e-6: with equal-length records the quotient of a record's FIRST byte is an integer, and the rounded
+        // factor n_rec / n_bytes can land it a hair below -- the guess is then one record short and the wave
+        // walks the gallop / bisect path (4-5 dependent memory round trips) for it: 0.8 % of the occurrences,
+        // i.e. 4 of 10 drains of 64.  The nudge is far below 1 / record length and above the rounding error
+        // for up to ~10^10 records.
+        lo = (uint64_t)((double)p * P.rec_per_byte + 1e-6);
+        if (P.rec_index) {
+            // records of unequal length: the quotient drifts by thousands of records over a 15 GB batch and the
+            // gallop below would take ~20 dependent memory round trips (+8 % kernel time at 1 % of the reads
+            // hitting, r02_ragged_sweep).  A coarse index -- the record at every 64 Ki-th byte, L2-resident --
+            // and interpolation inside its 64 KiB window land within a record or two.
+            const uint32_t k = (uint32_t)(p >> kRecIndexShift);
+            const uint32_t r0 = P.rec_index[k], r1 = P.rec_index[k + 1];
+            lo = r0 + ((((uint32_t)p & ((1u << kRecIndexShift) - 1u)) * (uint64_t)(r1 - r0 + 1)) >> kRecIndexShift);
+            if (lo > r1) lo = r1;
+        }
+        if (lo >= n) lo = n - 1;
+        // Two forms of the loads below, chosen with the kernel variant (WIDE = every flavour but the one for
+        // sparse hits).  Once more than a few reads in a hundred hit, the kernel is bound by the number of
+        // memory REQUESTS per occurrence (the L2 serves ~200 G of them a second next to the stream), so the
+        // record-offset pair is one 16-byte request and a pattern of 16..32 bytes -- every k-mer -- is compared
+        // with two overlapping 16-byte loads a side, [0, 16) and [len - 16, len): 7.7 -> 5.9 ms per 100 M reads
+        // when every read hits.  In the kernels for sparse hits the same code costs the scan loop around it
+        // 1.4 % (register allocation; r02_cmp16_ab) and gains nothing, so they keep 8-byte loads; from 2 % of
+        // the records hitting the host launches the 16-byte twin (FL = 2).  (seq_off[0] == 0 is part of the ABI.)
+        if constexpr (WIDE) {
+            uint64_t rpair[2];
+            __builtin_memcpy(rpair, P.rec_off + lo, 16);
+            rstart = rpair[0], rend = rpair[1];
+        } else {
+            rstart = P.rec_off[lo], rend = P.rec_off[lo + 1];
+        }
     }
     if (P.case_insensitive) {
         for (uint32_t i = 0; i < len; ++i)
@@ -277,8 +297,9 @@ __device__ __forceinline__ void flush_stage(const ScanParams &P, HitRing &hr, ui
     hr.staged = 0;
 }
 
-template <bool EMIT, bool WIDE>
+template <bool EMIT, int FL>
 __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uint64_t newest_end, uint32_t lane, uint32_t &n_true) {
+    constexpr bool WIDE = FL == 0;  // hit-dense text: flags stored directly
     const uint32_t n = hr.count;
     // entries were written by other lanes of this wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -290,7 +311,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
     if (lane < n) {
         uint64_t p = (newest_end & 0xFFFFFFFF00000000ull) | e.x;
         if (p >= newest_end) p -= 1ull << 32;
-        hit = resolve_one<EMIT, WIDE>(P, e.y, p, n_true, out);
+        hit = resolve_one<EMIT, FL>(P, e.y, p, n_true, out);
     }
     hr.count = 0;
     // The record's flag.  A byte stored into the 100 MB flag array is a partial write to a line that is
@@ -328,7 +349,7 @@ __device__ __forceinline__ void drain_hits(const ScanParams &P, HitRing &hr, uin
 // hit ring; returns whether this lane must look at the next bucket (its bucket has overflowed).
 // CS > 0: context kernels (filter.hpp: gf_has_ctx), CS = the sampling stride; an entry's fingerprint
 // is then the q-gram hash mixed with the candidate's context bases under the mask of the entry's offset.
-template <bool EMIT, int CS, bool WIDE>
+template <bool EMIT, int CS, int FL>
 __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, uint32_t fp, uint32_t ctx, uint64_t t, uint4 v0, uint4 v1,
                                             uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true) {
     const uint32_t efp[4] = {v0.x, v0.z, v1.x, v1.z};
@@ -342,7 +363,7 @@ __device__ __forceinline__ bool probe_round(const ScanParams &P, bool active, ui
         const uint64_t mm = (MK_ABLATE & 64) ? 0ull : __ballot(match);
         if (mm) {  // uniform, rare
             const uint32_t cnt = (uint32_t)__popcll(mm);
-            if (hr.count + cnt > kHitSlots) drain_hits<EMIT, WIDE>(P, hr, newest_end, lane, n_true);  // make room
+            if (hr.count + cnt > kHitSlots) drain_hits<EMIT, FL>(P, hr, newest_end, lane, n_true);  // make room
             if (match) {
                 const uint32_t below =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
@@ -367,13 +388,13 @@ __device__ __forceinline__ void load_bucket(const ScanParams &P, bool active, ui
 
 // synchronous probe: wave-uniform loop over the bucket chain (one iteration unless a home
 // bucket is full), each iteration one memory round trip
-template <bool EMIT, int CS, bool WIDE>
+template <bool EMIT, int CS, int FL>
 __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, uint32_t b, uint32_t fp, uint32_t ctx, uint64_t t,
                                             uint32_t lane, HitRing &hr, uint64_t newest_end, uint32_t &n_true) {
     while (__ballot(active)) {
         uint4 v0, v1;
         load_bucket(P, active, b, v0, v1);
-        active = probe_round<EMIT, CS, WIDE>(P, active, fp, ctx, t, v0, v1, lane, hr, newest_end, n_true);
+        active = probe_round<EMIT, CS, FL>(P, active, fp, ctx, t, v0, v1, lane, hr, newest_end, n_true);
         b = (b + 1) & P.table_mask;
     }
 }
@@ -444,15 +465,16 @@ __device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32
 }
 
 // ---- main kernel -----------------------------------------------------------------------
-template <int S, int QC, bool EMIT, bool GF, bool NTL>
+template <int S, int QC, bool EMIT, bool GF, int FL>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
+    constexpr bool NTL = FL != 0;  // non-temporal stream loads
     // context kernels: global filter with a compile-time q (filter.hpp: gf_has_ctx); kPipe: their
     // filter probes run one chunk ahead of their use (two samples per lane keeps that in registers)
     constexpr bool kCtx = GF && QC > 0;
     constexpr int CS = kCtx ? S : 0;
     using G = Geo<S, QC, kCtx>;
     constexpr bool kPipe = kCtx && G::kNS <= 2 && (MK_ABLATE & 7) == 0;
-    constexpr bool kWide = !NTL;  // level-3 loads: resolve_one
+    constexpr bool kWide = FL == 0;  // hit-dense flavour: flags stored directly (drain_hits)
     __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
     uint32_t *lds_sums = bloom + kLdsBytes / 4 - kLdsSumWords;
     if (threadIdx.x < kLdsSumWords) lds_sums[threadIdx.x] = 0;
@@ -579,7 +601,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         uint64_t t;
         uint32_t ctx;
         take_from_ring(n, active, b, fp, ctx, t);
-        probe_chain<EMIT, CS, kWide>(P, active, b, fp, ctx, t, lane, hr, newest_end, n_true);
+        probe_chain<EMIT, CS, FL>(P, active, b, fp, ctx, t, lane, hr, newest_end, n_true);
     };
     auto issue_probe = [&](uint32_t n) __attribute__((always_inline)) {  // asynchronous: loads only
         take_from_ring(n, pend_active, pend_b, pend_fp, pend_ctx, pend_t);
@@ -587,9 +609,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         pend_on = true;
     };
     auto consume_probe = [&]() __attribute__((always_inline)) {
-        const bool more = probe_round<EMIT, CS, kWide>(P, pend_active, pend_fp, pend_ctx, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true);
+        const bool more = probe_round<EMIT, CS, FL>(P, pend_active, pend_fp, pend_ctx, pend_t, pend_v0, pend_v1, lane, hr, newest_end, n_true);
         if (__ballot(more))  // some home bucket had overflowed: finish those chains synchronously
-            probe_chain<EMIT, CS, kWide>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_ctx, pend_t, lane, hr, newest_end, n_true);
+            probe_chain<EMIT, CS, FL>(P, more, (pend_b + 1) & P.table_mask, pend_fp, pend_ctx, pend_t, lane, hr, newest_end, n_true);
         pend_on = false;
     };
 
@@ -746,7 +768,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             if (base - last_push_base >= (1ull << 30)) {
                 last_push_base = base;
                 flush_slots();
-                if (hr.count) drain_hits<EMIT, kWide>(P, hr, newest_end, lane, n_true);  // 32-bit positions too
+                if (hr.count) drain_hits<EMIT, FL>(P, hr, newest_end, lane, n_true);  // 32-bit positions too
                 if (q_count && !pend_on) issue_probe(q_count < 64 ? q_count : 64);
             }
 #pragma unroll 1
@@ -860,7 +882,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     // drain what is left in this wave's slots and rings
     flush_slots();
     while (q_count) drain_ring(q_count < 64 ? q_count : 64);
-    if (hr.count) drain_hits<EMIT, kWide>(P, hr, newest_end, lane, n_true);
+    if (hr.count) drain_hits<EMIT, FL>(P, hr, newest_end, lane, n_true);
     if constexpr (EMIT) flush_stage<!kWide>(P, hr, lane);
     if (hr.flist && lane == 0) P.flag_counts[wave_id] = hr.nflag;  // every wave of the grid, empty lists too
     if ((MK_ABLATE & 1) != 0 && abl_acc == 0xFFFFFFFFu) n_cand++;

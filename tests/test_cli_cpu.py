@@ -179,6 +179,46 @@ def test_windowed_fastx_reader(tmp_path):
             assert last.split()[2] == str(len(recs)) and (w >= 1 << 30) == (last.split()[0] == "1"), (name, w, last)
 
 
+def test_fasta_records_longer_than_a_parse_piece(tmp_path):
+    """a window is parsed in pieces on the host threads; a FASTA record longer than a piece (a chromosome) leaves
+    the trailing pieces empty -- the piece that owns the record must then be the one that says where the window
+    ends (plain input) and the one allowed to find its record cut off by the buffer end (gzip input)"""
+    import gzip
+    import numpy as np
+    cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
+    exe = str(tmp_path / "fs")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/fastx_stream_harness.cpp"),
+                    os.path.join(cli_dir, "io.cpp"), os.path.join(cli_dir, "decompress.cpp"), os.path.join(cli_dir, "util.cpp"),
+                    "-lz", "-ldl", "-lpthread"], check=True)
+    g = np.random.default_rng(4)
+    lens = [36 << 20, 100, 40 << 20, 33 << 20, 7]
+    seqs = [np.frombuffer(b"ACGT", dtype=np.uint8)[g.integers(0, 4, n)] for n in lens]
+
+    fa = bytearray()
+    for i, sq in enumerate(seqs):
+        fa += f">chr{i} x\n".encode()
+        body = sq.tobytes()
+        if len(body) > 1000:  # 80-column lines
+            lines = np.frombuffer(body[:len(body) // 80 * 80], dtype=np.uint8).reshape(-1, 80)
+            fa += np.concatenate([lines, np.full((lines.shape[0], 1), 10, dtype=np.uint8)], axis=1).tobytes()
+            fa += body[len(body) // 80 * 80:] + b"\n"
+        else:
+            fa += body + b"\n"
+    (tmp_path / "g.fasta").write_bytes(bytes(fa))
+    (tmp_path / "g.fasta.gz").write_bytes(gzip.compress(bytes(fa), 1))
+    env = dict(os.environ, MERKURIO_IO_THREADS="8")
+    ref = None
+    for name in ("g.fasta", "g.fasta.gz"):
+        for w in (64 << 20, 48 << 20, 1 << 30):
+            out = subprocess.run([exe, str(tmp_path / name), str(w), "0", "digest"], capture_output=True, text=True, env=env).stdout
+            assert "#error" not in out, (name, w, out[-300:])
+            rows = [l.split("\t") for l in out.splitlines() if not l.startswith("#")]
+            assert [r[0] for r in rows] == [f"chr{i} x" for i in range(len(lens))], (name, w, out[-300:])
+            assert [int(r[1]) for r in rows] == lens, (name, w)
+            ref = ref or [r[2] for r in rows]
+            assert [r[2] for r in rows] == ref, (name, w)  # the same bytes whatever the window and the container
+
+
 def test_windowed_sam_bam_reader(tmp_path, golden):
     """tag reads its input a window at a time (SamFile::open / fill): SAM text, BGZF BAM, a BAM written as ONE
     gzip member, and an uncompressed BAM must yield the same header and records whatever the window size."""

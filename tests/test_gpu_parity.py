@@ -385,7 +385,7 @@ def test_sparse_and_dense_kernel_variants_agree(mk, lens, options):
     assert len(exp) > 600
     m = mk.Matcher(patterns, algo=mk.MK_ALGO_AC, options=options)
     names = set()
-    for density in (0, 1000):
+    for density in (0, 50, 1000):  # sparse / some hits (16-byte compare, k-mer families only) / hit-dense
         for mode in (mk.MK_MODE_HITS, mk.MK_MODE_ANY):
             m.hint_hit_density(density)  # mk_scan_batch replaces it with what the batch showed: set before each scan
             flags, hits = m.scan(recs, mode, hits_cap=len(exp) + 16)  # one launch: no capacity retry
@@ -393,7 +393,78 @@ def test_sparse_and_dense_kernel_variants_agree(mk, lens, options):
             assert flags.tolist() == [bool(f) for f in found_exp], (density, mode)
             if mode == mk.MK_MODE_HITS:
                 assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp, density
-    assert len(names) == 4 and sum(n.endswith("plain>") for n in names) == 2, names
+    fixed_q = options is not None and (options["force_stride"], min(lens)) in ((16, 31), (8, 31), (4, 31), (4, 21))
+    assert sum(n.endswith("plain>") for n in names) == 2, names
+    assert sum(n.endswith("cmp16>") for n in names) == (2 if fixed_q else 0), names
+    assert len(names) == (6 if fixed_q else 4), names
+
+
+@pytest.mark.parametrize("L,k", [(150, 31), (100, 21), (31, 31), (33, 31), (250, 21)])
+def test_fixed_record_length_batches(mk, L, k):
+    """records of one length: mk_scan_batch finds that out from its offsets, device callers state it with
+    mk_matcher_set_fixed_record_length (no offsets array at all) -- the record of an occurrence is then computed,
+    not looked up.  Same result set as the oracle in every kernel flavour, for occurrences on the first and the
+    last byte of a record and text that matches across a record border (no occurrence); a wrong byte count is
+    refused."""
+    torch = pytest.importorskip("torch")
+    rnd = random.Random(L * 1000 + k)
+    raw = [_rand_seq(rnd, k, b"ACGT") for _ in range(200)]
+    patterns = mk.parse_pattern_list(kmer_seq=raw)
+    n_rec = 30_000
+    buf = bytearray(_rand_seq(rnd, n_rec * L, b"ACGT"))
+    for i in range(0, n_rec, 3):
+        p = rnd.choice(patterns)
+        where = rnd.choice(["first", "last", "any", "straddle"])
+        if where == "first":
+            o = i * L
+        elif where == "last":
+            o = (i + 1) * L - k
+        elif where == "any":
+            o = i * L + rnd.randrange(0, L - k + 1)
+        else:  # across the border to the next record: not an occurrence of either
+            o = (i + 1) * L - rnd.randrange(1, k)
+        if o + k <= len(buf):
+            buf[o:o + k] = p
+    recs = [bytes(buf[i * L:(i + 1) * L]) for i in range(n_rec)]
+    exp, _, found_exp = _oracle_hits(patterns, True, recs)
+    assert len(exp) > 5000
+    m = mk.Matcher(patterns, algo=mk.MK_ALGO_AC)
+    lib = mk.load()
+    dev = torch.device("cuda", 0)
+    d_seq = torch.zeros(len(buf) + 64, dtype=torch.uint8, device=dev)
+    d_seq[:len(buf)] = torch.frombuffer(bytes(buf), dtype=torch.uint8).to(dev)
+    d_flags = torch.zeros(n_rec + 8, dtype=torch.uint8, device=dev)
+    cap = len(exp) + 16
+    d_hits = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mk_matcher_set_fixed_record_length(m.handle, L) == 0
+    names = set()
+    for density in (0, 50, 1000):
+        m.hint_hit_density(density)
+        # no offsets array: d_seq_off = NULL
+        assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), len(buf), None, n_rec, mk.MK_MODE_HITS, d_flags.data_ptr(),
+                                  d_hits.data_ptr(), cap, d_nh.data_ptr(), None, st) == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        names.add(m.kernel_name)
+        nh = int(d_nh.item())
+        assert nh == len(exp), density
+        assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), nh, st) == 0
+        torch.cuda.synchronize()
+        got = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)[:nh]
+        assert list(zip(got["rec"].tolist(), got["pat"].tolist(), got["pos"].tolist())) == exp, density
+        assert d_flags[:n_rec].cpu().numpy().astype(bool).tolist() == [bool(f) for f in found_exp], density
+    assert len(names) == 3, names
+    # the byte count must be n_rec * L
+    assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), len(buf) - 1, None, n_rec, mk.MK_MODE_ANY, d_flags.data_ptr(),
+                              None, 0, d_nh.data_ptr(), None, st) == mk.MK_E_INVALID_ARG
+    # back to offsets: a null offsets pointer is refused again
+    assert lib.mk_matcher_set_fixed_record_length(m.handle, 0) == 0
+    assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), len(buf), None, n_rec, mk.MK_MODE_ANY, d_flags.data_ptr(),
+                              None, 0, d_nh.data_ptr(), None, st) == mk.MK_E_INVALID_ARG
+    # and mk_scan_batch (host buffers, equal lengths detected) agrees
+    flags, hits = m.scan(recs, mk.MK_MODE_HITS, hits_cap=cap)
+    assert list(zip(hits["rec"].tolist(), hits["pat"].tolist(), hits["pos"].tolist())) == exp
 
 
 def test_device_out_of_memory_is_an_error_code(mk):
