@@ -82,7 +82,7 @@ def measured_traffic(kernel, n_rec, read_len, n_pat):
     return None, None
 
 
-def make_patterns(n, k, seed=0x4D65724B):
+def make_patterns(n, k, seed=0x4D65724B):  # (the pattern set of a run never depends on anything but n, k, seed)
     import numpy as np
     rng = np.random.default_rng(seed)
     codes = rng.integers(0, 4, size=(int(n * 1.01) + 8, k), dtype=np.uint8)
@@ -118,6 +118,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-counters", action="store_true", help="diagnostic: scan without the device counter vector")
     ap.add_argument("--no-order", action="store_true", help="diagnostic with --mode hits: leave the tuples unordered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default workload only: skip the short runs of the other BASELINE configurations that are "
+                         "appended to the JSON line as other_configs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     # filter-geometry tuning hooks (mk_matcher_options; results never depend on them)
     ap.add_argument("--force-stride", type=int, default=0)
@@ -281,26 +284,11 @@ def main():
     # ---- the job's only collective, through the C ABI (RCCL); torch.distributed carries the id
     reduce_via = "none (1 GPU)"
     if use_dist and not rehearsal:
-        # every rank first checks that it can bind RCCL through the library (a probe id), and all
-        # ranks agree before any of them enters the collective init: none may wait for a peer
-        # that has already given up
-        buf = np.zeros(mk.MK_COMM_ID_BYTES, dtype=np.uint8)
-        rc0 = lib.mk_comm_unique_id(buf.ctypes.data) if rank == 0 else lib.mk_comm_available()
-        ok = torch.tensor([1 if rc0 == 0 else 0], dtype=torch.int32, device=dev)
-        why = "" if int(ok.item()) else lib.mk_last_error().decode()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            idt = torch.from_numpy(buf).to(dev)  # rank 0's id is the job's id
-            dist.broadcast(idt, src=0)
-            idb = idt.cpu().numpy().copy()
-            ok = torch.tensor([1 if lib.mk_comm_init(m.handle, idb.ctypes.data, rank, world) == 0 else 0],
-                              dtype=torch.int32, device=dev)
-            why = "" if int(ok.item()) else lib.mk_last_error().decode()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
+        ok, why = sharding.agree_on_communicator(lib, m.handle, rank, world, dev)
+        if ok:
             reduce_via = "mk_comm_reduce_counters (RCCL ncclAllReduce, C ABI)"
         else:  # same sum either way; say which path ran and why
-            reduce_via = f"torch.distributed all_reduce over RCCL (C-ABI communicator unavailable on some rank: {why})"
+            reduce_via = f"torch.distributed all_reduce over RCCL (C-ABI communicator unavailable: {why})"
     elif use_dist:
         reduce_via = "torch.distributed all_reduce over gloo (rehearsal)"
 
@@ -415,10 +403,107 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.paired and not args.ragged:
             out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, mates[0][2],
                                                args.cpu_seconds)
+        default_workload = (args.records, L, args.patterns, args.k, args.mode, args.plant_every, args.rc) == \
+            (100_000_000, 150, 10_000, 31, "any", 100, False) and options is None
+        if world == 1 and default_workload and not (args.no_other_configs or args.paired or args.ragged or args.with_offsets):
+            out["other_configs"] = other_configs(mk, lib, torch, dev, dev_index, m, mates[0], n_rec, L, seed, st)
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()
         dist.destroy_process_group()
+
+
+def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, st, steps=5, warmup=2):
+    """Short runs (5 timed steps each) of the other BASELINE configurations that fit one GPU and of the headline
+    batch with 10 % / all of the reads hitting, appended to the headline's JSON line: the same step as the
+    headline (clear + scan + flag count; hits mode: + the tuples put into the reference's emission order), the
+    scan kernel timed by hipEvents, fractions against the same 8 TB/s and the same algorithmic bytes
+    (1 B per base + 9 B per record)."""
+    import numpy as np
+    res = []
+
+    def run(label, m, d_seq, d_off, d_flags, n_rec, L, n_pat, emit, plant_every):
+        n_bytes = n_rec * L
+        d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_cnt = torch.zeros(n_pat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        cap = max(1 << 20, 2 * n_rec // max(1, plant_every)) if emit else 0
+        d_hits = torch.empty(2 * cap, dtype=torch.int64, device=dev) if emit else None
+        order_s = []
+
+        def step():
+            mk._check(lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), n_rec,
+                                         mk.MK_MODE_HITS if emit else mk.MK_MODE_ANY, d_flags.data_ptr(),
+                                         d_hits.data_ptr() if emit else None, cap, d_nh.data_ptr(), d_cnt.data_ptr(), st))
+            if emit:
+                nh = int(d_nh.item())
+                t_o = time.perf_counter()
+                mk._check(lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), min(nh, cap), st))
+                torch.cuda.synchronize()
+                order_s.append(time.perf_counter() - t_o)
+
+        mk._check(lib.mk_matcher_set_fixed_record_length(m.handle, L))
+        mk._check(lib.mk_matcher_hint_hit_density(m.handle, 0))
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        w = d_cnt.cpu().numpy()[n_pat:]
+        mk._check(lib.mk_matcher_hint_hit_density(m.handle, int(w[mk.MK_SUM_RECORDS_HIT]) * 1000 // max(1, int(w[mk.MK_SUM_RECORDS]))))
+        step()  # the flavour the hint selects, warm
+        torch.cuda.synchronize()
+        d_cnt.zero_()
+        del order_s[:]
+        m.enable_timing(steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        k_ms = float(np.mean(m.kernel_times_ms()))
+        algo = n_bytes + 9 * n_rec
+        summ = d_cnt.cpu().numpy()[n_pat:]
+        r = {"workload": label, "kernel": m.kernel_name, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+             "value_gbases_per_s": round(n_bytes * steps / dt / 1e9, 1), "kernel_ms": round(k_ms, 4),
+             "algorithmic_bytes_per_launch": algo, "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "records_hit_per_launch": int(summ[mk.MK_SUM_RECORDS_HIT]) // steps, "hits_per_launch": int(summ[mk.MK_SUM_HITS]) // steps}
+        if emit:
+            o_ms = float(np.mean(order_s)) * 1e3
+            r["order_ms"] = round(o_ms, 4)
+            r["order"] = m.order_info()
+            r["frac_scan_plus_order"] = round(algo / ((k_ms + o_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        res.append(r)
+
+    # the headline batch again with 10 % and all of the reads hitting (tag on already extracted reads)
+    d_seq, d_off, d_flags = mate0
+    for pe, what in ((10, "10 % of the reads hit"), (1, "every read hits")):
+        mk._check(lib.mk_synth_reads_device_range(m0.handle, seed, 0, n_rec0, L0, pe, d_seq.data_ptr(), d_off.data_ptr(), st))
+        run(f"headline batch, {what}: {n_rec0} x {L0} bp, {len(m0.patterns)} 31-mers, any-hit flags", m0, d_seq, d_off, d_flags,
+            n_rec0, L0, len(m0.patterns), False, pe)
+    del d_seq, d_off, d_flags
+
+    def fresh(n_rec, L, n_pat, k, rc, plant_every, s):
+        raw = make_patterns(n_pat, k, seed=s)
+        pats = mk.parse_pattern_list(kmer_seq=raw)[:n_pat]
+        if rc:
+            pats = mk.parse_pattern_list(kmer_seq=pats, reverse_complement=True)
+        m = mk.Matcher(pats, device=dev_index)
+        d_seq = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+        d_flags = torch.empty((n_rec + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        mk._check(lib.mk_synth_reads_device_range(m.handle, seed + 7, 0, n_rec, L, plant_every, d_seq.data_ptr(), d_off.data_ptr(), st))
+        return m, d_seq, d_off, d_flags, len(pats)
+
+    m, a, b, c, n_pat = fresh(10_000_000, 150, 1024, 31, True, 100, 11)
+    run(f"config 2 shape: extract, 10 M x 150 bp, 1 024 31-mers + RC ({n_pat} patterns), any-hit flags", m, a, b, c, 10_000_000, 150, n_pat, False, 100)
+    del m, a, b, c
+    m, a, b, c, n_pat = fresh(20_000_000, 150, 10_000, 31, False, 100, 12)
+    run("config 4 shape: tag, 20 M x 150 bp records, 10 k 31-mers, every hit tuple in emission order", m, a, b, c, 20_000_000, 150, n_pat, True, 100)
+    del m, a, b, c
+    m, a, b, c, n_pat = fresh(12_500_000, 250, 500_000, 21, False, 100, 13)
+    run("config 5, one GPU's shard: extract, 12.5 M x 250 bp, 500 k 21-mers (filter in global memory), any-hit flags", m, a, b, c,
+        12_500_000, 250, n_pat, False, 100)
+    del m, a, b, c
+    return res
 
 
 def host_cores():

@@ -214,6 +214,13 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
                    uint32_t mode, void *d_rec_flags, void *d_hits, uint64_t hits_cap, void *d_n_hits,
                    void *d_counters, void *stream);
 
+/* mk_scan_device only enqueues, so what a kernel finds wrong with its input comes back later: waits for `stream`,
+ * then returns MK_E_UNSUPPORTED if a MK_MODE_HITS scan on this handle since the last check met an occurrence 4 GiB
+ * or more into its record (mk_hit.pos cannot hold it; the flags of that scan are valid, its tuples are not), else
+ * MK_OK.  mk_order_hits_device makes the same check at its own round trip; mk_scan_batch refuses such a record
+ * before it scans.  The condition is cleared by the call that reports it. */
+int mk_matcher_check_device(mk_matcher *m, void *stream);
+
 /* Performance hint for mk_scan_device (never changes results): how many of 1000 records the caller
  * expects to contain a pattern.  Dense text (>= 120) is streamed with cacheable loads, because the
  * exact verification re-reads every hit window; sparse text with non-temporal loads.  mk_scan_batch

@@ -294,6 +294,8 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     MK_HIP(hipMalloc((void **)&m->d_pat_bytes, m->pat_bytes.size() + 16));
     MK_HIP(hipMalloc((void **)&m->d_pat_off, (n_pat + 1) * sizeof(uint32_t)));
     MK_HIP(hipMalloc((void **)&m->d_nhits, sizeof(unsigned long long)));
+    MK_HIP(hipMalloc((void **)&m->d_error, 16));
+    MK_HIP(hipMemset(m->d_error, 0, 16));
     // staging of verified occurrences for the hit-tuple kernels, kHitStage tuples per scan wave.
     // Allocated here, not by the first MK_MODE_HITS scan: mk_scan_device only enqueues.
     MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * (kBlockThreads / 64) * kHitStage * sizeof(mk_hit)));
@@ -332,7 +334,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
                     (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp,
-                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank})
+                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -405,6 +407,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.hits_cap = (mode == MK_MODE_HITS) ? hits_cap : 0;
     p.n_hits = (unsigned long long *)d_n_hits;
     p.counters = (unsigned long long *)d_counters;
+    p.error_word = m->d_error;
     const uint64_t waves_per_block = kBlockThreads / 64;
     uint64_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > (uint64_t)m->num_cus) blocks = m->num_cus;
@@ -434,11 +437,11 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     // per 15 GB.  Everything else: non-temporal stream (16 % faster without hits), 8-byte compare loads,
     // flagged records listed per wave and their bytes set by a small kernel afterwards.  The flavours cross
     // at 12 % of the records (profiles/r02_crossover2.txt).
-    constexpr uint32_t kDensePerMille = 120, kSomePerMille = 20;
+    constexpr uint32_t kDensePerMille = 120;
     const bool plain_loads = m->hit_density_pm >= kDensePerMille;
-    // between the two: the sparse kernel with 16-byte loads in the exact comparison (6 instead of 10 memory requests
-    // per occurrence; the no-hit scan pays 1.4 % for them, which is why the sparse flavour proper does not)
-    const int flavour = plain_loads ? 0 : (m->hit_density_pm >= kSomePerMille ? 2 : 1);
+    // (r03: a third flavour -- the sparse kernel with 16-byte compare loads as its own instantiation, for 2-12 % of
+    // the records hitting -- gained nothing at any density: profiles/r03_cmp16_mid.txt)
+    const int flavour = plain_loads ? 0 : 1;
     // the flag-only kernels for sparse hits list the records they flag (one list per scan wave) and a small
     // kernel sets the flag bytes afterwards (scan_kernel_impl.hpp: drain_hits); record indices in the lists are
     // 32 bits.  (Their tuple-emitting twins set the flags from the tuples they stage.)
@@ -462,6 +465,23 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     m->last_grid = (int)blocks;
     MK_HIP(hipGetLastError());
     return MK_OK;
+}
+
+// reads and clears the handle's sticky device error word (after the work on `st` has completed)
+static int take_device_errors(mk_matcher *m, hipStream_t st) {
+    uint32_t w = 0;
+    MK_HIP(hipMemcpyAsync(&w, m->d_error, sizeof(w), hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    if (!w) return MK_OK;
+    MK_HIP(hipMemsetAsync(m->d_error, 0, sizeof(w), st));
+    return fail(MK_E_UNSUPPORTED, "an occurrence lies 4 GiB or more into its record: a single record must be shorter than 4 GiB "
+                                  "(mk_hit.pos is 32 bits); the tuples of that scan are not usable");
+}
+
+int mk_matcher_check_device(mk_matcher *m, void *stream) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    MK_HIP(hipSetDevice(m->device));
+    return take_device_errors(m, (hipStream_t)stream);
 }
 
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000) {
@@ -592,7 +612,12 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
         launch_order_hist(hits, n, L, S, m->num_cus, st);
         MK_HIP(hipGetLastError());
         MK_HIP(hipMemcpyAsync(stats, S.stats, sizeof(stats), hipMemcpyDeviceToHost, st));
-        MK_HIP(hipStreamSynchronize(st));
+        if (attempt == 0) {  // the scan that wrote these tuples may have met a record it cannot address
+            int rc_e = take_device_errors(m, st);
+            if (rc_e) return rc_e;
+        } else {
+            MK_HIP(hipStreamSynchronize(st));
+        }
         // done unless a record lies beyond the bound (tuples of another batch than the handle's last scan), or a
         // bin overflows while the bound is at least twice the largest record seen (the bins are coarser than they
         // need be): once more with the exact bound

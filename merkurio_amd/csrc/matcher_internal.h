@@ -49,6 +49,7 @@ struct mk_matcher {
     mk_hit *d_hits = nullptr;
     size_t d_hits_cap = 0;
     unsigned long long *d_nhits = nullptr;
+    uint32_t *d_error = nullptr;  // sticky device error word (scan_kernel.h: error_word)
     mk_hit *d_stage = nullptr;  // EMIT kernels: per-wave staging of hit tuples
     // kernels for sparse hits: per-scan-wave lists of flagged records (scan_kernel.h: flag_list)
     uint32_t *d_flag_list = nullptr;

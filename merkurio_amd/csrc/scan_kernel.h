@@ -53,12 +53,14 @@ struct ScanParams {
     uint64_t hits_cap;
     unsigned long long *n_hits;    // device counter (every occurrence, even beyond hits_cap)
     unsigned long long *counters;  // n_pat + MK_NUM_SUMMARY, may be null
+    // sticky error word of the handle (never null): bit 0 = a tuple's position did not fit mk_hit.pos (an occurrence
+    // 4 GiB or more into its record); set by the tuple kernels, read at the handle's next host round trip
+    uint32_t *error_word;
 };
 
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
-// flavour: 1 sparse hits, 2 some hits (16-byte compare loads; k-mer families of the LDS filter only, else as 1),
-// 0 hit-dense text (scan_kernel_impl.hpp: FL)
+// flavour: 1 sparse hits, 0 hit-dense text (scan_kernel_impl.hpp: FL; honoured by the kernels with the filter in LDS)
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream);
 

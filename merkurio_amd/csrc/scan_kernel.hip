@@ -176,9 +176,6 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
     return emit ? launch_one<S_, QC_, true, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,plain>") \
                 : launch_one<S_, QC_, false, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,plain>")
 
-#define MK_VARIANT_MID(S_, QC_)                                                                                    \
-    return emit ? launch_one<S_, QC_, true, false, 2>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,cmp16>") \
-                : launch_one<S_, QC_, false, false, 2>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,cmp16>")
 
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream) {
@@ -228,12 +225,6 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
             default: return nullptr;
         }
     }
-    if (flavour == 2) {  // some hits: the k-mer families with 16-byte compare loads (everything else: as sparse)
-        if (S == 16 && p.q == 16) MK_VARIANT_MID(16, 16);
-        if (S == 8 && p.q == 24) MK_VARIANT_MID(8, 24);
-        if (S == 4 && p.q == 28) MK_VARIANT_MID(4, 28);
-        if (S == 4 && p.q == 18) MK_VARIANT_MID(4, 18);
-    }
     if (S == 16 && p.q == 16) MK_VARIANT(16, 16, false);
     if (S == 8 && p.q == 24) MK_VARIANT(8, 24, false);
     if (S == 4 && p.q == 28) MK_VARIANT(4, 28, false);
@@ -258,7 +249,6 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
 }
 #undef MK_VARIANT
 #undef MK_VARIANT_PLAIN
-#undef MK_VARIANT_MID
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
 // byte0 = global position of seq[0] in the synthetic stream (a multiple of 32)

@@ -92,8 +92,8 @@ static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 // check, then flag / counters; returns whether it is a true occurrence and, for EMIT kernels,
 // its tuple in `out`.
 // FL = flavour of the kernel variant: 1 sparse hits (non-temporal stream, 8-byte compare loads, flagged records
-// listed), 2 some hits (the same with 16-byte compare loads), 0 hit-dense text (cacheable stream, 16-byte
-// compare loads, flags stored directly)
+// listed), 0 hit-dense text (cacheable stream, 16-byte compare loads, flags stored directly).  (2 = the sparse
+// flavour with 16-byte compare loads still compiles; it is not instantiated: no gain, profiles/r03_cmp16_mid.txt)
 template <bool EMIT, int FL>
 __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, uint64_t p, uint32_t &n_true, mk_hit &out) {
     // uniform-length pattern sets (every k-mer list): no pat_off lookup, one dependent trip fewer
@@ -147,8 +147,8 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
         // record-offset pair is one 16-byte request and a pattern of 16..32 bytes -- every k-mer -- is compared
         // with two overlapping 16-byte loads a side, [0, 16) and [len - 16, len): 7.7 -> 5.9 ms per 100 M reads
         // when every read hits.  In the kernels for sparse hits the same code costs the scan loop around it
-        // 1.4 % (register allocation; r02_cmp16_ab) and gains nothing, so they keep 8-byte loads; from 2 % of
-        // the records hitting the host launches the 16-byte twin (FL = 2).  (seq_off[0] == 0 is part of the ABI.)
+        // 1.4 % (register allocation; r02_cmp16_ab) and gains nothing (as their own instantiation for 2-12 % of
+        // the records hitting either: r03_cmp16_mid), so they keep 8-byte loads.  (seq_off[0] == 0 is part of the ABI.)
         if constexpr (WIDE) {
             uint64_t rpair[2];
             __builtin_memcpy(rpair, P.rec_off + lo, 16);
@@ -244,6 +244,10 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
     if (EMIT) {  // the caller stages the tuple (HitStage)
         out.pat = pat;
         out.pos = (uint32_t)(p - rstart);
+        // mk_hit.pos is 32 bits: an occurrence 4 GiB or more into its record cannot be reported -- say so instead of
+        // wrapping (the host returns MK_E_UNSUPPORTED at its next round trip: mk_matcher_check_device / mk_scan_batch
+        // / mk_order_hits_device)
+        if (p - rstart > 0xFFFFFFFFull) atomicOr(P.error_word, 1u);
     }
     return true;
 }

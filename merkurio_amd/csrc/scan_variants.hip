@@ -5,7 +5,7 @@
 #include "scan_kernel_impl.hpp"
 
 #ifndef MK_TU
-#error "compile with -DMK_TU=0..9"
+#error "compile with -DMK_TU=0..8"
 #endif
 
 namespace mk {
@@ -22,10 +22,6 @@ void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream) {
 #define MK_INST_PLAIN(S_, QC_, GF_)                                                               \
     template void launch_variant<S_, QC_, false, GF_, 0>(const ScanParams &, int, hipStream_t); \
     template void launch_variant<S_, QC_, true, GF_, 0>(const ScanParams &, int, hipStream_t)
-// non-temporal stream like the default, 16-byte loads in the exact comparison: a few reads in a hundred hit
-#define MK_INST_MID(S_, QC_)                                                                    \
-    template void launch_variant<S_, QC_, false, false, 2>(const ScanParams &, int, hipStream_t); \
-    template void launch_variant<S_, QC_, true, false, 2>(const ScanParams &, int, hipStream_t)
 
 #if MK_TU == 0  // LDS filter, q fixed at compile time: the 31-mer and 21-mer families
 uint32_t scan_lds_bytes() { return kLdsBytes; }
@@ -38,11 +34,6 @@ MK_INST_PLAIN(16, 16, false);
 MK_INST_PLAIN(8, 24, false);
 MK_INST_PLAIN(4, 28, false);
 MK_INST_PLAIN(4, 18, false);
-#elif MK_TU == 9  // the k-mer families once more: non-temporal stream, 16-byte compare loads
-MK_INST_MID(16, 16);
-MK_INST_MID(8, 24);
-MK_INST_MID(4, 28);
-MK_INST_MID(4, 18);
 #elif MK_TU == 7  // plain stream loads, runtime q <= 16
 MK_INST_PLAIN(1, 0, false);
 MK_INST_PLAIN(2, 0, false);

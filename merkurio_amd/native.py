@@ -47,7 +47,7 @@ EXPORTS = [
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
-    "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length",
+    "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_destroy",
@@ -167,6 +167,7 @@ def load(build_if_missing=True):
     L.mk_matcher_hint_hit_density.argtypes = [C.c_void_p, C.c_uint32]
     L.mk_matcher_hint_record_lengths.argtypes = [C.c_void_p, C.c_int]
     L.mk_matcher_set_fixed_record_length.argtypes = [C.c_void_p, C.c_uint32]
+    L.mk_matcher_check_device.argtypes = [C.c_void_p, C.c_void_p]
     L.mk_matcher_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -62,3 +62,32 @@ def gather_to_rank0(flags, hits, bounds):
     out = [None] * world if rank == 0 else None
     dist.gather_object((np.asarray(flags), np.asarray(hits)), out, dst=0)
     return merge_shards(out, bounds) if rank == 0 else None
+
+
+def agree_on_communicator(lib, handle, rank, world, device, id_bytes=128):
+    """One process per GPU: sets up the C ABI's RCCL communicator on every rank (mk_comm_unique_id on rank 0, the id
+    carried by torch.distributed, mk_comm_init everywhere) -- or makes every rank give up together.  No rank may
+    enter the collective init while a peer has already decided against it, so the ranks agree twice: first that
+    each of them could bind librccl at all (a local check), then that every mk_comm_init came back with MK_OK.
+    -> (True, "") or (False, reason of the first rank that failed); `device`: where the agreement tensors live
+    ("cpu" under gloo, the rank's GPU under RCCL)."""
+    import torch
+    import torch.distributed as dist
+
+    def all_ok(rc):
+        why = "" if rc == 0 else (lib.mk_last_error() or b"").decode(errors="replace")
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        whys = [None] * world
+        dist.all_gather_object(whys, (rank, why))
+        bad = [f"rank {r}: {w}" for r, w in whys if w]
+        return int(ok.item()) == 1, "; ".join(bad)
+
+    buf = np.zeros(id_bytes, dtype=np.uint8)
+    ok, why = all_ok(lib.mk_comm_unique_id(buf.ctypes.data) if rank == 0 else lib.mk_comm_available())
+    if not ok:
+        return False, why
+    idt = torch.from_numpy(buf).to(device)  # rank 0's id is the job's id
+    dist.broadcast(idt, src=0)
+    idb = idt.cpu().numpy().copy()
+    return all_ok(lib.mk_comm_init(handle, idb.ctypes.data, rank, world))

@@ -106,3 +106,62 @@ def test_two_rank_gloo(tmp_path):
     s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "result").read() == "ok"
+
+
+class _FakeCommLib:
+    """stands in for libmerkurio_hip.so's mk_comm_* entry points on one rank: `fail_at` names the call that
+    fails on this rank ("bind", "init" or None)"""
+
+    def __init__(self, rank, fail_at):
+        self.rank, self.fail_at, self.calls = rank, fail_at, []
+
+    def mk_last_error(self):
+        return b"simulated failure"
+
+    def mk_comm_unique_id(self, p):
+        self.calls.append("unique_id")
+        return -11 if self.fail_at == "bind" else 0
+
+    def mk_comm_available(self):
+        self.calls.append("available")
+        return -11 if self.fail_at == "bind" else 0
+
+    def mk_comm_init(self, handle, idp, rank, world):
+        self.calls.append("init")
+        return -11 if self.fail_at == "init" else 0
+
+
+def _comm_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = []
+        # (who fails, where): nobody; rank 1 cannot bind librccl; rank 0 cannot; rank 1's init comes back with an error
+        for bad_rank, where in ((None, None), (1, "bind"), (0, "bind"), (1, "init")):
+            lib = _FakeCommLib(rank, where if rank == bad_rank else None)
+            ok, why = sharding.agree_on_communicator(lib, None, rank, world, "cpu")
+            res.append((ok, why, lib.calls))
+        open(os.path.join(out_dir, f"comm{rank}"), "w").write(repr(res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_rccl_communicator_or_give_up_together(tmp_path):
+    """bench.py --gpus N: a rank that cannot bind librccl (or whose mk_comm_init fails) must land the whole job in
+    the torch.distributed fallback -- never leave its peers waiting inside a collective init"""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_comm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (eval(open(tmp_path / f"comm{r}").read()) for r in (0, 1))
+    assert [x[0] for x in r0] == [x[0] for x in r1] == [True, False, False, False]  # both ranks decide alike
+    assert r0[0][2] == ["unique_id", "init"] and r1[0][2] == ["available", "init"]
+    for case in (1, 2):  # a bind failure anywhere: NO rank enters the collective init
+        assert "init" not in r0[case][2] and "init" not in r1[case][2]
+        assert "simulated failure" in r0[case][1] and r0[case][1] == r1[case][1]
+    assert "rank 1" in r0[3][1]

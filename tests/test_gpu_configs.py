@@ -475,3 +475,121 @@ def test_config4_full_size_bam_through_the_cli(mk, tmp_path):
     assert [g[0] for g in got] == sorted(want)
     for r, val in got[:: max(1, len(got) // 5000)]:
         assert val == b",".join(patterns[k] for k in sorted(want[r])), r
+    # ... and against the ORACLE (the reference's tag loop restated, src/cmd_tag.rs:387-490) on a 200 k-record
+    # slice of the same BAM: which records `-m` keeps and the km value of each of them
+    a = min(n, 7_300_000) - min(n, 200_000) if n >= 400_000 else 0
+    b = min(n, a + 200_000)
+    recs = [seq_all[i * L:(i + 1) * L].tobytes() for i in range(a, b)]
+    om = ob.Matcher(patterns, True, 0, False)
+    keep_o, _, _, found_o = ob.tag_records(om, recs, logging=False, filter_matching=True)
+    by_rec = dict(got)
+    kept_cli = [r for r, _ in got if a <= r < b]
+    assert kept_cli == [a + i for i, k in enumerate(keep_o) if k] and len(kept_cli) >= (b - a) // every - 1
+    for i, k in enumerate(keep_o):
+        if k:
+            assert by_rec[a + i] == ob.tag_value(patterns, found_o[i]), a + i
+
+
+def test_more_than_2_pow_32_records(mk):
+    """2^32 + 16 records (one byte each: 4.3 GB of text, 34 GB of offsets): record indices beyond 32 bits through
+    every place that narrows them elsewhere -- no per-wave flag lists (their entries are 32 bits), no coarse record
+    index for ragged batches (its entries are 32 bits), 64-bit records in the tuples and in the emission order.
+    The expectation is by construction: the text is all 'C' but for 'A' in chosen records."""
+    torch = pytest.importorskip("torch")
+    lib = mk.load()
+    dev = torch.device("cuda", 0)
+    n = (1 << 32) + 16
+    planted = [0, 5, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, 1 << 32, (1 << 32) + 7, n - 1]
+    m = mk.Matcher([b"A"])  # one pattern: the BNDMq domain, stride 1
+    st = torch.cuda.current_stream().cuda_stream
+    d_flags = torch.zeros(n + 8, dtype=torch.uint8, device=dev)
+    d_hits = torch.zeros(2 * 1024, dtype=torch.int64, device=dev)
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_cnt = torch.zeros(1 + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+
+    def check(d_seq, n_bytes, d_off, where, label):
+        d_cnt.zero_()
+        for mode in (mk.MK_MODE_ANY, mk.MK_MODE_HITS):
+            assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr() if d_off is not None else None, n, mode,
+                                      d_flags.data_ptr(), d_hits.data_ptr(), 1024, d_nh.data_ptr(), d_cnt.data_ptr(), st) == 0, lib.mk_last_error()
+            torch.cuda.synchronize()
+            assert int(d_flags[:n].sum(dtype=torch.int64).item()) == len(where), (label, mode)
+            assert all(int(d_flags[r].item()) == 1 for r in where), (label, mode)
+        assert lib.mk_matcher_check_device(m.handle, st) == 0
+        nh = int(d_nh.item())
+        assert nh == len(where)
+        assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), nh, st) == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        got = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)[:nh]
+        assert got["rec"].tolist() == sorted(where) and set(got["pat"].tolist()) == {0}, label
+        c = d_cnt.cpu().numpy()
+        assert c[0] == len(where) and c[1 + mk.MK_SUM_RECORDS_HIT] == 2 * len(where) and c[1 + mk.MK_SUM_RECORDS] == 2 * n
+        return got
+
+    # (1) equal lengths through the offsets array
+    d_seq = torch.full((n + 64,), ord("C"), dtype=torch.uint8, device=dev)
+    d_seq[torch.tensor(planted, device=dev)] = ord("A")
+    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev)
+    got = check(d_seq, n, d_off, planted, "offsets")
+    assert set(got["pos"].tolist()) == {0}
+    # (2) the same as a fixed-length batch: no offsets array
+    assert lib.mk_matcher_set_fixed_record_length(m.handle, 1) == 0
+    check(d_seq, n, None, planted, "fixed length")
+    assert lib.mk_matcher_set_fixed_record_length(m.handle, 0) == 0
+    # (3) ragged: record 3 has two bytes ("CA": an occurrence at position 1), every record behind it starts one byte later
+    d_off[4:] += 1
+    d_seq2 = torch.full((n + 1 + 64,), ord("C"), dtype=torch.uint8, device=dev)
+    where = [3] + [r for r in planted if r > 3]
+    d_seq2[torch.tensor([4] + [r + 1 for r in planted if r > 3], device=dev)] = ord("A")
+    assert lib.mk_matcher_hint_record_lengths(m.handle, 0) == 0
+    got = check(d_seq2, n + 1, d_off, where, "ragged")
+    assert got["pos"].tolist() == [1] + [0] * (len(where) - 1)
+
+
+def test_occurrence_beyond_4_gib_of_its_record_is_reported(mk):
+    """mk_hit.pos is 32 bits.  mk_scan_batch refuses a record of 4 GiB or more before it scans; the device API only
+    enqueues, so its tuple kernels raise a sticky error word and mk_matcher_check_device / mk_order_hits_device
+    return MK_E_UNSUPPORTED -- never a wrapped position.  The flags of that scan are still right."""
+    torch = pytest.importorskip("torch")
+    lib = mk.load()
+    dev = torch.device("cuda", 0)
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(20, 31, 9))
+    m = mk.Matcher(patterns)
+    big = (1 << 32) + 4096
+    lens = [1000, big, 500]
+    n_bytes = sum(lens)
+    d_seq = torch.full((n_bytes + 64,), ord("C"), dtype=torch.uint8, device=dev)
+    p0 = torch.frombuffer(bytearray(patterns[0]), dtype=torch.uint8).to(dev)
+    d_off = torch.tensor([0, 1000, 1000 + big, n_bytes], dtype=torch.int64, device=dev)
+    d_flags = torch.zeros(8, dtype=torch.uint8, device=dev)
+    d_hits = torch.zeros(2 * 64, dtype=torch.int64, device=dev)
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def scan():
+        assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), 3, mk.MK_MODE_HITS, d_flags.data_ptr(),
+                                  d_hits.data_ptr(), 64, d_nh.data_ptr(), None, st) == 0, lib.mk_last_error()
+
+    # occurrences in the first 4 GiB of the long record and in the short ones: fine
+    for o in (10, 1000 + 77, 1000 + (1 << 32) - 31, 1000 + big + 400):
+        d_seq[o:o + 31] = p0
+    scan()
+    assert lib.mk_matcher_check_device(m.handle, st) == 0
+    assert int(d_nh.item()) == 4 and d_flags[:3].tolist() == [1, 1, 1]
+    assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), 4, st) == 0
+    torch.cuda.synchronize()
+    got = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)[:4]
+    assert list(zip(got["rec"].tolist(), got["pos"].tolist())) == [(0, 10), (1, 77), (1, (1 << 32) - 31), (2, 400)]
+    # one more, 4 GiB + 100 into the long record: reported, once
+    d_seq[1000 + (1 << 32) + 100:1000 + (1 << 32) + 131] = p0
+    scan()
+    assert lib.mk_matcher_check_device(m.handle, st) == mk.MK_E_UNSUPPORTED
+    assert b"4 GiB" in lib.mk_last_error()
+    assert lib.mk_matcher_check_device(m.handle, st) == 0  # cleared by the call that reported it
+    assert d_flags[:3].tolist() == [1, 1, 1]
+    scan()
+    assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), int(d_nh.item()), st) == mk.MK_E_UNSUPPORTED
+    # flags-only scans have no position to lose
+    assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr(), 3, mk.MK_MODE_ANY, d_flags.data_ptr(),
+                              None, 0, d_nh.data_ptr(), None, st) == 0
+    assert lib.mk_matcher_check_device(m.handle, st) == 0 and d_flags[:3].tolist() == [1, 1, 1]
