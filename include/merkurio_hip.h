@@ -299,6 +299,12 @@ int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint6
                    int filter_matching, int invert, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
                    mk_counters *counters, uint32_t *pattern_hit_counts, uint64_t *found_off, uint32_t *found_pat,
                    uint64_t found_cap);
+/* Where the last mk_extract_single / mk_tag_records call on this handle spent its time, in milliseconds:
+ * ms[0] upload of the records (host -> device), ms[1] device work (scan, emission order, log rows, per-pattern
+ * counts, per-record pattern sets -- all kernels), ms[2] download of the results, ms[3] host loops (flags -> keep,
+ * adding counts).  Both calls run on the device from end to end; the host only copies and decides keep. */
+int mk_matcher_batch_times(const mk_matcher *m, float ms[4]);
+
 /* tag value, src/cmd_tag.rs:470-490: found patterns merged with an existing tag value
  * (split on ','), sort_unstable, dedup, join(",").  Writes a NUL-terminated string into
  * out (cap bytes); returns MK_E_CAPACITY with *out_len = required (excl. NUL) if too small. */

@@ -49,6 +49,7 @@ def _units():
     units.append(("scan_kernel.o", "scan_kernel.hip", []))
     units.append(("order_hits.o", "order_hits.hip", []))
     units.append(("order_hits_fallback.o", "order_hits_fallback.hip", []))
+    units.append(("sets.o", "sets.hip", []))
     units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     return units
 

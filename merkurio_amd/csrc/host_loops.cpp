@@ -3,8 +3,12 @@
 //   extract single   src/cmd_extract.rs:321-406
 //   extract paired   src/cmd_extract.rs:463-612
 //   tag              src/cmd_tag.rs:387-490
-// The matching itself is mk_scan_batch (gfx950 kernel); nothing here searches text.
+// The matching itself is the gfx950 scan kernel; nothing here searches text.  extract (single) and tag work on the
+// device from end to end: scan -> tuples ordered on the device (order_hits.hip) -> log rows, per-pattern counts and
+// the per-record pattern sets by the kernels of sets.hip -> results copied back.  The host threads only turn flags
+// into keep decisions.  (The paired loop still merges its two ordered tuple lists on the host.)
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +71,130 @@ uint64_t popcount_flags(const std::vector<uint8_t> &f, uint64_t n) {
     return c;
 }
 
+// One driver-loop call on the device: upload, scan, then whatever the loop derives from the tuples, each step
+// enqueued on the handle's stream; the time of the call is split into upload / device / download / host.
+struct DeviceLoop {
+    mk_matcher *m;
+    hipStream_t st;
+    unsigned long long found = 0;  // tuples of the scan (all of them are on the device)
+    uint64_t n_bytes = 0;
+    using clk = std::chrono::steady_clock;
+    clk::time_point t_last;
+    int phase = 0;
+    explicit DeviceLoop(mk_matcher *m_) : m(m_), st(m_->stream), t_last(clk::now()) {
+        for (float &x : m->batch_ms) x = 0;
+    }
+    void mark(int next) {  // the stream is idle at every call: time since the last mark goes to the current phase
+        const auto t = clk::now();
+        m->batch_ms[phase] += std::chrono::duration<float, std::milli>(t - t_last).count();
+        t_last = t;
+        phase = next;
+    }
+    void host_begin() { mark(3); }
+    void finish() { mark(3); }
+
+    int scan(const uint8_t *seq, const uint64_t *off, uint64_t n_rec, uint32_t mode, uint8_t *flags, uint64_t *flagged) {
+        int rc = batch_check(seq, off, n_rec, &n_bytes);
+        if (rc) return rc;
+        uint32_t batch_len = 0;
+        phase = 0;
+        if ((rc = batch_upload(m, seq, off, n_rec, n_bytes, &batch_len))) return rc;
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload failed");
+        mark(1);
+        // all tuples stay on the device: no caller-side limit
+        if ((rc = batch_scan(m, n_bytes, n_rec, mode, batch_len, std::max<uint64_t>(4096, n_rec / 8), ~0ull, &found))) return rc;
+        mark(2);
+        if ((rc = batch_flags(m, n_rec, flags, flagged))) return rc;
+        mark(1);
+        return MK_OK;
+    }
+    int order(bool ac_order) { return order_hits_on_device(m, m->d_hits, found, ac_order, st); }
+
+    // mk_row per tuple (in their current order) -> rows[0, min(found, cap))
+    int rows_to_host(uint32_t file, mk_row *rows, uint64_t cap) {
+        const uint64_t n = std::min<uint64_t>(found, rows ? cap : 0);
+        if (!n) return MK_OK;
+        int rc = ensure_device(&m->d_aux, &m->d_aux_cap, n * sizeof(mk_row));
+        if (rc) return rc;
+        launch_rows(m->d_hits, n, file, (mk_row *)m->d_aux, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "row kernel failed");
+        mark(2);
+        if (hipMemcpy(rows, m->d_aux, n * sizeof(mk_row), hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the log rows failed");
+        mark(1);
+        return MK_OK;
+    }
+
+    // pattern_hit_counts += this batch's: per hit (AC, src/cmd_extract.rs:353) or per (record, pattern) with a hit
+    // (BNDMq, :380-383; the tuples must be in BNDMq order = set order)
+    int pattern_counts(bool per_hit, uint64_t n_rec, uint32_t *counts) {
+        if (!found) return MK_OK;
+        const uint32_t n_pat = m->n_pat;
+        if (per_hit) {
+            int rc = ensure_device(&m->d_aux, &m->d_aux_cap, ((size_t)n_pat + MK_NUM_SUMMARY) * 8);
+            if (rc) return rc;
+            if (hipMemsetAsync(m->d_aux, 0, ((size_t)n_pat + MK_NUM_SUMMARY) * 8, st) != hipSuccess) return fail(MK_E_HIP, "memset failed");
+            ScanParams p;
+            memset(&p, 0, sizeof(p));
+            p.hits = m->d_hits;
+            p.n_hits = m->d_nhits;  // still holds `found`
+            p.hits_cap = found;
+            p.counters = (unsigned long long *)m->d_aux;
+            p.n_pat = n_pat;
+            launch_hist_hits(p, m->num_cus, st);
+            std::vector<unsigned long long> v(n_pat);
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "histogram kernel failed");
+            mark(2);
+            if (hipMemcpy(v.data(), m->d_aux, (size_t)n_pat * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the counts failed");
+            mark(3);
+            for (uint32_t i = 0; i < n_pat; ++i) counts[i] += (uint32_t)v[i];
+            mark(1);
+            return MK_OK;
+        }
+        // BNDMq: the heads of the (record, pattern) runs = the entries of the pattern sets
+        uint64_t n_found = 0;
+        return pattern_sets(n_rec, nullptr, nullptr, 0, &n_found, counts);
+    }
+
+    // the distinct patterns of every record (tuples in set order).  found_off == nullptr: only the counts.
+    int pattern_sets(uint64_t n_rec, uint64_t *found_off, uint32_t *found_pat, uint64_t found_cap, uint64_t *n_found, uint32_t *counts) {
+        const uint32_t n_pat = m->n_pat;
+        const size_t off_bytes = (n_rec + 1) * 8, pat_bytes = ((size_t)found * 4 + 15) & ~(size_t)15;
+        const size_t tiles = std::max<size_t>((found + 4095) / 4096, (n_rec + 1 + 4095) / 4096) + 1;
+        const size_t cnt_bytes = ((size_t)n_pat * 4 + 15) & ~(size_t)15;
+        int rc = ensure_device(&m->d_aux, &m->d_aux_cap, off_bytes + pat_bytes + tiles * 8 + 16 + cnt_bytes);
+        if (rc) return rc;
+        char *base = (char *)m->d_aux;
+        unsigned long long *d_off = (unsigned long long *)base;
+        uint32_t *d_pat = (uint32_t *)(base + off_bytes);
+        void *d_tile = base + off_bytes + pat_bytes;
+        unsigned long long *d_total = (unsigned long long *)(base + off_bytes + pat_bytes + tiles * 8);
+        uint32_t *d_cnt = (uint32_t *)(base + off_bytes + pat_bytes + tiles * 8 + 16);
+        launch_pattern_sets(m->d_hits, found, n_rec, d_pat, d_off, d_total, d_tile, st);
+        unsigned long long total = 0;
+        if (hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
+        if (counts) {
+            if (hipMemsetAsync(d_cnt, 0, cnt_bytes, st) != hipSuccess) return fail(MK_E_HIP, "memset failed");
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "pattern-set kernels failed");
+        *n_found = total;
+        std::vector<uint32_t> v;
+        if (counts && total) {
+            launch_count_u32(d_pat, total, d_cnt, n_pat, st);
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "count kernel failed");
+            v.resize(n_pat);
+        }
+        mark(2);
+        if (found_off && hipMemcpy(found_off, d_off, off_bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the set offsets failed");
+        const uint64_t n_copy = std::min<uint64_t>(total, found_pat ? found_cap : 0);
+        if (n_copy && hipMemcpy(found_pat, d_pat, n_copy * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the sets failed");
+        if (!v.empty() && hipMemcpy(v.data(), d_cnt, (size_t)n_pat * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the counts failed");
+        mark(3);
+        for (size_t i = 0; i < v.size(); ++i) counts[i] += v[i];
+        mark(1);
+        return MK_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -76,27 +204,33 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
                       mk_counters *c, uint32_t *counts) {
     if (!m || !keep || !c || (logging && !counts)) return fail(MK_E_INVALID_ARG, "null argument");
     if (n_rows) *n_rows = 0;
+    if (n_rec == 0) return MK_OK;
     MK_ABI_BEGIN
-    std::vector<uint8_t> flags;
-    std::vector<mk_hit> hits;
-    int rc = scan_all(m, seq, off, n_rec, logging ? MK_MODE_HITS : MK_MODE_ANY, flags, hits);
+    DeviceLoop dl(m);
+    std::vector<uint8_t> flags(n_rec);
+    uint64_t flagged = 0;
+    int rc = dl.scan(seq, off, n_rec, logging ? MK_MODE_HITS : MK_MODE_ANY, flags.data(), &flagged);
     if (rc) return rc;
-    RowSink sink{rows, rows_cap};
     if (logging) {
-        c->nb_records_tot += n_rec;                                  // :326
-        c->nb_bases += n_rec ? off[n_rec] - off[0] : 0;              // :327
-        for (auto &h : hits) sink.push(0, h);                        // :338-351 / :369-377
-        c->nb_hits_tot[0] += hits.size();                            // :354 / :378
-        c->nb_records_hit[0] += popcount_flags(flags, n_rec);        // :358-360 / :385-387
-        count_patterns(m->algo, hits, counts);
+        c->nb_records_tot += n_rec;              // :326
+        c->nb_bases += off[n_rec] - off[0];      // :327
+        c->nb_hits_tot[0] += dl.found;           // :354 / :378
+        c->nb_records_hit[0] += flagged;         // :358-360 / :385-387
+        // rows in emission order (:338-351 / :369-377) and pattern_hit_counts: AC one per hit (:353), BNDMq one per
+        // record and pattern (:380-383) -- BNDMq's emission order is the set order, so its heads are counted in place
+        if ((rc = dl.order(m->algo == MK_ALGO_AC))) return rc;
+        if ((rc = dl.rows_to_host(0, rows, rows_cap))) return rc;
+        if ((rc = dl.pattern_counts(m->algo == MK_ALGO_AC, n_rec, counts))) return rc;
     }
+    dl.host_begin();
     for (uint64_t r = 0; r < n_rec; ++r) {  // :400-405
         keep[r] = (uint8_t)((flags[r] != 0) != (invert != 0));
         c->nb_records_extracted += keep[r];
     }
-    if (n_rows) *n_rows = sink.n;
-    if (logging && rows && sink.n > rows_cap)
-        return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
+    dl.finish();
+    if (n_rows) *n_rows = dl.found;
+    if (logging && rows && dl.found > rows_cap)
+        return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)dl.found);
     return MK_OK;
     MK_ABI_END
 }
@@ -170,46 +304,50 @@ int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint6
                    mk_counters *c, uint32_t *counts, uint64_t *found_off, uint32_t *found_pat, uint64_t found_cap) {
     if (!m || !keep || !c || !found_off || (logging && !counts)) return fail(MK_E_INVALID_ARG, "null argument");
     if (n_rows) *n_rows = 0;
+    found_off[0] = 0;
+    if (n_rec == 0) return MK_OK;
     MK_ABI_BEGIN
-    std::vector<uint8_t> flags;
-    std::vector<mk_hit> hits;
+    DeviceLoop dl(m);
+    std::vector<uint8_t> flags(n_rec);
+    uint64_t flagged = 0;
     // the tag loop always needs the matched-pattern SET (src/cmd_tag.rs:392-442)
-    int rc = scan_all(m, seq, off, n_rec, MK_MODE_HITS, flags, hits);
+    int rc = dl.scan(seq, off, n_rec, MK_MODE_HITS, flags.data(), &flagged);
     if (rc) return rc;
-    RowSink sink{rows, rows_cap};
+    const bool ac = m->algo == MK_ALGO_AC;
+    bool set_order = false;  // are the tuples in (record, pattern, position) order?
     if (logging) {
-        for (auto &h : hits) sink.push(0, h);
-        c->nb_hits_tot[0] += hits.size();
-        count_patterns(m->algo, hits, counts);
+        c->nb_hits_tot[0] += dl.found;
         c->nb_records_tot += n_rec;  // :446-450 (counted before filtering)
-        c->nb_bases += n_rec ? off[n_rec] - off[0] : 0;
-        c->nb_records_hit[0] += popcount_flags(flags, n_rec);
+        c->nb_bases += off[n_rec] - off[0];
+        c->nb_records_hit[0] += flagged;
+        if ((rc = dl.order(ac))) return rc;
+        if ((rc = dl.rows_to_host(0, rows, rows_cap))) return rc;
+        set_order = !ac;
+        if (ac && (rc = dl.pattern_counts(true, n_rec, counts))) return rc;  // one per hit (:412); BNDMq: below, from the sets
     }
-    // distinct matched patterns per record, ascending
-    uint64_t w = 0;
-    size_t i = 0;
-    std::vector<uint32_t> tmp;
-    for (uint64_t r = 0; r < n_rec; ++r) {
-        found_off[r] = w;
-        tmp.clear();
-        while (i < hits.size() && hits[i].rec == r) tmp.push_back(hits[i++].pat);
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        for (uint32_t p : tmp) {
-            if (found_pat && w < found_cap) found_pat[w] = p;
-            ++w;
-        }
-        const bool has = flags[r] != 0;  // :457-467
+    // distinct matched patterns per record, ascending: kmers_found after sort_unstable + dedup (:484-485)
+    if (!set_order && (rc = dl.order(false))) return rc;
+    uint64_t n_found = 0;
+    if ((rc = dl.pattern_sets(n_rec, found_off, found_pat, found_cap, &n_found, (logging && !ac) ? counts : nullptr))) return rc;
+    dl.host_begin();
+    for (uint64_t r = 0; r < n_rec; ++r) {  // :457-467
+        const bool has = flags[r] != 0;
         keep[r] = (uint8_t)(filter_matching ? has : (invert ? !has : true));
         c->nb_records_extracted += keep[r];
     }
-    found_off[n_rec] = w;
-    if (n_rows) *n_rows = sink.n;
-    if (w > found_cap) return fail(MK_E_CAPACITY, "found_pat too small: need %llu", (unsigned long long)w);
-    if (logging && rows && sink.n > rows_cap)
-        return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
+    dl.finish();
+    if (n_rows) *n_rows = logging ? dl.found : 0;
+    if (n_found > found_cap) return fail(MK_E_CAPACITY, "found_pat too small: need %llu", (unsigned long long)n_found);
+    if (logging && rows && dl.found > rows_cap)
+        return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)dl.found);
     return MK_OK;
     MK_ABI_END
+}
+
+int mk_matcher_batch_times(const mk_matcher *m, float ms[4]) {
+    if (!m || !ms) return fail(MK_E_INVALID_ARG, "null argument");
+    for (int i = 0; i < 4; ++i) ms[i] = m->batch_ms[i];
+    return MK_OK;
 }
 
 int mk_tag_value(const mk_matcher *m, const uint32_t *found_pat, uint64_t n_found, const char *existing, char *out,

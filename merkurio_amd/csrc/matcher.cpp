@@ -122,17 +122,19 @@ uint64_t pack_qgram(const uint8_t *p, uint32_t q) {
 
 using namespace mk;
 
-
-static int ensure(void **p, size_t *cap, size_t need) {
+int mk::ensure_device(void **p, size_t *cap, size_t need) {
     if (need <= *cap) return MK_OK;
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
     size_t want = need + need / 4 + 4096;
-    MK_HIP(hipMalloc(p, want));
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     *cap = want;
     return MK_OK;
 }
+
+static int ensure(void **p, size_t *cap, size_t need) { return ensure_device(p, cap, need); }
 
 extern "C" {
 
@@ -334,7 +336,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
                     (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp,
-                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error})
+                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -551,8 +553,7 @@ int mk_matcher_launch_info(const mk_matcher *m, uint32_t *grid_blocks, uint32_t 
 // the device, like every other workspace of the handle.
 static uint32_t bits_of(uint64_t v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
 
-static int order_library(mk_matcher *m, mk_hit *d_hits, uint64_t n, hipStream_t st) {
-    const bool ac = m->algo == MK_ALGO_AC;
+static int order_library(mk_matcher *m, mk_hit *d_hits, uint64_t n, bool ac, hipStream_t st) {
     size_t need = 0;
     MK_HIP(order_hits_library(d_hits, n, ac, m->d_pat_off, m->uniform_len, nullptr, &need, st));
     int rc = ensure(&m->d_sort_tmp, &m->d_sort_tmp_cap, need ? need : 16);
@@ -564,6 +565,14 @@ static int order_library(mk_matcher *m, mk_hit *d_hits, uint64_t n, hipStream_t 
 
 int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    return mk::order_hits_on_device(m, d_hits, n_hits, m->algo == MK_ALGO_AC, stream);
+}
+
+}  // extern "C"
+
+// ac: Aho-Corasick emission order; !ac: (record, pattern, position) -- BNDMq's emission order and, for any matcher,
+// the order in which a record's distinct patterns are adjacent and ascending (sets.hip)
+int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool ac_order, void *stream) {
     m->order_path = 0;
     if (n_hits < 2) return MK_OK;
     if (!d_hits) return fail(MK_E_INVALID_ARG, "null buffer");
@@ -573,7 +582,7 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
     hipStream_t st = (hipStream_t)stream;
     mk_hit *hits = (mk_hit *)d_hits;
     const uint64_t n = n_hits;
-    if (n >= (1ull << 32)) return order_library(m, hits, n, st);  // bin cursors are 32 bits
+    if (n >= (1ull << 32)) return order_library(m, hits, n, ac_order, st);  // bin cursors are 32 bits
     if (!m->order_prepared) {  // once per handle (function attributes are per device)
         MK_HIP(order_kernels_prepare());
         m->order_prepared = true;
@@ -595,9 +604,9 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
     memset(&L, 0, sizeof(L));
     L.pat_off = m->d_pat_off;
     L.uniform_len = m->uniform_len;
-    L.rank = m->d_pat_rank;
-    L.unrank = m->d_pat_unrank;
-    L.ac = m->algo == MK_ALGO_AC ? 1 : 0;
+    L.rank = ac_order ? m->d_pat_rank : nullptr;
+    L.unrank = ac_order ? m->d_pat_unrank : nullptr;
+    L.ac = ac_order ? 1 : 0;
     // first attempt: bins of 2^s consecutive records, s from the record count of the handle's last scan
     uint64_t rec_bound = m->last_n_rec ? m->last_n_rec : (1ull << 32);
     unsigned long long stats[5] = {0, 0, 0, 0, 0};
@@ -628,8 +637,8 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
     }
     uint32_t bits_rec = bits_of(stats[0]);
     const uint32_t bits_a = std::max(1u, bits_of(stats[1])), bits_b = std::max(1u, bits_of(stats[2]));
-    if (bits_rec + bits_a + bits_b > 64) return order_library(m, hits, n, st);  // the triple does not fit one 64-bit key
-    if (s + bits_a > 63) return order_library(m, hits, n, st);  // (cannot happen below 2^31 records)
+    if (bits_rec + bits_a + bits_b > 64) return order_library(m, hits, n, ac_order, st);  // the triple does not fit one 64-bit key
+    if (s + bits_a > 63) return order_library(m, hits, n, ac_order, st);  // (cannot happen below 2^31 records)
     L.bits_a = bits_a;
     L.bits_b = bits_b;
     m->order_path = 1;
@@ -647,7 +656,7 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
         MK_HIP(hipGetLastError());
         MK_HIP(hipMemcpyAsync(stats, S.stats, sizeof(stats), hipMemcpyDeviceToHost, st));
         MK_HIP(hipStreamSynchronize(st));
-        if (stats[3] > kOrderLeafMax) return order_library(m, hits, n, st);
+        if (stats[3] > kOrderLeafMax) return order_library(m, hits, n, ac_order, st);
         m->order_path = 2;
     } else {
         L.shift = s + bits_a;  // ((rec << bits_a) | A) >> (s + bits_a) == rec >> s: the bins just counted
@@ -659,6 +668,8 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
     return MK_OK;
     MK_ABI_END
 }
+
+extern "C" {
 
 int mk_matcher_order_info(const mk_matcher *m, uint32_t *path, uint32_t *n_bins, uint32_t *max_bin) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
@@ -693,45 +704,38 @@ int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits) {
     return MK_OK;
 }
 
-int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint32_t mode,
-                  uint8_t *rec_flags, mk_hit *hits, uint64_t hits_cap, uint64_t *n_hits) {
-    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
-    if (n_hits) *n_hits = 0;
-    if (n_rec == 0) return MK_OK;
-    if (!seq_off || !rec_flags) return fail(MK_E_INVALID_ARG, "null buffer");
-    const uint64_t base = seq_off[0];
-    const uint64_t n_bytes = seq_off[n_rec] - base;
-    if (n_bytes && !seq_bytes) return fail(MK_E_INVALID_ARG, "null sequence buffer");
-    if (n_bytes >= (1ull << 32))  // mk_hit.pos is 32 bits: refuse a record it cannot address instead of wrapping
+}  // extern "C"
+
+namespace mk {
+
+// ---- host-buffer batches, in steps (mk_scan_batch and the driver loops of host_loops.cpp) ----------------------
+// argument checks of a host batch; *n_bytes = bytes of the batch
+int batch_check(const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint64_t *n_bytes) {
+    if (!seq_off) return fail(MK_E_INVALID_ARG, "null buffer");
+    *n_bytes = seq_off[n_rec] - seq_off[0];
+    if (*n_bytes && !seq_bytes) return fail(MK_E_INVALID_ARG, "null sequence buffer");
+    if (*n_bytes >= (1ull << 32))  // mk_hit.pos is 32 bits: refuse a record it cannot address instead of wrapping
         for (uint64_t i = 0; i < n_rec; ++i)
             if (seq_off[i + 1] - seq_off[i] >= (1ull << 32))
                 return fail(MK_E_UNSUPPORTED, "record %llu is %llu bytes long: a single record must be shorter than 4 GiB",
                             (unsigned long long)i, (unsigned long long)(seq_off[i + 1] - seq_off[i]));
-    MK_ABI_BEGIN
+    return MK_OK;
+}
+
+// records and offsets -> the handle's device buffers (enqueued on its stream); *batch_len = the length all records
+// share (0 = they differ): such a batch needs no record lookup at all, a ragged one gets a coarse record index
+int batch_upload(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *batch_len) {
     MK_HIP(hipSetDevice(m->device));
     int rc;
     if ((rc = ensure((void **)&m->d_seq, &m->d_seq_cap, n_bytes + 64))) return rc;
     if ((rc = ensure((void **)&m->d_off, &m->d_off_cap, (n_rec + 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure((void **)&m->d_flags, &m->d_flags_cap, n_rec + 8))) return rc;
-    uint32_t batch_len = 0;
-    {  // records of unequal length get a coarse index for the record lookup of verified occurrences; records of
-       // ONE length need no lookup at all (the kernel computes the record of an occurrence)
-        const uint64_t len0 = seq_off[1] - seq_off[0];
-        bool equal = true;
-        for (uint64_t i = 1; i < n_rec && equal; ++i) equal = seq_off[i + 1] - seq_off[i] == len0;
-        m->ragged = !equal;
-        batch_len = (equal && len0 > 0 && len0 < (1ull << 32)) ? (uint32_t)len0 : 0;
-    }
-    struct BatchLen {  // holds for the scans of THIS call only; a length set for device scans does not apply to them
-        mk_matcher *m;
-        uint32_t saved;
-        ~BatchLen() {
-            m->batch_rec_len = 0;
-            m->fixed_rec_len = saved;
-        }
-    } batch_len_guard{m, m->fixed_rec_len};
-    m->fixed_rec_len = 0;
-    m->batch_rec_len = batch_len;
+    const uint64_t base = seq_off[0];
+    const uint64_t len0 = seq_off[1] - seq_off[0];
+    bool equal = true;
+    for (uint64_t i = 1; i < n_rec && equal; ++i) equal = seq_off[i + 1] - seq_off[i] == len0;
+    m->ragged = !equal;
+    *batch_len = (equal && len0 > 0 && len0 < (1ull << 32)) ? (uint32_t)len0 : 0;
     std::vector<uint64_t> rel;
     const uint64_t *off_src = seq_off;
     if (base != 0) {  // device offsets are relative to the first byte uploaded
@@ -741,24 +745,70 @@ int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_o
     }
     if (n_bytes) MK_HIP(hipMemcpyAsync(m->d_seq, seq_bytes + base, n_bytes, hipMemcpyHostToDevice, m->stream));
     MK_HIP(hipMemcpyAsync(m->d_off, off_src, (n_rec + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
-    uint64_t cap = (mode == MK_MODE_HITS) ? std::max<uint64_t>(hits_cap, 1024) : 0;
-    unsigned long long found = 0;
+    if (!rel.empty()) MK_HIP(hipStreamSynchronize(m->stream));  // `rel` must outlive the copy
+    return MK_OK;
+}
+
+// scans the uploaded batch; tuples (MK_MODE_HITS) stay UNORDERED in m->d_hits.  The device buffer starts at `cap`
+// tuples and the scan is repeated once with the exact size when more turn up and limit allows it (limit: the most
+// the caller can take; beyond it *found is reported and the tuples are incomplete).  Waits for the stream.
+int batch_scan(mk_matcher *m, uint64_t n_bytes, uint64_t n_rec, uint32_t mode, uint32_t batch_len, uint64_t cap, uint64_t limit,
+               unsigned long long *found) {
+    struct BatchLen {  // holds for the scans of THIS call only; a length set for device scans does not apply to them
+        mk_matcher *m;
+        uint32_t saved;
+        ~BatchLen() {
+            m->batch_rec_len = 0;
+            m->fixed_rec_len = saved;
+        }
+    } guard{m, m->fixed_rec_len};
+    m->fixed_rec_len = 0;
+    m->batch_rec_len = batch_len;
+    if (mode != MK_MODE_HITS) cap = 0;
+    *found = 0;
+    int rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (cap && (rc = ensure((void **)&m->d_hits, &m->d_hits_cap, cap * sizeof(mk_hit)))) return rc;
-        rc = mk_scan_device(m, m->d_seq, n_bytes, m->d_off, n_rec, mode, m->d_flags, m->d_hits, cap, m->d_nhits, nullptr,
-                            m->stream);
+        rc = mk_scan_device(m, m->d_seq, n_bytes, m->d_off, n_rec, mode, m->d_flags, m->d_hits, cap, m->d_nhits, nullptr, m->stream);
         if (rc) return rc;
-        MK_HIP(hipMemcpyAsync(&found, m->d_nhits, sizeof(found), hipMemcpyDeviceToHost, m->stream));
+        MK_HIP(hipMemcpyAsync(found, m->d_nhits, sizeof(*found), hipMemcpyDeviceToHost, m->stream));
         MK_HIP(hipStreamSynchronize(m->stream));
-        if (mode != MK_MODE_HITS || found <= cap || found > hits_cap) break;
-        cap = found;  // device buffer was the limit, the caller's buffer is big enough: rescan
+        if (mode != MK_MODE_HITS || *found <= cap || *found > limit) break;
+        cap = *found;  // the device buffer was the limit: once more, with room for all of them
     }
+    return MK_OK;
+}
+
+// flags of the scanned batch -> host; what the batch looked like steers the load flavour of the next one
+int batch_flags(mk_matcher *m, uint64_t n_rec, uint8_t *rec_flags, uint64_t *flagged_out) {
     MK_HIP(hipMemcpy(rec_flags, m->d_flags, n_rec, hipMemcpyDeviceToHost));
-    {  // what this batch looked like steers the load flavour of the next one
-        uint64_t flagged = 0;
-        for (uint64_t i = 0; i < n_rec; ++i) flagged += rec_flags[i] != 0;
-        m->hit_density_pm = (uint32_t)(flagged * 1000 / n_rec);
-    }
+    uint64_t flagged = 0;
+    for (uint64_t i = 0; i < n_rec; ++i) flagged += rec_flags[i] != 0;
+    m->hit_density_pm = n_rec ? (uint32_t)(flagged * 1000 / n_rec) : 0;
+    if (flagged_out) *flagged_out = flagged;
+    return MK_OK;
+}
+
+}  // namespace mk
+
+extern "C" {
+
+int mk_scan_batch(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint32_t mode,
+                  uint8_t *rec_flags, mk_hit *hits, uint64_t hits_cap, uint64_t *n_hits) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (mode > MK_MODE_HITS) return fail(MK_E_INVALID_ARG, "unknown mode %u", mode);
+    if (n_hits) *n_hits = 0;
+    if (n_rec == 0) return MK_OK;
+    if (!seq_off || !rec_flags) return fail(MK_E_INVALID_ARG, "null buffer");
+    uint64_t n_bytes = 0;
+    int rc = batch_check(seq_bytes, seq_off, n_rec, &n_bytes);
+    if (rc) return rc;
+    MK_ABI_BEGIN
+    uint32_t batch_len = 0;
+    if ((rc = batch_upload(m, seq_bytes, seq_off, n_rec, n_bytes, &batch_len))) return rc;
+    unsigned long long found = 0;
+    if ((rc = batch_scan(m, n_bytes, n_rec, mode, batch_len, std::max<uint64_t>(hits_cap, 1024), hits_cap, &found))) return rc;
+    if ((rc = batch_flags(m, n_rec, rec_flags, nullptr))) return rc;
     if (mode == MK_MODE_HITS) {
         if (n_hits) *n_hits = found;
         if (found > hits_cap)

@@ -64,6 +64,12 @@ struct mk_matcher {
     // what the last mk_order_hits_device did: 0 nothing, 1 record bins, 2 (record, A) bins, 3 library sort
     uint32_t order_path = 0, order_bins = 0, order_max_bin = 0;
     bool order_prepared = false;  // the ordering kernels' dynamic-LDS limit has been raised on this device
+    // scratch of the driver loops (host_loops.cpp): pattern sets, counters, rows
+    void *d_aux = nullptr;
+    size_t d_aux_cap = 0;
+    // where the last driver-loop call (mk_extract_single / mk_tag_records) spent its time, milliseconds:
+    // [0] upload (H2D), [1] device work (scan, ordering, sets, counts), [2] download (D2H), [3] host loops
+    float batch_ms[4] = {0, 0, 0, 0};
     const char *kernel_name = "";
     int last_grid = 0;
     // optional per-launch kernel timing (hipEvents recorded on the launch stream, tightly
@@ -74,3 +80,16 @@ struct mk_matcher {
     void *comm = nullptr;
     int comm_rank = 0, comm_size = 0;
 };
+
+namespace mk {
+// matcher.cpp: host-buffer batches in steps (mk_scan_batch, host_loops.cpp)
+int ensure_device(void **p, size_t *cap, size_t need);
+int batch_check(const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint64_t *n_bytes);
+int batch_upload(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *batch_len);
+int batch_scan(mk_matcher *m, uint64_t n_bytes, uint64_t n_rec, uint32_t mode, uint32_t batch_len, uint64_t cap, uint64_t limit,
+               unsigned long long *found);
+int batch_flags(mk_matcher *m, uint64_t n_rec, uint8_t *rec_flags, uint64_t *flagged_out);
+// tuples on the device into emission order: ac_order ? Aho-Corasick's : (record, pattern, position)
+int order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool ac_order, void *stream);
+int hip_fail(hipError_t e, const char *what);
+}  // namespace mk

@@ -118,6 +118,14 @@ hipError_t order_kernels_prepare();
 hipError_t order_hits_library(mk_hit *d_hits, size_t n, bool ac, const uint32_t *d_pat_off, uint32_t uniform_len, void *tmp,
                               size_t *tmp_bytes, hipStream_t stream);
 
+// ---- sets.hip: what the record loops derive from the ordered tuples ------------------------------------------
+// tuples in (record, pattern, position) order -> the distinct patterns of every record (CSR) and their total;
+// d_tile: scratch of max(ceil(n / 4096), ceil((n_rec + 1) / 4096)) * 8 bytes
+void launch_pattern_sets(const mk_hit *d_hits, uint64_t n, uint64_t n_rec, uint32_t *d_found_pat, unsigned long long *d_found_off,
+                         unsigned long long *d_total, void *d_tile, hipStream_t st);
+void launch_count_u32(const uint32_t *d_list, uint64_t n, uint32_t *d_counts, uint32_t n_bins, hipStream_t st);
+void launch_rows(const mk_hit *d_hits, uint64_t n, uint32_t file, mk_row *d_rows, hipStream_t st);
+
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);
 

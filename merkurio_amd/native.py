@@ -48,7 +48,7 @@ EXPORTS = [
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
-    "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_synth_reads_device",
+    "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_destroy",
 ]
@@ -168,6 +168,7 @@ def load(build_if_missing=True):
     L.mk_matcher_hint_record_lengths.argtypes = [C.c_void_p, C.c_int]
     L.mk_matcher_set_fixed_record_length.argtypes = [C.c_void_p, C.c_uint32]
     L.mk_matcher_check_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.mk_matcher_batch_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mk_matcher_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -355,6 +356,12 @@ class Matcher:
         g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(load().mk_matcher_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)))
         return {"grid_blocks": g.value, "block_threads": b.value, "lds_bytes": l.value}
+
+    def batch_times_ms(self):
+        """upload / device / download / host milliseconds of the last extract_single / tag_records call"""
+        ms = (C.c_float * 4)()
+        _check(load().mk_matcher_batch_times(self._h, ms))
+        return {"upload": ms[0], "device": ms[1], "download": ms[2], "host": ms[3]}
 
     def order_info(self):
         """what the last mk_order_hits_device did: path 0 nothing, 1 record bins, 2 (record, end) bins, 3 library sort"""

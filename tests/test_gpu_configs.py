@@ -502,7 +502,7 @@ def test_more_than_2_pow_32_records(mk):
     planted = [0, 5, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, 1 << 32, (1 << 32) + 7, n - 1]
     m = mk.Matcher([b"A"])  # one pattern: the BNDMq domain, stride 1
     st = torch.cuda.current_stream().cuda_stream
-    d_flags = torch.zeros(n + 8, dtype=torch.uint8, device=dev)
+    d_flags = torch.empty(n + 8, dtype=torch.uint8, device=dev)  # (every scan clears it)
     d_hits = torch.zeros(2 * 1024, dtype=torch.int64, device=dev)
     d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
     d_cnt = torch.zeros(1 + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
@@ -513,8 +513,11 @@ def test_more_than_2_pow_32_records(mk):
             assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, d_off.data_ptr() if d_off is not None else None, n, mode,
                                       d_flags.data_ptr(), d_hits.data_ptr(), 1024, d_nh.data_ptr(), d_cnt.data_ptr(), st) == 0, lib.mk_last_error()
             torch.cuda.synchronize()
-            assert int(d_flags[:n].sum(dtype=torch.int64).item()) == len(where), (label, mode)
-            assert all(int(d_flags[r].item()) == 1 for r in where), (label, mode)
+            flagged = [r for r in where if int(d_flags[r:r + 1].item()) == 1]
+            assert flagged == where, (label, mode, flagged)
+            # (sums in pieces of 2^30: nothing here relies on 64-bit indexing inside a torch reduction)
+            total = sum(int(d_flags[a:min(n, a + (1 << 30))].sum(dtype=torch.int64).item()) for a in range(0, n, 1 << 30))
+            assert total == len(where), (label, mode, total)
         assert lib.mk_matcher_check_device(m.handle, st) == 0
         nh = int(d_nh.item())
         assert nh == len(where)
@@ -527,9 +530,34 @@ def test_more_than_2_pow_32_records(mk):
         return got
 
     # (1) equal lengths through the offsets array
-    d_seq = torch.full((n + 64,), ord("C"), dtype=torch.uint8, device=dev)
-    d_seq[torch.tensor(planted, device=dev)] = ord("A")
-    d_off = torch.arange(n + 1, dtype=torch.int64, device=dev)
+    # torch's own kernels index with 32 bits in places (arange over 2^32 + 17 elements returned zeros beyond 2^32 on
+    # this image): every torch operation below works on pieces of at most 2^30 elements
+    PIECE = 1 << 30
+
+    def fill(t, value):
+        for a in range(0, t.numel(), PIECE):
+            t[a:a + PIECE].fill_(value)
+
+    def iota(t, add_from=None):  # t[i] = i (+ 1 from index add_from on)
+        for a in range(0, t.numel(), PIECE):
+            b = min(t.numel(), a + PIECE)
+            t[a:b] = torch.arange(a, b, dtype=torch.int64, device=dev)
+            if add_from is not None and b > add_from:
+                t[max(a, add_from):b] += 1
+
+    def plant(t, positions):  # one slice per byte
+        for q in positions:
+            t[q:q + 1] = ord("A")
+        torch.cuda.synchronize()
+        assert all(int(t[q:q + 1].item()) == ord("A") for q in positions)
+
+    d_seq = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    fill(d_seq, ord("C"))
+    plant(d_seq, planted)
+    assert int(d_seq[(1 << 32) + 1:(1 << 32) + 2].item()) == ord("C")
+    d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    iota(d_off)
+    assert int(d_off[n:n + 1].item()) == n and int(d_off[(1 << 32) + 3:(1 << 32) + 4].item()) == (1 << 32) + 3
     got = check(d_seq, n, d_off, planted, "offsets")
     assert set(got["pos"].tolist()) == {0}
     # (2) the same as a fixed-length batch: no offsets array
@@ -537,10 +565,12 @@ def test_more_than_2_pow_32_records(mk):
     check(d_seq, n, None, planted, "fixed length")
     assert lib.mk_matcher_set_fixed_record_length(m.handle, 0) == 0
     # (3) ragged: record 3 has two bytes ("CA": an occurrence at position 1), every record behind it starts one byte later
-    d_off[4:] += 1
-    d_seq2 = torch.full((n + 1 + 64,), ord("C"), dtype=torch.uint8, device=dev)
+    iota(d_off, add_from=4)
+    d_seq2 = torch.empty(n + 1 + 64, dtype=torch.uint8, device=dev)
+    fill(d_seq2, ord("C"))
     where = [3] + [r for r in planted if r > 3]
-    d_seq2[torch.tensor([4] + [r + 1 for r in planted if r > 3], device=dev)] = ord("A")
+    plant(d_seq2, [4] + [r + 1 for r in planted if r > 3])
+    assert int(d_off[n:n + 1].item()) == n + 1 and int(d_off[3:4].item()) == 3 and int(d_off[4:5].item()) == 5
     assert lib.mk_matcher_hint_record_lengths(m.handle, 0) == 0
     got = check(d_seq2, n + 1, d_off, where, "ragged")
     assert got["pos"].tolist() == [1] + [0] * (len(where) - 1)

@@ -13,11 +13,11 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--records $REC --steps $STEPS --warmup 1 --no-cpu-baseline $*"
+ARGS="--records $REC --steps $STEPS --warmup 1 --no-cpu-baseline --no-other-configs $*"
 echo "python3 bench.py $ARGS" > $OUT/command.txt
 # the kernel trace runs the bench's own default step counts (20 timed + 3 warm-up launches), so that its
 # average is the steady-state figure bench.py reports from hipEvents; the PMC passes use fewer steps
-KT_ARGS="--records $REC --steps 20 --warmup 3 --no-cpu-baseline $*"
+KT_ARGS="--records $REC --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs $*"
 echo "python3 bench.py $KT_ARGS   (kernel trace)" >> $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py $KT_ARGS > $OUT/kt.log 2>&1
 echo "kernel-trace rc=$?"

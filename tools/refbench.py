@@ -17,8 +17,9 @@ rng = np.random.default_rng(20240)
 
 def write_fastq(path, mate):
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(N, L))]
-    hdr = np.array([f"@SRR022868.{i:07d}/{mate}\n" for i in range(N)], dtype="S22")
+    hdr = np.array([f"@SRR022868.{i:07d}/{mate}\n" for i in range(N)], dtype="S21")
     H = hdr.dtype.itemsize
+    assert H == len(f"@SRR022868.{0:07d}/{mate}\n")
     rec = np.empty((N, H + L + 3 + L + 1), dtype=np.uint8)
     rec[:, :H] = hdr.view(np.uint8).reshape(N, H)
     rec[:, H:H + L] = bases

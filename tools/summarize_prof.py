@@ -61,9 +61,9 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and scan_name:
     a = bench.parse_args(bench_args.split())
     short = re.sub(r"^void mk::", "", scan_name).split("(")[0].replace(" ", "")
     # bench.py's kernel names leave the stream-load flavour (5th template argument) out / call it "plain"
-    m5 = re.match(r"(mk_scan_kernel<[^>]*),(true|false)>$", short)
+    m5 = re.match(r"(mk_scan_kernel<[^>]*),(true|false|0|1)>$", short)
     if m5:
-        short = m5.group(1) + (">" if m5.group(2) == "true" else ",plain>")
+        short = m5.group(1) + (">" if m5.group(2) in ("true", "1") else ",plain>")
     fetch_kb, write_kb = pmc["FETCH_SIZE"], pmc["WRITE_SIZE"]
     j = {
         "source": "tools/profile_gpu.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, --kernel-trace only",
