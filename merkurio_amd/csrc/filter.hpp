@@ -33,7 +33,11 @@ constexpr uint32_t kBloomWords = 2 * kBloomBlocks;         // 32-bit words: 128 
 constexpr uint32_t kBloomBytes = kBloomWords * 4;
 constexpr uint32_t kEmptyPat = 0xFFFFFFFFu;
 constexpr int kChunkBytes = 1024;                          // one wave-iteration: 64 lanes x 16 B
-constexpr int kTileChunks = 31;                            // scanned chunks per wave tile (+1 halo chunk = 32 loads)
+#ifndef MK_TILE_CHUNKS
+#define MK_TILE_CHUNKS 31  // (A/B builds: 4 k - 1 for any k, e.g. 127 = the halo chunk carried across a run of four tiles)
+#endif
+constexpr int kTileChunks = MK_TILE_CHUNKS;                // scanned chunks per wave tile (+1 halo chunk = 32 loads)
+static_assert((kTileChunks + 1) % 4 == 0, "a tile is a whole number of four-chunk load groups");
 constexpr int kBlockThreads = 1024;                        // 16 waves, one workgroup per CU
 
 // one exact-table slot (8 B): the 32-bit filter hash h of the q-gram key (level 2 is keyed by the
