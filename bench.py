@@ -104,6 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--plant-every", type=int, default=100, help="1 in N reads carries a planted k-mer")
     ap.add_argument("--rc", action="store_true", help="add reverse complements to the pattern list (-r)")
+    ap.add_argument("--random-kmers", action="store_true",
+                    help="all k-mers uniform random (default: half of them sampled from reads of the job, SURVEY.md 8d)")
     ap.add_argument("--mode", choices=["any", "hits"], default="any",
                     help="any = per-record flags (extract without logging, the headline); hits = also emit every "
                          "(record, pattern, position) tuple (extract/tag with logging)")
@@ -183,8 +185,27 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
 
-    # ---- pattern set (identical on every rank) and matcher
+    # ---- pattern set (identical on every rank) and matcher.  SURVEY.md 8d / the reference's own recipe
+    # (benchmarks/scripts/02-generate-kmers.sh:24-39): half of the k-mers are substrings of distinct reads of the job
+    # at uniform offsets, half uniform random (--random-kmers: all random, the round-1/2 recipe)
+    L = args.read_len
+    seed = 0x4D65724B7572696F
+    lib = mk.load()
     raw = make_patterns(args.patterns, args.k)
+    if not args.random_kmers and args.k <= L:
+        job_reads = (args.total_records or args.records) if args.scaling == "strong" else args.records * world
+        rng = np.random.default_rng(0x6B6D6572)
+        n_from = args.patterns // 2
+        picks = np.unique(rng.integers(0, job_reads, size=n_from + n_from // 8 + 8))[:n_from]
+        offs = rng.integers(0, L - args.k + 1, size=len(picks))
+        tmp = mk.Matcher([b"A" * args.k], device=dev_index)  # (only its handle: the generator plants nothing here)
+        buf, one_off = np.zeros(L, dtype=np.uint8), np.zeros(2, dtype=np.uint64)
+        sampled = []
+        for r, o in zip(picks.tolist(), offs.tolist()):
+            mk._check(lib.mk_synth_reads_host(tmp.handle, seed, r, 1, L, 0, buf.ctypes.data, one_off.ctypes.data))
+            sampled.append(buf[o:o + args.k].tobytes())
+        tmp.close()
+        raw = sampled + raw[len(sampled):]
     patterns = mk.parse_pattern_list(kmer_seq=raw)[:args.patterns]
     assert len(patterns) == args.patterns
     if args.rc:
@@ -195,7 +216,6 @@ def main():
                        gbloom_log2_blocks=args.gbloom_log2_blocks, tile_run=args.tile_run, gbloom_kib=args.gbloom_kib)
     m = mk.Matcher(patterns, device=dev_index, options=options)
     assert m.use_ac == mk.recommend_aho_corasick(patterns)
-    lib = mk.load()
     if args.ragged and not args.no_rec_index:
         mk._check(lib.mk_matcher_hint_record_lengths(m.handle, 0))
     if not args.ragged and not args.with_offsets:
@@ -206,7 +226,6 @@ def main():
 
     # ---- this rank's shard of the job: contiguous range of records (pairs), in units of 16 so
     # that every shard starts on a block of the counter-based generator
-    L = args.read_len
     if args.scaling == "strong":
         total = (args.total_records or args.records) // 16 * 16
         lo, hi = [16 * b for b in sharding.shard_bounds(total // 16, world)[rank]]
@@ -218,7 +237,6 @@ def main():
     n_rec = hi - lo
     n_bytes = n_rec * L
     n_mates = 2 if args.paired else 1
-    seed = 0x4D65724B7572696F
     stream = torch.cuda.current_stream()
     st = stream.cuda_stream
     mates = []
@@ -362,7 +380,8 @@ def main():
             "config": {
                 "workload": f"extract{' -2 (paired)' if args.paired else ''} ({'all hit tuples' if emit else 'any-hit flags'}): "
                             f"{total} x {L} bp synthetic {what} in the job, {n_rec} per GPU on rank 0, "
-                            f"{len(patterns)} {args.k}-mers, Aho-Corasick semantics, 1/{args.plant_every} reads planted",
+                            f"{len(patterns)} {args.k}-mers ({'all random' if args.random_kmers else 'half sampled from reads, half random'}), "
+                            f"Aho-Corasick semantics, 1/{args.plant_every} reads planted",
                 "records_total": total, "records_per_gpu": n_rec, "paired": args.paired, "read_len": L,
                 "patterns": len(patterns), "k": args.k,
                 "sharding": f"contiguous record ranges x{world}" + (", pairs unsplit" if args.paired else ""),
