@@ -124,6 +124,43 @@ struct DeviceLoop {
         return MK_OK;
     }
 
+    // paired extract: the marked pair list (sets.hip) -> rows with their mate
+    int pair_rows_to_host(bool ac, mk_row *rows, uint64_t cap) {
+        const uint64_t n = std::min<uint64_t>(found, rows ? cap : 0);
+        if (!n) return MK_OK;
+        int rc = ensure_device(&m->d_aux, &m->d_aux_cap, n * sizeof(mk_row));
+        if (rc) return rc;
+        launch_rows_pair(m->d_hits, n, ac, (mk_row *)m->d_aux, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "row kernel failed");
+        mark(2);
+        if (hipMemcpy(rows, m->d_aux, n * sizeof(mk_row), hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the log rows failed");
+        mark(1);
+        return MK_OK;
+    }
+    // pattern_hit_counts of the ordered pair list: AC one per hit of either mate (:492,:520); BNDMq one per pair,
+    // pattern and mate with a hit (:575-584)
+    int pair_counts(bool ac, uint32_t *counts) {
+        const uint32_t n_pat = m->n_pat;
+        if (ac) {
+            unsigned long long n = found;  // the histogram kernel reads the tuple count from the device
+            if (hipMemcpyAsync(m->d_nhits, &n, sizeof(n), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                return fail(MK_E_HIP, "copy failed");
+            return pattern_counts(true, 0, counts);
+        }
+        int rc = ensure_device(&m->d_aux, &m->d_aux_cap, (size_t)n_pat * 4);
+        if (rc) return rc;
+        if (hipMemsetAsync(m->d_aux, 0, (size_t)n_pat * 4, st) != hipSuccess) return fail(MK_E_HIP, "memset failed");
+        launch_count_pair_heads(m->d_hits, found, (uint32_t *)m->d_aux, n_pat, st);
+        std::vector<uint32_t> v(n_pat);
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "count kernel failed");
+        mark(2);
+        if (hipMemcpy(v.data(), m->d_aux, (size_t)n_pat * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the counts failed");
+        mark(3);
+        for (uint32_t i = 0; i < n_pat; ++i) counts[i] += v[i];
+        mark(1);
+        return MK_OK;
+    }
+
     // pattern_hit_counts += this batch's: per hit (AC, src/cmd_extract.rs:353) or per (record, pattern) with a hit
     // (BNDMq, :380-383; the tuples must be in BNDMq order = set order)
     int pattern_counts(bool per_hit, uint64_t n_rec, uint32_t *counts) {
@@ -235,6 +272,58 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
     MK_ABI_END
 }
 
+// the pair loop with the rows merged on the host (mates of 2 GiB or more under BNDMq: the device pair order keeps
+// the mate in bit 31 of the position)
+static int extract_paired_host_merge(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, const uint8_t *seq2,
+                                     const uint64_t *off2, uint64_t n_rec, int invert, uint8_t *keep, mk_row *rows,
+                                     uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts) {
+    std::vector<uint8_t> f1, f2;
+    std::vector<mk_hit> h1, h2;
+    int rc = scan_all(m, seq1, off1, n_rec, MK_MODE_HITS, f1, h1);
+    if (rc) return rc;
+    rc = scan_all(m, seq2, off2, n_rec, MK_MODE_HITS, f2, h2);
+    if (rc) return rc;
+    RowSink sink{rows, rows_cap};
+    c->nb_records_tot += 2 * n_rec;  // :472
+    c->nb_bases += (off1[n_rec] - off1[0]) + (off2[n_rec] - off2[0]);
+    c->nb_hits_tot[0] += h1.size();
+    c->nb_hits_tot[1] += h2.size();
+    c->nb_records_hit[0] += popcount_flags(f1, n_rec);
+    c->nb_records_hit[1] += popcount_flags(f2, n_rec);
+    count_patterns(m->algo, h1, counts);  // BNDMq: once per mate that hit (:575-584)
+    count_patterns(m->algo, h2, counts);
+    size_t i1 = 0, i2 = 0;  // merge the two ordered hit lists pair by pair
+    while (i1 < h1.size() || i2 < h2.size()) {
+        const uint64_t r1 = i1 < h1.size() ? h1[i1].rec : ~0ull, r2 = i2 < h2.size() ? h2[i2].rec : ~0ull;
+        const uint64_t r = std::min(r1, r2);
+        size_t e1 = i1, e2 = i2;
+        while (e1 < h1.size() && h1[e1].rec == r) ++e1;
+        while (e2 < h2.size() && h2[e2].rec == r) ++e2;
+        if (m->algo == MK_ALGO_AC) {  // all of mate 1, then all of mate 2 (:480-533)
+            for (size_t k = i1; k < e1; ++k) sink.push(0, h1[k]);
+            for (size_t k = i2; k < e2; ++k) sink.push(1, h2[k]);
+        } else {  // per pattern: mate-1 hits then mate-2 hits (:543-585)
+            size_t a = i1, b = i2;
+            while (a < e1 || b < e2) {
+                const uint32_t pa = a < e1 ? h1[a].pat : 0xFFFFFFFFu, pb = b < e2 ? h2[b].pat : 0xFFFFFFFFu;
+                const uint32_t p = std::min(pa, pb);
+                while (a < e1 && h1[a].pat == p) sink.push(0, h1[a++]);
+                while (b < e2 && h2[b].pat == p) sink.push(1, h2[b++]);
+            }
+        }
+        i1 = e1;
+        i2 = e2;
+    }
+    for (uint64_t r = 0; r < n_rec; ++r) {  // :600-606
+        const bool found = f1[r] || f2[r];
+        keep[r] = (uint8_t)(found != (invert != 0));
+        c->nb_records_extracted += 2 * keep[r];
+    }
+    if (n_rows) *n_rows = sink.n;
+    if (rows && sink.n > rows_cap) return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
+    return MK_OK;
+}
+
 int mk_extract_paired(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, uint64_t n_rec1,
                       const uint8_t *seq2, const uint64_t *off2, uint64_t n_rec2, int logging, int invert,
                       uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c,
@@ -245,56 +334,79 @@ int mk_extract_paired(mk_matcher *m, const uint8_t *seq1, const uint64_t *off1, 
         return fail(MK_E_PAIR_MISMATCH,
                     "The two input files have a different number of records. Please provide valid paired-end read files.");
     const uint64_t n_rec = n_rec1;
+    if (n_rec == 0) return MK_OK;
+    if (!off1 || !off2) return fail(MK_E_INVALID_ARG, "null buffer");
     MK_ABI_BEGIN
-    std::vector<uint8_t> f1, f2;
-    std::vector<mk_hit> h1, h2;
+    const bool ac = m->algo == MK_ALGO_AC;
+    if (logging && !ac) {  // the device pair order of BNDMq keeps the mate in bit 31 of the position
+        bool small = true;
+        if ((off1[n_rec] - off1[0]) >= (1ull << 31) || (off2[n_rec] - off2[0]) >= (1ull << 31))
+            for (uint64_t i = 0; i < n_rec && small; ++i)
+                small = off1[i + 1] - off1[i] < (1ull << 31) && off2[i + 1] - off2[i] < (1ull << 31);
+        if (!small) return extract_paired_host_merge(m, seq1, off1, seq2, off2, n_rec, invert, keep, rows, rows_cap, n_rows, c, counts);
+    }
+    DeviceLoop dl(m);
+    std::vector<uint8_t> f1(n_rec), f2(n_rec);
+    uint64_t flagged1 = 0, flagged2 = 0;
     const uint32_t mode = logging ? MK_MODE_HITS : MK_MODE_ANY;
-    int rc = scan_all(m, seq1, off1, n_rec, mode, f1, h1);
+    int rc = dl.scan(seq1, off1, n_rec, mode, f1.data(), &flagged1);
     if (rc) return rc;
-    rc = scan_all(m, seq2, off2, n_rec, mode, f2, h2);
-    if (rc) return rc;
-    RowSink sink{rows, rows_cap};
+    const unsigned long long n1 = dl.found;
+    if (logging && n1) {  // mate 1's tuples wait in their own buffer while mate 2 is scanned
+        if ((rc = ensure_device(&m->d_pair, &m->d_pair_cap, n1 * sizeof(mk_hit)))) return rc;
+        if (hipMemcpyAsync(m->d_pair, m->d_hits, n1 * sizeof(mk_hit), hipMemcpyDeviceToDevice, dl.st) != hipSuccess ||
+            hipStreamSynchronize(dl.st) != hipSuccess)
+            return fail(MK_E_HIP, "copy of the first mate's tuples failed");
+    }
+    if ((rc = dl.scan(seq2, off2, n_rec, mode, f2.data(), &flagged2))) return rc;
+    const unsigned long long n2 = dl.found;
+    uint64_t total_rows = 0;
     if (logging) {
         c->nb_records_tot += 2 * n_rec;  // :472
-        c->nb_bases += n_rec ? (off1[n_rec] - off1[0]) + (off2[n_rec] - off2[0]) : 0;
-        c->nb_hits_tot[0] += h1.size();
-        c->nb_hits_tot[1] += h2.size();
-        c->nb_records_hit[0] += popcount_flags(f1, n_rec);
-        c->nb_records_hit[1] += popcount_flags(f2, n_rec);
-        count_patterns(m->algo, h1, counts);  // BNDMq: once per mate that hit (:575-584)
-        count_patterns(m->algo, h2, counts);
-        // merge the two ordered hit lists pair by pair
-        size_t i1 = 0, i2 = 0;
-        while (i1 < h1.size() || i2 < h2.size()) {
-            const uint64_t r1 = i1 < h1.size() ? h1[i1].rec : ~0ull, r2 = i2 < h2.size() ? h2[i2].rec : ~0ull;
-            const uint64_t r = std::min(r1, r2);
-            size_t e1 = i1, e2 = i2;
-            while (e1 < h1.size() && h1[e1].rec == r) ++e1;
-            while (e2 < h2.size() && h2[e2].rec == r) ++e2;
-            if (m->algo == MK_ALGO_AC) {  // all of mate 1, then all of mate 2 (:480-533)
-                for (size_t k = i1; k < e1; ++k) sink.push(0, h1[k]);
-                for (size_t k = i2; k < e2; ++k) sink.push(1, h2[k]);
-            } else {  // per pattern: mate-1 hits then mate-2 hits (:543-585)
-                size_t a = i1, b = i2;
-                while (a < e1 || b < e2) {
-                    const uint32_t pa = a < e1 ? h1[a].pat : 0xFFFFFFFFu, pb = b < e2 ? h2[b].pat : 0xFFFFFFFFu;
-                    const uint32_t p = std::min(pa, pb);
-                    while (a < e1 && h1[a].pat == p) sink.push(0, h1[a++]);
-                    while (b < e2 && h2[b].pat == p) sink.push(1, h2[b++]);
+        c->nb_bases += (off1[n_rec] - off1[0]) + (off2[n_rec] - off2[0]);
+        c->nb_hits_tot[0] += n1;
+        c->nb_hits_tot[1] += n2;
+        c->nb_records_hit[0] += flagged1;
+        c->nb_records_hit[1] += flagged2;
+        total_rows = n1 + n2;
+        if (total_rows) {
+            // one list: mate 2's tuples (already in the scan buffer), then mate 1's, the mate marked inside a key field
+            if ((n1 + n2) * sizeof(mk_hit) > m->d_hits_cap) {  // grow the scan buffer, keeping mate 2's tuples
+                void *bigger = nullptr;
+                size_t cap = 0;
+                if ((rc = ensure_device(&bigger, &cap, (n1 + n2) * sizeof(mk_hit)))) return rc;
+                if (n2 && hipMemcpy(bigger, m->d_hits, n2 * sizeof(mk_hit), hipMemcpyDeviceToDevice) != hipSuccess) {
+                    (void)hipFree(bigger);
+                    return fail(MK_E_HIP, "copy of the second mate's tuples failed");
                 }
+                if (m->d_hits) (void)hipFree(m->d_hits);
+                m->d_hits = (mk_hit *)bigger;
+                m->d_hits_cap = cap;
             }
-            i1 = e1;
-            i2 = e2;
+            if (n1 && hipMemcpyAsync(m->d_hits + n2, m->d_pair, n1 * sizeof(mk_hit), hipMemcpyDeviceToDevice, dl.st) != hipSuccess)
+                return fail(MK_E_HIP, "copy of the first mate's tuples failed");
+            launch_pair_mark(m->d_hits, n2, 1, ac, dl.st);
+            launch_pair_mark(m->d_hits + n2, n1, 0, ac, dl.st);
+            dl.found = total_rows;
+            const uint64_t bound = m->last_n_rec;
+            if (ac) m->last_n_rec = 2 * n_rec;  // record' = 2 * record + mate: the bins of the ordering
+            rc = dl.order(ac);
+            m->last_n_rec = bound;
+            if (rc) return rc;
+            if ((rc = dl.pair_rows_to_host(ac, rows, rows_cap))) return rc;
+            if ((rc = dl.pair_counts(ac, counts))) return rc;
         }
     }
+    dl.host_begin();
     for (uint64_t r = 0; r < n_rec; ++r) {  // :600-606
         const bool found = f1[r] || f2[r];
         keep[r] = (uint8_t)(found != (invert != 0));
         c->nb_records_extracted += 2 * keep[r];
     }
-    if (n_rows) *n_rows = sink.n;
-    if (logging && rows && sink.n > rows_cap)
-        return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)sink.n);
+    dl.finish();
+    if (n_rows) *n_rows = total_rows;
+    if (logging && rows && total_rows > rows_cap)
+        return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)total_rows);
     return MK_OK;
     MK_ABI_END
 }

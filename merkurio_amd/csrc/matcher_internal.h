@@ -67,6 +67,8 @@ struct mk_matcher {
     // scratch of the driver loops (host_loops.cpp): pattern sets, counters, rows
     void *d_aux = nullptr;
     size_t d_aux_cap = 0;
+    void *d_pair = nullptr;  // paired extract: mate 1's tuples while mate 2 is scanned
+    size_t d_pair_cap = 0;
     // where the last driver-loop call (mk_extract_single / mk_tag_records) spent its time, milliseconds:
     // [0] upload (H2D), [1] device work (scan, ordering, sets, counts), [2] download (D2H), [3] host loops
     float batch_ms[4] = {0, 0, 0, 0};

@@ -125,6 +125,10 @@ void launch_pattern_sets(const mk_hit *d_hits, uint64_t n, uint64_t n_rec, uint3
                          unsigned long long *d_total, void *d_tile, hipStream_t st);
 void launch_count_u32(const uint32_t *d_list, uint64_t n, uint32_t *d_counts, uint32_t n_bins, hipStream_t st);
 void launch_rows(const mk_hit *d_hits, uint64_t n, uint32_t file, mk_row *d_rows, hipStream_t st);
+// paired extract: both mates' tuples in one list, the mate inside a key field (sets.hip)
+void launch_pair_mark(mk_hit *d_hits, uint64_t n, uint32_t mate, bool ac, hipStream_t st);
+void launch_rows_pair(const mk_hit *d_hits, uint64_t n, bool ac, mk_row *d_rows, hipStream_t st);
+void launch_count_pair_heads(const mk_hit *d_hits, uint64_t n, uint32_t *d_counts, uint32_t n_bins, hipStream_t st);
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

@@ -224,7 +224,66 @@ __global__ void mk_rows_kernel(const mk_hit *__restrict__ hits, uint64_t n, uint
     }
 }
 
+// ---- paired extract: the tuples of both mates in ONE list, the mate carried inside a key field ------------------
+// Aho-Corasick pair order (src/cmd_extract.rs:479-537): per pair all mate-1 matches, then all mate-2 matches ->
+// record' = 2 * record + mate, then the AC order.  BNDMq pair order (:542-587): per pair and pattern the mate-1
+// positions, then the mate-2 positions -> position' = mate << 31 | position (mates shorter than 2 GiB), then the
+// BNDMq order.
+__global__ void mk_pair_mark_kernel(mk_hit *__restrict__ hits, uint64_t n, uint32_t mate, uint32_t ac) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (ac)
+            hits[i].rec = 2 * hits[i].rec + mate;
+        else
+            hits[i].pos |= mate << 31;
+    }
+}
+
+__global__ void mk_rows_pair_kernel(const mk_hit *__restrict__ hits, uint64_t n, uint32_t ac, mk_row *__restrict__ rows) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const mk_hit h = hits[i];
+        mk_row r;
+        r.rec = ac ? h.rec >> 1 : h.rec;
+        r.pat = h.pat;
+        r.pos = ac ? h.pos : (h.pos & 0x7FFFFFFFu);
+        r.file = ac ? (uint32_t)(h.rec & 1) : (h.pos >> 31);
+        r._pad = 0;
+        rows[i] = r;
+    }
+}
+
+// BNDMq pattern_hit_counts of a pair list in BNDMq pair order: += 1 per (pair, pattern, mate) with a hit
+// (src/cmd_extract.rs:575-584: once for mate 1, once more for mate 2)
+__global__ void mk_count_pair_heads_kernel(const mk_hit *__restrict__ hits, uint64_t n, uint32_t *__restrict__ counts, uint32_t n_bins) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const mk_hit h = hits[i];
+        bool head = i == 0;
+        if (!head) {
+            const mk_hit p = hits[i - 1];
+            head = p.rec != h.rec || p.pat != h.pat || (p.pos >> 31) != (h.pos >> 31);
+        }
+        if (head && h.pat < n_bins) atomicAdd(&counts[h.pat], 1u);
+    }
+}
+
 }  // namespace
+
+void launch_pair_mark(mk_hit *d_hits, uint64_t n, uint32_t mate, bool ac, hipStream_t st) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(mk_pair_mark_kernel, dim3(blocks), dim3(256), 0, st, d_hits, n, mate, ac ? 1u : 0u);
+}
+
+void launch_rows_pair(const mk_hit *d_hits, uint64_t n, bool ac, mk_row *d_rows, hipStream_t st) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(mk_rows_pair_kernel, dim3(blocks), dim3(256), 0, st, d_hits, n, ac ? 1u : 0u, d_rows);
+}
+
+void launch_count_pair_heads(const mk_hit *d_hits, uint64_t n, uint32_t *d_counts, uint32_t n_bins, hipStream_t st) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(mk_count_pair_heads_kernel, dim3(blocks), dim3(256), 0, st, d_hits, n, d_counts, n_bins);
+}
 
 // tuples in set order -> d_found_pat (distinct patterns per record, ascending), d_found_off[n_rec + 1], *d_total.
 // d_tile: scratch of max(ceil(n / 4096), ceil((n_rec + 1) / 4096)) * 8 bytes.
