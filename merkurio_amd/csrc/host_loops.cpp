@@ -6,7 +6,7 @@
 // The matching itself is the gfx950 scan kernel; nothing here searches text.  extract (single) and tag work on the
 // device from end to end: scan -> tuples ordered on the device (order_hits.hip) -> log rows, per-pattern counts and
 // the per-record pattern sets by the kernels of sets.hip -> results copied back.  The host threads only turn flags
-// into keep decisions.  (The paired loop still merges its two ordered tuple lists on the host.)
+// into keep decisions.  The paired loop orders both mates' tuples as one list, the mate inside a key field.
 #include <algorithm>
 #include <chrono>
 #include <cstring>

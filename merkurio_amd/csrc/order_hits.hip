@@ -258,13 +258,25 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint
 #pragma unroll
         for (int r = 0; r < kKpt; ++r) sk[base + r] = v[r];
     }
-    __syncthreads();
+    // A round whose four index bits lie below bit 10 - be <= 6 - keeps every wave inside its own block of 1024 keys
+    // (64 lanes x 16 keys): between two such rounds the waves need not wait for each other, the LDS pipeline orders
+    // a wave's own reads behind its writes.  Only the top rounds of the last phases cross waves.
+    bool prev_local = true;  // the round above touched 16 consecutive keys per lane
     for (uint32_t p = kLogKpt + 1; p <= logm; ++p) {
         for (int jhi = (int)p - 1; jhi >= 0;) {
             const int nb = ((jhi + 1) & 3) ? ((jhi + 1) & 3) : 4;  // the rounds below this one take four stages each
             const int jlo = jhi - nb + 1;
             const uint32_t be = std::min<uint32_t>((uint32_t)jlo, logm - kLogKpt);  // register index = index bits [be, be+4)
             const int jr_hi = jhi - (int)be, jr_lo = jlo - (int)be;
+            const bool local = be <= 6 || nact <= 64;
+            if (prev_local && local) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                __syncthreads();
+            }
+            prev_local = local;
             if (tid < nact) {
                 const uint32_t p_rel = p - be;
                 const uint32_t dir_t = (p < logm && p_rel >= (uint32_t)kLogKpt) ? ((tid >> (p - kLogKpt)) & 1u) : 0u;
@@ -279,10 +291,10 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint
 #pragma unroll
                 for (int r = 0; r < kKpt; ++r) sk[padi(i0 | ((uint32_t)r << be))] = v[r];
             }
-            __syncthreads();
             jhi = jlo - 1;
         }
     }
+    __syncthreads();
     // keys -> tuples, in their final place
     const uint64_t mask_b = (1ull << L.bits_b) - 1ull, mask_a = (1ull << L.bits_a) - 1ull;  // widths 1..63
     uint4 *__restrict__ ov = reinterpret_cast<uint4 *>(out);
