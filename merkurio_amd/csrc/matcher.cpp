@@ -621,12 +621,10 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
         launch_order_hist(hits, n, L, S, m->num_cus, st);
         MK_HIP(hipGetLastError());
         MK_HIP(hipMemcpyAsync(stats, S.stats, sizeof(stats), hipMemcpyDeviceToHost, st));
-        if (attempt == 0) {  // the scan that wrote these tuples may have met a record it cannot address
-            int rc_e = take_device_errors(m, st);
-            if (rc_e) return rc_e;
-        } else {
-            MK_HIP(hipStreamSynchronize(st));
-        }
+        uint32_t err_word = 0;  // the scan that wrote these tuples may have met a record it cannot address: same round trip
+        MK_HIP(hipMemcpyAsync(&err_word, m->d_error, sizeof(err_word), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        if (err_word) return take_device_errors(m, st);
         // done unless a record lies beyond the bound (tuples of another batch than the handle's last scan), or a
         // bin overflows while the bound is at least twice the largest record seen (the bins are coarser than they
         // need be): once more with the exact bound

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_hist_kernel(const mk_h
 // ---- bin starts (exclusive prefix sum over <= 32768 bins, one workgroup) and the largest bin -------------
 __global__ __launch_bounds__(kOrderThreads) void mk_order_scan_kernel(const uint32_t *__restrict__ g_cnt, uint32_t n_bins, uint32_t *__restrict__ bin_start,
                                                                        uint32_t *__restrict__ cursor, unsigned long long *__restrict__ stats) {
-    __shared__ uint32_t part[kOrderThreads];
+    __shared__ uint32_t part[kOrderThreads / 64];
     __shared__ uint32_t wmax[kOrderThreads / 64];
     const uint32_t per = (n_bins + kOrderThreads - 1) / kOrderThreads;
     const uint32_t lo = std::min(n_bins, threadIdx.x * per), hi = std::min(n_bins, lo + per);
@@ -136,21 +136,29 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_scan_kernel(const uint
         sum += c;
         mx = c > mx ? c : mx;
     }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < kOrderThreads; o <<= 1) {  // inclusive Hillis-Steele scan of the per-thread sums
-        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    // exclusive prefix of the per-lane sums: inside a wave by shuffles, across the 16 waves through LDS
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((threadIdx.x & 63) >= (uint32_t)o) incl += v;
     }
-    uint32_t run = part[threadIdx.x] - sum;  // exclusive
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kOrderThreads / 64; ++w) {
+        const uint32_t t = part[w];
+        if (w < (threadIdx.x >> 6)) before += t;
+        total += t;
+    }
+    uint32_t run = before + incl - sum;  // exclusive
     for (uint32_t i = lo; i < hi; ++i) {
         bin_start[i] = run;
         cursor[i] = run;
         run += g_cnt[i];
     }
-    if (threadIdx.x == kOrderThreads - 1) bin_start[n_bins] = part[kOrderThreads - 1];
+    if (threadIdx.x == 0) bin_start[n_bins] = total;
     mx = (uint32_t)wave_max(mx);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
@@ -258,25 +266,13 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint
 #pragma unroll
         for (int r = 0; r < kKpt; ++r) sk[base + r] = v[r];
     }
-    // A round whose four index bits lie below bit 10 - be <= 6 - keeps every wave inside its own block of 1024 keys
-    // (64 lanes x 16 keys): between two such rounds the waves need not wait for each other, the LDS pipeline orders
-    // a wave's own reads behind its writes.  Only the top rounds of the last phases cross waves.
-    bool prev_local = true;  // the round above touched 16 consecutive keys per lane
+    __syncthreads();
     for (uint32_t p = kLogKpt + 1; p <= logm; ++p) {
         for (int jhi = (int)p - 1; jhi >= 0;) {
             const int nb = ((jhi + 1) & 3) ? ((jhi + 1) & 3) : 4;  // the rounds below this one take four stages each
             const int jlo = jhi - nb + 1;
             const uint32_t be = std::min<uint32_t>((uint32_t)jlo, logm - kLogKpt);  // register index = index bits [be, be+4)
             const int jr_hi = jhi - (int)be, jr_lo = jlo - (int)be;
-            const bool local = be <= 6 || nact <= 64;
-            if (prev_local && local) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            } else {
-                __syncthreads();
-            }
-            prev_local = local;
             if (tid < nact) {
                 const uint32_t p_rel = p - be;
                 const uint32_t dir_t = (p < logm && p_rel >= (uint32_t)kLogKpt) ? ((tid >> (p - kLogKpt)) & 1u) : 0u;
@@ -291,10 +287,10 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint
 #pragma unroll
                 for (int r = 0; r < kKpt; ++r) sk[padi(i0 | ((uint32_t)r << be))] = v[r];
             }
+            __syncthreads();
             jhi = jlo - 1;
         }
     }
-    __syncthreads();
     // keys -> tuples, in their final place
     const uint64_t mask_b = (1ull << L.bits_b) - 1ull, mask_a = (1ull << L.bits_a) - 1ull;  // widths 1..63
     uint4 *__restrict__ ov = reinterpret_cast<uint4 *>(out);
