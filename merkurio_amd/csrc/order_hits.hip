@@ -234,12 +234,14 @@ __device__ __forceinline__ void leaf_stage(uint64_t (&v)[kKpt], uint32_t dir_t, 
     }
 }
 
+// One launch serves the bins with min_cnt < tuples <= max_cnt (its geometry is sized for max_cnt): a batch whose
+// largest bin is just past a power of two does not make every bin pay for the larger workgroup.
 __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ bin_start,
-                                                                       mk_hit *__restrict__ out, const OrderKey L) {
+                                                                       mk_hit *__restrict__ out, const OrderKey L, uint32_t min_cnt, uint32_t max_cnt) {
     extern __shared__ uint64_t sk[];
     const uint32_t bin = blockIdx.x;
     const uint32_t lo = bin_start[bin], cnt = bin_start[bin + 1] - lo;
-    if (cnt == 0) return;  // workgroup-uniform
+    if (cnt <= min_cnt || cnt > max_cnt) return;  // workgroup-uniform (empty bins: min_cnt >= 0)
     const uint32_t tid = threadIdx.x, T = blockDim.x;
     uint32_t logm = cnt > 1 ? 32u - (uint32_t)__builtin_clz(cnt - 1) : 0u;
     if (logm < kLogKpt) logm = kLogKpt;
@@ -332,12 +334,21 @@ void launch_order_scatter_leaf(mk_hit *d_hits, uint64_t n, const OrderKey &L, co
                                hipStream_t st) {
     const int blocks = (int)std::min<uint64_t>((uint64_t)num_cus, (n + 4095) / 4096);
     hipLaunchKernelGGL(mk_order_scatter_kernel, dim3(blocks), dim3(kOrderThreads), L.n_bins * sizeof(uint32_t), st, d_hits, n, S.cursor, S.keys, L);
-    // leaf geometry from the largest bin: 16 keys per lane, 64..1024 lanes
-    uint32_t m = kKpt * 64;
-    while (m < max_bin) m <<= 1;
-    const uint32_t threads = m / kKpt;
-    const size_t lds = ((size_t)m + m / 16) * sizeof(uint64_t);
-    hipLaunchKernelGGL(mk_order_leaf_kernel, dim3(L.n_bins), dim3(threads), lds, st, S.keys, S.bin_start, d_hits, L);
+    // leaf geometry: 16 keys per lane, 64..1024 lanes.  Bins of up to 4096 tuples (the common size: ~2048-3000 on
+    // average) get 256-lane workgroups of their own launch; larger ones a second launch sized for the largest bin.
+    auto leaf = [&](uint32_t min_cnt, uint32_t max_cnt) {
+        uint32_t m = kKpt * 64;
+        while (m < max_cnt) m <<= 1;
+        const size_t lds = ((size_t)m + m / 16) * sizeof(uint64_t);
+        hipLaunchKernelGGL(mk_order_leaf_kernel, dim3(L.n_bins), dim3(m / kKpt), lds, st, S.keys, S.bin_start, d_hits, L, min_cnt, max_cnt);
+    };
+    constexpr uint32_t kSmall = 4096;
+    if (max_bin <= kSmall) {
+        leaf(0, max_bin);
+    } else {
+        leaf(0, kSmall);
+        leaf(kSmall, max_bin);
+    }
 }
 
 }  // namespace mk
