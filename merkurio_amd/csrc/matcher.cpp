@@ -591,7 +591,7 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
     uint32_t log_bins = 0;
     while (log_bins < 15 && ((uint64_t)2048 << log_bins) < n) ++log_bins;
     // scratch: stats | counts | starts | cursors | keys
-    const size_t head = 64 + (size_t)(3 * kOrderMaxBins + 16) * sizeof(uint32_t);
+    const size_t head = 64 + (size_t)(4 * kOrderMaxBins + 16) * sizeof(uint32_t);
     int rc = ensure(&m->d_sort_tmp, &m->d_sort_tmp_cap, head + n * sizeof(uint64_t));
     if (rc) return rc;
     OrderScratch S;
@@ -599,6 +599,7 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
     S.g_cnt = (uint32_t *)((char *)m->d_sort_tmp + 64);
     S.bin_start = S.g_cnt + kOrderMaxBins;
     S.cursor = S.bin_start + kOrderMaxBins + 8;
+    S.big_list = S.cursor + kOrderMaxBins;
     S.keys = (uint64_t *)((char *)m->d_sort_tmp + head);
     OrderKey L;
     memset(&L, 0, sizeof(L));
@@ -609,7 +610,7 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
     L.ac = ac_order ? 1 : 0;
     // first attempt: bins of 2^s consecutive records, s from the record count of the handle's last scan
     uint64_t rec_bound = m->last_n_rec ? m->last_n_rec : (1ull << 32);
-    unsigned long long stats[5] = {0, 0, 0, 0, 0};
+    unsigned long long stats[6] = {0, 0, 0, 0, 0, 0};
     uint32_t s = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         s = bits_of(rec_bound - 1) > log_bins ? bits_of(rec_bound - 1) - log_bins : 0;
@@ -661,7 +662,7 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
     }
     m->order_bins = L.n_bins;
     m->order_max_bin = (uint32_t)stats[3];
-    launch_order_scatter_leaf(hits, n, L, S, (uint32_t)stats[3], m->num_cus, st);
+    launch_order_scatter_leaf(hits, n, L, S, (uint32_t)stats[3], (uint32_t)stats[5], m->num_cus, st);
     MK_HIP(hipGetLastError());
     return MK_OK;
     MK_ABI_END

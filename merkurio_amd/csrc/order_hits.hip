@@ -124,8 +124,10 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_hist_kernel(const mk_h
 }
 
 // ---- bin starts (exclusive prefix sum over <= 32768 bins, one workgroup) and the largest bin -------------
+// (also lists the bins above kOrderLeafSmall tuples -- big_list, their number in stats[5] -- for the second leaf launch)
 __global__ __launch_bounds__(kOrderThreads) void mk_order_scan_kernel(const uint32_t *__restrict__ g_cnt, uint32_t n_bins, uint32_t *__restrict__ bin_start,
-                                                                       uint32_t *__restrict__ cursor, unsigned long long *__restrict__ stats) {
+                                                                       uint32_t *__restrict__ cursor, unsigned long long *__restrict__ stats,
+                                                                       uint32_t *__restrict__ big_list) {
     __shared__ uint32_t part[kOrderThreads / 64];
     __shared__ uint32_t wmax[kOrderThreads / 64];
     const uint32_t per = (n_bins + kOrderThreads - 1) / kOrderThreads;
@@ -154,9 +156,11 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_scan_kernel(const uint
     }
     uint32_t run = before + incl - sum;  // exclusive
     for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = g_cnt[i];
         bin_start[i] = run;
         cursor[i] = run;
-        run += g_cnt[i];
+        run += c;
+        if (c > kOrderLeafSmall) big_list[atomicAdd(&stats[5], 1ull)] = i;  // rare
     }
     if (threadIdx.x == 0) bin_start[n_bins] = total;
     mx = (uint32_t)wave_max(mx);
@@ -237,9 +241,10 @@ __device__ __forceinline__ void leaf_stage(uint64_t (&v)[kKpt], uint32_t dir_t, 
 // One launch serves the bins with min_cnt < tuples <= max_cnt (its geometry is sized for max_cnt): a batch whose
 // largest bin is just past a power of two does not make every bin pay for the larger workgroup.
 __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ bin_start,
-                                                                       mk_hit *__restrict__ out, const OrderKey L, uint32_t min_cnt, uint32_t max_cnt) {
+                                                                       mk_hit *__restrict__ out, const OrderKey L, uint32_t min_cnt, uint32_t max_cnt,
+                                                                       const uint32_t *__restrict__ bin_list) {
     extern __shared__ uint64_t sk[];
-    const uint32_t bin = blockIdx.x;
+    const uint32_t bin = bin_list ? bin_list[blockIdx.x] : blockIdx.x;
     const uint32_t lo = bin_start[bin], cnt = bin_start[bin + 1] - lo;
     if (cnt <= min_cnt || cnt > max_cnt) return;  // workgroup-uniform (empty bins: min_cnt >= 0)
     const uint32_t tid = threadIdx.x, T = blockDim.x;
@@ -327,27 +332,26 @@ hipError_t order_kernels_prepare() {
 void launch_order_hist(const mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, int num_cus, hipStream_t st) {
     const int blocks = (int)std::min<uint64_t>((uint64_t)num_cus, (n + 4095) / 4096);
     hipLaunchKernelGGL(mk_order_hist_kernel, dim3(blocks), dim3(kOrderThreads), L.n_bins * sizeof(uint32_t), st, d_hits, n, S.g_cnt, S.stats, L);
-    hipLaunchKernelGGL(mk_order_scan_kernel, dim3(1), dim3(kOrderThreads), 0, st, S.g_cnt, L.n_bins, S.bin_start, S.cursor, S.stats);
+    hipLaunchKernelGGL(mk_order_scan_kernel, dim3(1), dim3(kOrderThreads), 0, st, S.g_cnt, L.n_bins, S.bin_start, S.cursor, S.stats, S.big_list);
 }
 
-void launch_order_scatter_leaf(mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, uint32_t max_bin, int num_cus,
-                               hipStream_t st) {
+void launch_order_scatter_leaf(mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, uint32_t max_bin, uint32_t n_big,
+                               int num_cus, hipStream_t st) {
     const int blocks = (int)std::min<uint64_t>((uint64_t)num_cus, (n + 4095) / 4096);
     hipLaunchKernelGGL(mk_order_scatter_kernel, dim3(blocks), dim3(kOrderThreads), L.n_bins * sizeof(uint32_t), st, d_hits, n, S.cursor, S.keys, L);
     // leaf geometry: 16 keys per lane, 64..1024 lanes.  Bins of up to 4096 tuples (the common size: ~2048-3000 on
     // average) get 256-lane workgroups of their own launch; larger ones a second launch sized for the largest bin.
-    auto leaf = [&](uint32_t min_cnt, uint32_t max_cnt) {
+    auto leaf = [&](uint32_t min_cnt, uint32_t max_cnt, uint32_t grid, const uint32_t *bin_list) {
         uint32_t m = kKpt * 64;
         while (m < max_cnt) m <<= 1;
         const size_t lds = ((size_t)m + m / 16) * sizeof(uint64_t);
-        hipLaunchKernelGGL(mk_order_leaf_kernel, dim3(L.n_bins), dim3(m / kKpt), lds, st, S.keys, S.bin_start, d_hits, L, min_cnt, max_cnt);
+        hipLaunchKernelGGL(mk_order_leaf_kernel, dim3(grid), dim3(m / kKpt), lds, st, S.keys, S.bin_start, d_hits, L, min_cnt, max_cnt, bin_list);
     };
-    constexpr uint32_t kSmall = 4096;
-    if (max_bin <= kSmall) {
-        leaf(0, max_bin);
+    if (max_bin <= kOrderLeafSmall) {
+        leaf(0, max_bin, L.n_bins, nullptr);
     } else {
-        leaf(0, kSmall);
-        leaf(kSmall, max_bin);
+        leaf(0, kOrderLeafSmall, L.n_bins, nullptr);
+        if (n_big) leaf(kOrderLeafSmall, max_bin, n_big, S.big_list);  // one workgroup per listed bin
     }
 }
 

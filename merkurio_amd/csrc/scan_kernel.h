@@ -99,19 +99,21 @@ struct OrderKey {
     uint32_t n_bins;          // <= kOrderMaxBins
 };
 struct OrderScratch {
-    unsigned long long *stats;  // [0..2] maxima of record, A, B; [3] largest bin; [4] ~(smallest record)
+    unsigned long long *stats;  // [0..2] maxima of record, A, B; [3] largest bin; [4] ~(smallest record); [5] bins above kOrderLeafSmall
     uint32_t *g_cnt;            // n_bins
     uint32_t *bin_start;        // n_bins + 1
     uint32_t *cursor;           // n_bins
+    uint32_t *big_list;         // n_bins: the bins above kOrderLeafSmall tuples
     uint64_t *keys;             // n
 };
 constexpr uint32_t kOrderMaxBins = 32768;  // LDS histogram: 128 KiB of u32 bins
 constexpr uint32_t kOrderLeafMax = 16384;  // keys one workgroup sorts in LDS (136 KiB with padding)
+constexpr uint32_t kOrderLeafSmall = 4096;  // bins up to this size share a launch of 256-lane workgroups; larger ones get their own
 // zeroes nothing: the caller clears stats and g_cnt first.  Enqueues the histogram and the bin-start scan.
 void launch_order_hist(const mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, int num_cus, hipStream_t st);
 // scatter into bins + one LDS sort per bin; the sorted tuples replace d_hits[0, n)
-void launch_order_scatter_leaf(mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, uint32_t max_bin, int num_cus,
-                               hipStream_t st);
+void launch_order_scatter_leaf(mk_hit *d_hits, uint64_t n, const OrderKey &L, const OrderScratch &S, uint32_t max_bin, uint32_t n_big,
+                               int num_cus, hipStream_t st);
 // the kernels above use more than 64 KiB of dynamic LDS: raises their limit once per process
 hipError_t order_kernels_prepare();
 // library fallback (rocPRIM merge sort with the reference's comparator): tmp == nullptr only sets *tmp_bytes
