@@ -222,7 +222,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
 int mk_matcher_check_device(mk_matcher *m, void *stream);
 
 /* Performance hint for mk_scan_device (never changes results): how many of 1000 records the caller
- * expects to contain a pattern.  Dense text (>= 120) is streamed with cacheable loads, because the
+ * expects to contain a pattern.  Dense text (>= 145, or >= 95 when tuples are written) is streamed with cacheable loads, because the
  * exact verification re-reads every hit window; sparse text with non-temporal loads.  mk_scan_batch
  * and the driver-loop entry points maintain the value themselves from the batch they have just scanned. */
 int mk_matcher_hint_hit_density(mk_matcher *m, uint32_t records_hit_per_1000);

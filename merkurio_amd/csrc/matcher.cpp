@@ -438,8 +438,10 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     // level 3 itself uses 16-byte loads, and flags are stored directly.  Every read hitting: 9.1 -> 6.0 ms
     // per 15 GB.  Everything else: non-temporal stream (16 % faster without hits), 8-byte compare loads,
     // flagged records listed per wave and their bytes set by a small kernel afterwards.  The flavours cross
-    // at 12 % of the records (profiles/r02_crossover2.txt).
-    constexpr uint32_t kDensePerMille = 120;
+    // at 10 % (tuples) / 14 % (flags only) of the records (profiles/r03_crossover.txt; r02: 12 %).
+    // r03 (dense flavour probing / resolving early, profiles/r03_crossover.txt): flags only 1 in 8 records sparse 3.24 vs
+    // dense 3.32 ms, 1 in 6 3.68 vs 3.44; with tuples 1 in 12 3.29 vs 3.39, 1 in 10 3.49 vs 3.43
+    const uint32_t kDensePerMille = mode == MK_MODE_HITS ? 95 : 145;
     const bool plain_loads = m->hit_density_pm >= kDensePerMille;
     // (r03: a third flavour -- the sparse kernel with 16-byte compare loads as its own instantiation, for 2-12 % of
     // the records hitting -- gained nothing at any density: profiles/r03_cmp16_mid.txt)

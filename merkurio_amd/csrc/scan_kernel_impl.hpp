@@ -406,6 +406,17 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 #ifndef MK_ISSUE_AT
 #define MK_ISSUE_AT 56  // ring fill at which a group ends with an asynchronous level-2 probe
 #endif
+// hit-dense flavour (FL == 0): level 3 re-reads the occurrence's text, which the wave streamed a while ago -- by then
+// ~80 MB have passed through the chip and the line comes back from the Infinity Cache (66 G random lines/s) instead of
+// the XCD's L2.  Probing from 16 queued candidates and resolving from 16 queued q-gram hits (instead of 56 / a full
+// buffer of 64) halves that distance: every read hitting 5.94 -> 5.43 ms, a third of them 4.0 -> 3.8
+// (profiles/r03_dense_drain_ab.txt; 8 / 8 and flushing the parked candidates every group gain nothing more).
+#ifndef MK_ISSUE_AT_DENSE
+#define MK_ISSUE_AT_DENSE 16
+#endif
+#ifndef MK_DRAIN_AT_DENSE
+#define MK_DRAIN_AT_DENSE 16  // q-gram hits waiting at the end of a group from which they are resolved (65 = only when full)
+#endif
 
 // Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
 // sizes that matter get their own kernels: no runtime masks, no unused halo words);
@@ -841,8 +852,11 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                         q_head = (q_head + q_count) & (kRingEntries - 1);
                         q_count = 0;
                     }
-                } else if (!pend_on && q_count >= MK_ISSUE_AT) {
+                } else if (!pend_on && q_count >= (FL == 0 ? MK_ISSUE_AT_DENSE : MK_ISSUE_AT)) {
                     issue_probe(q_count < 64 ? q_count : 64);
+                }
+                if constexpr (FL == 0 && MK_DRAIN_AT_DENSE <= 64) {
+                    if (hr.count >= MK_DRAIN_AT_DENSE) drain_hits<EMIT, FL>(P, hr, newest_end, lane, n_true);
                 }
                 pk_prev = p3;
             }
