@@ -410,7 +410,8 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 // ~80 MB have passed through the chip and the line comes back from the Infinity Cache (66 G random lines/s) instead of
 // the XCD's L2.  Probing from 16 queued candidates and resolving from 16 queued q-gram hits (instead of 56 / a full
 // buffer of 64) halves that distance: every read hitting 5.94 -> 5.43 ms, a third of them 4.0 -> 3.8
-// (profiles/r03_dense_drain_ab.txt; 8 / 8 and flushing the parked candidates every group gain nothing more).
+// (profiles/r03_dense_drain_ab.txt; 8 / 8 and flushing the parked candidates every group gain nothing more; in the
+// sparse flavour, whose non-temporal stream is in no cache anyway, 16 / 16 costs 3-6 %).
 #ifndef MK_ISSUE_AT_DENSE
 #define MK_ISSUE_AT_DENSE 16
 #endif
