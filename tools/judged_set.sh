@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: the judged set in one call, on one box and one build -- full GPU suite, default bench line (headline +
+# the judged set of a round in one call (round 3: profiles/r03_*), on one box and one build -- full GPU suite, default bench line (headline +
 # other_configs), rocprofv3 kernel trace + PMC passes of the headline and of the config-5 shard, ordering timings and
 # their per-kernel split, hits-mode lines, hit-rate sweep, dense driver-loop timing
 cd "$(dirname "$0")/.."
