@@ -148,6 +148,9 @@ def _compile_lib(out_path, extra_flags, obj_dir, force, verbose):
     if jobs:
         with ThreadPoolExecutor(max(1, JOBS)) as ex:
             list(ex.map(run, jobs))
+    for f in os.listdir(obj_dir):  # objects of translation units that no longer exist
+        if (f.endswith(".o") or f.endswith(".isa.txt")) and os.path.join(obj_dir, f.replace(".isa.txt", "")) not in objs:
+            os.remove(os.path.join(obj_dir, f))
     isa_resources(obj_dir, os.path.join(os.path.dirname(out_path), "isa_resources" + os.path.basename(out_path)[len("libmerkurio_hip"):-3] + ".txt"),
                   strict=not extra_flags)
     if jobs or force or _stale(out_path, objs):
