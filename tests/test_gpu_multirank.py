@@ -206,3 +206,62 @@ def test_bench_starts_its_own_ranks_and_strong_scaling_is_the_same_job():
     weak = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "1000000", "--patterns", "2000")
     assert weak["scaling"] == "weak" and weak["config"]["records_total"] == 2000000
     assert [weak["summary"][k] for k in keys] == [one["summary"][k] for k in keys]
+
+
+def _agree_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from merkurio_amd import native as mk
+    from merkurio_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_dev = torch.cuda.device_count()
+        dev = rank % n_dev
+        torch.cuda.set_device(dev)
+        lib = mk.load()
+        m = mk.Matcher([b"ACGTACGTACGTACGTACGTA", b"TTTTTTTTTTTTTTTTTTTTT"], device=dev)
+        ok, why = sharding.agree_on_communicator(lib, m.handle, rank, world, "cpu")
+        total = None
+        if ok:  # one GPU per rank: the in-place RCCL all-reduce of the counter vector through the C ABI
+            n = len(m.patterns) + mk.MK_NUM_SUMMARY
+            t = torch.full((n,), rank + 1, dtype=torch.int64, device=torch.device("cuda", dev))
+            st = torch.cuda.current_stream().cuda_stream
+            assert lib.mk_comm_reduce_counters(m.handle, t.data_ptr(), n, st) == 0, lib.mk_last_error()
+            torch.cuda.synchronize()
+            total = t.cpu().tolist()
+            assert lib.mk_comm_destroy(m.handle) == 0
+        json.dump({"ok": ok, "why": why, "n_dev": n_dev, "total": total}, open(os.path.join(out_dir, f"agree{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_set_up_the_rccl_communicator_or_fall_back_together(tmp_path):
+    """bench.py's protocol (sharding.agree_on_communicator) with the REAL library, two ranks: with one GPU per rank the
+    C ABI's RCCL communicator comes up and mk_comm_reduce_counters sums the vectors; on a 1-GPU box RCCL refuses two
+    ranks on one device -- then BOTH ranks must come back with the same refusal (the job falls back to
+    torch.distributed), none may be left waiting in the collective init"""
+    pytest.importorskip("torch")
+    import time
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False)
+    deadline = time.time() + 240
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("a rank is still waiting inside the communicator set-up after 240 s")
+    r0, r1 = (json.load(open(tmp_path / f"agree{r}.json")) for r in (0, 1))
+    assert r0["ok"] == r1["ok"] and r0["why"] == r1["why"], (r0, r1)
+    if r0["n_dev"] >= 2:
+        assert r0["ok"], r0
+        assert r0["total"] == r1["total"] and set(r0["total"]) == {3}
+    else:
+        assert not r0["ok"] and r0["why"], r0
