@@ -512,6 +512,46 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
         mk._check(lib.mk_synth_reads_device_range(m.handle, seed + 7, 0, n_rec, L, plant_every, d_seq.data_ptr(), d_off.data_ptr(), st))
         return m, d_seq, d_off, d_flags, len(pats)
 
+    # config 3, one GPU's shard of the 8-GPU job: 2 x 6.25 M x 150 bp mates, 10 k 31-mers (the headline's matcher); a pair
+    # is kept if either mate hits (src/cmd_extract.rs:600-606)
+    n3 = 6_250_000
+    pair = []
+    for f in range(2):
+        d_seq = torch.empty(n3 * L0 + 64, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n3 + 1, dtype=torch.int64, device=dev)
+        d_flags = torch.empty((n3 + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        mk._check(lib.mk_synth_reads_device_range(m0.handle, seed + 20 + f, 0, n3, L0, 100, d_seq.data_ptr(), d_off.data_ptr(), st))
+        pair.append((d_seq, d_off, d_flags))
+    d_keep = torch.empty_like(pair[0][2])
+    d_nh3 = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_cnt3 = torch.zeros(len(m0.patterns) + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+    mk._check(lib.mk_matcher_set_fixed_record_length(m0.handle, L0))
+    mk._check(lib.mk_matcher_hint_hit_density(m0.handle, 10))
+
+    def step3():
+        for d_seq, d_off, d_flags in pair:
+            mk._check(lib.mk_scan_device(m0.handle, d_seq.data_ptr(), n3 * L0, d_off.data_ptr(), n3, mk.MK_MODE_ANY, d_flags.data_ptr(), None, 0,
+                                         d_nh3.data_ptr(), d_cnt3.data_ptr(), st))
+        torch.bitwise_or(pair[0][2], pair[1][2], out=d_keep)
+
+    for _ in range(warmup):
+        step3()
+    torch.cuda.synchronize()
+    m0.enable_timing(2 * steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step3()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms = float(np.mean(m0.kernel_times_ms()))
+    algo = n3 * L0 + 9 * n3
+    res.append({"workload": f"config 3, one GPU's shard: extract paired, 2 x {n3} x {L0} bp mates, {len(m0.patterns)} 31-mers, any-hit flags, pair kept if either mate hits",
+                "kernel": m0.kernel_name, "steps": steps, "launches_per_step": 2, "ms_per_step": round(dt / steps * 1e3, 4),
+                "value_gbases_per_s": round(2 * n3 * L0 * steps / dt / 1e9, 1), "kernel_ms": round(k_ms, 4),
+                "algorithmic_bytes_per_launch": algo, "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pairs_kept": int(d_keep[:n3].sum().item())})
+    del pair, d_keep
+
     m, a, b, c, n_pat = fresh(10_000_000, 150, 1024, 31, True, 100, 11)
     run(f"config 2 shape: extract, 10 M x 150 bp, 1 024 31-mers + RC ({n_pat} patterns), any-hit flags", m, a, b, c, 10_000_000, 150, n_pat, False, 100)
     del m, a, b, c
