@@ -429,6 +429,8 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()
+        if reduce_via.startswith("mk_comm"):  # every rank is past its last collective: drop the C ABI's communicator now,
+            lib.mk_comm_destroy(m.handle)     # not at interpreter exit
         dist.destroy_process_group()
 
 
