@@ -115,6 +115,35 @@ static void open_loggers(const CommonArgs &a, Loggers &lg) {
     lg.active = a.out_log || a.json_log;
 }
 
+// The log rows of a batch (reference emission order), formatted by the host threads -- a batch in which every read
+// hits carries millions of rows, and one thread building them took four times the rest of the run -- and written
+// in order.  id_of(row) -> the record id's bytes; file_of(row) -> the file name to log.
+template <class IdOf, class FileOf>
+static void emit_log_rows(Loggers &lg, const Patterns &pats, const mk_row *rows, uint64_t n_rows, IdOf id_of, FileOf file_of) {
+    if (!lg.active || n_rows == 0) return;
+    const bool text = lg.text.out != nullptr, json = lg.has_json;
+    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), n_rows / 2048));
+    std::vector<std::string> tb(T), jb(T);
+    const bool first_row_of_log = json && lg.json.first;
+    run_threads(T, [&](size_t t) {
+        const uint64_t lo = n_rows * t / T, hi = n_rows * (t + 1) / T;
+        if (text) tb[t].reserve((hi - lo) * 96);
+        if (json) jb[t].reserve((hi - lo) * 176);
+        for (uint64_t k = lo; k < hi; ++k) {
+            const mk_row &r = rows[k];
+            const std::pair<const char *, size_t> id = id_of(r);
+            const std::string &file = file_of(r);
+            if (text) TextLogger::format(tb[t], file, id.first, id.second, pats.list[r.pat], r.pos);
+            if (json) JsonLogger::format(jb[t], !(first_row_of_log && k == 0), file, id.first, id.second, pats.list[r.pat], r.pos);
+        }
+    });
+    for (size_t t = 0; t < T; ++t) {
+        if (text) lg.text.out->write(tb[t]);
+        if (json) lg.json.out->write(jb[t]);
+    }
+    if (json) lg.json.first = false;
+}
+
 // ---- --gpus N: one matcher handle + one host thread per device, contiguous record ranges ---------
 // [lo, hi) of shard d of n units over `parts` shards, sizes differing by at most one (the same
 // rule as merkurio_amd/sharding.py): concatenating shard outputs in device order reproduces the
@@ -331,13 +360,14 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     const uint64_t batch_bytes = (uint64_t)a.batch_mb << 20;
     // what a batch's results turn into: log rows (reference emission order) and the kept records
     auto emit_rows = [&](size_t b0, const mk_row *rows, uint64_t n_rows) {
-        for (uint64_t k = 0; k < n_rows; ++k) {
-            const mk_row &r = rows[k];
-            const FastxFile &ff = r.file ? f2 : f1;
-            const std::string id = ff.id(b0 + r.rec);
-            lg.text.row(r.file ? name2 : name1, id, pats.list[r.pat], r.pos);
-            if (lg.has_json) lg.json.row(r.file ? name2 : name1, id, pats.list[r.pat], r.pos);
-        }
+        emit_log_rows(
+            lg, pats, rows, n_rows,
+            [&](const mk_row &r) {
+                const FastxFile &ff = r.file ? f2 : f1;
+                const auto &rec = ff.recs[b0 + r.rec];
+                return std::pair<const char *, size_t>(ff.data + rec.id_b, rec.id_e - rec.id_b);
+            },
+            [&](const mk_row &r) -> const std::string & { return r.file ? name2 : name1; });
     };
     auto emit_records = [&](size_t b0, const uint8_t *keep, uint64_t nb) {
         if (a.suppress_output) return;
@@ -612,11 +642,13 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     };
     auto emit = [&](const BatchOut &o) {
         if (lg.active)
-            for (const mk_row &r : o.rows) {
-                const std::string name = sam.name(r.rec);
-                lg.text.row(in_name, name, pats.list[r.pat], r.pos);
-                if (lg.has_json) lg.json.row(in_name, name, pats.list[r.pat], r.pos);
-            }
+            emit_log_rows(
+                lg, pats, o.rows.data(), o.rows.size(),
+                [&](const mk_row &r) {
+                    const auto &rec = sam.recs[r.rec];
+                    return std::pair<const char *, size_t>(sam.data + rec.off + (sam.is_bam ? 36 : 0), rec.name_len);
+                },
+                [&](const mk_row &) -> const std::string & { return in_name; });
         for (auto &b : o.bin) bw.put_encoded(b);
         for (auto &t : o.txt) w.write(t);
     };

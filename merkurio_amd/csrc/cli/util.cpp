@@ -193,38 +193,59 @@ void Sink::flush() {
     if (f) fflush(f);
 }
 
-void TextLogger::row(const std::string &file, const std::string &id, const std::string &pattern, uint64_t pos) {
-    if (!out) return;  // src/logger.rs:48-55
-    std::string &b = out->buf;
-    b += file;
+static void append_u64(std::string &b, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) b += tmp[--n];
+}
+
+void TextLogger::format(std::string &b, const std::string &file, const char *id, size_t id_len, const std::string &pattern, uint64_t pos) {
+    b += file;  // src/logger.rs:48-55
     b += '\t';
-    b += id;
+    b.append(id, id_len);
     b += '\t';
     b += pattern;
     b += '\t';
-    b += std::to_string(pos);
+    append_u64(b, pos);
     b += '\n';
-    if (b.size() >= (1u << 20)) out->flush();
+}
+
+void TextLogger::row(const std::string &file, const std::string &id, const std::string &pattern, uint64_t pos) {
+    if (!out) return;
+    format(out->buf, file, id.data(), id.size(), pattern, pos);
+    if (out->buf.size() >= (1u << 20)) out->flush();
 }
 
 void JsonLogger::begin() { out->write("{\n  \"matching_records\": [\n"); }  // src/logger.rs:97
 
+static void json_escape_raw(const char *p, size_t n, std::string &out) { json_escape(std::string(p, n), out); }
+
+// One hit as the reference writes it: serde_json's pretty object (keys in alphabetical order, position a STRING:
+// src/logger.rs:116-121) re-indented by four spaces (src/logger.rs:123-128), rows separated by a line holding a comma
+// (src/logger.rs:111-113).  Written out directly -- the generic Json value + pretty printer took a microsecond per row.
+void JsonLogger::format(std::string &b, bool separator, const std::string &file, const char *id, size_t id_len, const std::string &pattern,
+                        uint64_t pos) {
+    if (separator) b += ",\n";
+    b += "    {\n      \"file\": ";
+    json_escape(file, b);
+    b += ",\n      \"pattern\": ";
+    json_escape(pattern, b);
+    b += ",\n      \"position\": \"";
+    append_u64(b, pos);
+    b += "\",\n      \"record_id\": ";
+    json_escape_raw(id, id_len, b);
+    b += "\n    }\n";
+}
+
 void JsonLogger::row(const std::string &file, const std::string &id, const std::string &pattern, uint64_t pos) {
-    if (!first) out->write(",\n");  // src/logger.rs:111-113
+    std::string b;
+    format(b, !first, file, id.data(), id.size(), pattern, pos);
     first = false;
-    Json v = Json::object();
-    v.set("file", Json::string(file)).set("record_id", Json::string(id)).set("pattern", Json::string(pattern));
-    v.set("position", Json::string(std::to_string(pos)));  // position is a STRING (src/logger.rs:120)
-    const std::string pretty = json_pretty(v);
-    size_t b = 0;
-    while (b < pretty.size()) {  // re-indent by 4 (src/logger.rs:123-128)
-        size_t e = pretty.find('\n', b);
-        if (e == std::string::npos) e = pretty.size();
-        out->write("    ");
-        out->write(pretty.data() + b, e - b);
-        out->write("\n");
-        b = e + 1;
-    }
+    out->write(b);
 }
 
 static void write_indented(Sink &s, const Json &v, int indent) {  // src/logger.rs:145-155 (+ pop of the last '\n')

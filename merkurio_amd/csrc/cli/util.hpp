@@ -70,6 +70,8 @@ struct TextLogger {
     std::unique_ptr<Sink> out;  // null: no text log
     void header(const std::string &s) { if (out) { out->write(s); } }
     void row(const std::string &file, const std::string &id, const std::string &pattern, uint64_t pos);
+    // the bytes row() writes, appended to b (rows of a batch are formatted by several host threads, then written in order)
+    static void format(std::string &b, const std::string &file, const char *id, size_t id_len, const std::string &pattern, uint64_t pos);
     void flush() { if (out) out->flush(); }
 };
 
@@ -79,6 +81,9 @@ struct JsonLogger {
     bool first = true;
     void begin();  // writes `{\n  "matching_records": [\n`
     void row(const std::string &file, const std::string &id, const std::string &pattern, uint64_t pos);
+    // the bytes row() writes (with the separator line in front unless it is the log's first row), appended to b
+    static void format(std::string &b, bool separator, const std::string &file, const char *id, size_t id_len, const std::string &pattern,
+                       uint64_t pos);
     void finalize(const Json &meta, const Json &pattern_hit_counts, const Json &summary, const Json *paired);
 };
 

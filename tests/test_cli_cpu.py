@@ -284,3 +284,27 @@ def test_windowed_sam_bam_reader(tmp_path, golden):
     want = [f"read{i}\t{s.upper()}\t" + ("1:OLD,VAL" if i % 97 == 0 else "0:") for i, s in enumerate(seqs)]
     assert ref["x.sam"] == want and ref["b.bam"] == want and ref["g.bam"] == want and ref["u.bam"] == want
     assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16)
+
+
+def test_log_rows_are_formatted_like_serde_json(tmp_path):
+    """the CLI writes a hit's text row and its pretty JSON object directly (several host threads format the rows of a
+    batch): the bytes must be what serde_json's pretty printer + the reference's re-indentation produce
+    (src/logger.rs:41-60,108-133) -- checked against Python's json module for ids with quotes, backslashes, control
+    characters, tabs and non-ASCII text"""
+    import json
+    cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
+    exe = str(tmp_path / "lr")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I", cli_dir, "-o", exe, os.path.join(ROOT, "tests/helpers/logrow_harness.cpp"),
+                    os.path.join(cli_dir, "util.cpp"), "-lz", "-ldl", "-lpthread"], check=True)
+    rows = [("reads.fastq", "r1 desc", "ACGT", 0), ("a \"quoted\" name.fq", "id\\with\\backslashes", "ACGTN", 4294967295),
+            ("f.fa", "tab\there\x01\x1c ctrl", "acgt", 17), ("ünïcödé.fastq", "日本語 id", "ACGT" * 20, 18446744073709551615),
+            ("f", "", "A", 7)]
+    (tmp_path / "in").write_bytes("\x1e".join("\x1f".join([f, i, p, str(pos)]) for f, i, p, pos in rows).encode())
+    out = subprocess.run([exe, str(tmp_path / "in")], capture_output=True, check=True).stdout
+    text, js = out.split(b"\x1d")
+    assert text.decode() == "".join(f"{f}\t{i}\t{p}\t{pos}\n" for f, i, p, pos in rows)
+    want = []
+    for f, i, p, pos in rows:
+        pretty = json.dumps({"file": f, "record_id": i, "pattern": p, "position": str(pos)}, indent=2, sort_keys=True, ensure_ascii=False)
+        want.append("".join("    " + line + "\n" for line in pretty.split("\n")))
+    assert js.decode() == ",\n".join(want)
