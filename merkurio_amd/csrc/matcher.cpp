@@ -618,6 +618,8 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
         s = bits_of(rec_bound - 1) > log_bins ? bits_of(rec_bound - 1) - log_bins : 0;
         L.bits_a = 0;
         L.bits_b = 1;
+        L.b_hi = 0;
+        L.b_lo = 63;  // (histogram on the record alone: B >> b_lo must vanish whatever B is)
         L.shift = s;
         L.n_bins = 1u << log_bins;
         MK_HIP(hipMemsetAsync(m->d_sort_tmp, 0, 64 + (size_t)L.n_bins * sizeof(uint32_t), st));
@@ -642,15 +644,30 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
     if (s + bits_a > 63) return order_library(m, hits, n, ac_order, st);  // (cannot happen below 2^31 records)
     L.bits_a = bits_a;
     L.bits_b = bits_b;
+    L.b_hi = 0;
+    L.b_lo = bits_b;
     m->order_path = 1;
     if (stats[3] > kOrderLeafMax || (stats[0] >> s) >= L.n_bins) {
         // a bin overflows its LDS sort (few huge records, or hits clustered in one stretch of the batch): bin on the
         // top bits of (record, A) instead, with as many bins as the histogram kernel can hold
         L.rec_base = ~stats[4];  // the smallest record: the bins span the records that occur, not [0, largest]
         bits_rec = bits_of(stats[0] - L.rec_base);
-        const uint32_t total = bits_rec + bits_a;
-        const uint32_t lb = std::min(15u, log_bins + 3);  // ~256 tuples per bin on average: room for skew
-        L.shift = total > lb ? total - lb : 0;
+        // the bins are the top bits of the whole (record, A, B) triple: a bin whose keys share all but 14 bits cannot
+        // overflow, whatever the distribution
+        const uint32_t total = bits_rec + bits_a + bits_b;
+        // ~256 tuples per bin on average (room for skew), and where the triple is short enough, so many bins that only
+        // 14 bits stay in the key: such a bin cannot hold more than 2^14 distinct tuples
+        const uint32_t lb = std::min(15u, std::max(log_bins + 3, total > 14 ? total - 14 : 0u));
+        const uint32_t drop = total > lb ? total - lb : 0;  // low bits of the triple that stay in the key
+        if (drop >= bits_b) {
+            L.b_hi = 0;
+            L.b_lo = bits_b;
+            L.shift = drop - bits_b;
+        } else {
+            L.b_hi = bits_b - drop;
+            L.b_lo = drop;
+            L.shift = 0;
+        }
         L.n_bins = 1u << std::min(lb, total);
         MK_HIP(hipMemsetAsync(m->d_sort_tmp, 0, 64 + (size_t)L.n_bins * sizeof(uint32_t), st));
         launch_order_hist(hits, n, L, S, m->num_cus, st);

@@ -16,7 +16,9 @@
 //              ascending) order (identity for a k-mer set: all lengths equal) -- "longer pattern first,
 //              then pattern id" at one end IS that rank;
 //       BNDMq: A = pattern, B = pos;
-//   G = (record - base) << bits(A) | A;  bin = G >> shift;  key = (G mod 2^shift) << bits(B) | B   (8 bytes).
+//   G = (record - base) << bits(A) | A;  bin = G >> shift;  key = (G mod 2^shift) << bits(B) | B   (8 bytes)
+//   (second attempt on skewed batches: the bins are the top bits of the WHOLE triple -- with shift = 0 the top b_hi
+//   bits of B go into the bin index as well, key = the low bits of B).
 //
 //   1. mk_order_hist_kernel     reads the tuples once: tuples per bin (LDS histogram per workgroup, one
 //                               global atomic per non-empty bin) and the maxima of record, A and B;
@@ -35,7 +37,8 @@
 //
 // Bins are 2^k consecutive records with ~2048 tuples on average and at most 16384 (128 KiB of keys in
 // LDS).  Skew: when a bin overflows (few huge records: a genome FASTA; hits clustered in one stretch of
-// the batch) the histogram is taken again on the top bits of (record, A) instead of the record alone;
+// the batch; one pattern all over one chromosome) the histogram is taken again on the top bits of the whole
+// (record, A, B) triple instead of the record alone;
 // if that overflows too, or the three fields do not fit 64 bits, the caller falls back to the library
 // merge sort (order_hits_fallback.hip) -- correctness never depends on the distribution.
 #include <hip/hip_runtime.h>
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_hist_kernel(const mk_h
         ma = a > ma ? a : ma;
         mb = b > mb ? b : mb;
         const uint64_t g = L.bits_a ? ((rec << L.bits_a) | a) : rec;
-        const uint64_t d = g >> L.shift;
+        const uint64_t d = ((g >> L.shift) << L.b_hi) | (b >> L.b_lo);  // b_hi == 0: b_lo >= the width of B, the second term is 0
         atomicAdd(&lds_cnt[d < L.n_bins ? (uint32_t)d : L.n_bins - 1], 1u);
     }
     mr = wave_max(mr);
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_scatter_kernel(const m
     __syncthreads();
     const uint4 *__restrict__ hv = reinterpret_cast<const uint4 *>(hits);
     const uint64_t low_mask = (1ull << L.shift) - 1ull;  // shift <= 63
+    const uint64_t b_lo_mask = (1ull << L.b_lo) - 1ull;  // b_lo = bits of B kept in the key (<= 63)
     constexpr uint64_t kTile = (uint64_t)kOrderThreads * kScatterPer;
     for (uint64_t base = (uint64_t)blockIdx.x * kTile; base < n; base += (uint64_t)gridDim.x * kTile) {
         uint64_t key[kScatterPer];
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_scatter_kernel(const m
                 uint64_t rec, a, b;
                 tuple_fields(L, hv[i], rec, a, b);
                 const uint64_t g = ((rec - L.rec_base) << L.bits_a) | a;
-                const uint64_t d = g >> L.shift;
+                const uint64_t d = ((g >> L.shift) << L.b_hi) | (b >> L.b_lo);
                 bin[k] = d < L.n_bins ? (uint32_t)d : L.n_bins - 1;
-                key[k] = ((g & low_mask) << L.bits_b) | b;
+                key[k] = ((g & low_mask) << L.b_lo) | (b & b_lo_mask);
                 rk[k] = atomicAdd(&lds_cnt[bin[k]], 1u);  // rank inside (tile, bin)
             }
         }
@@ -299,12 +303,13 @@ __global__ __launch_bounds__(kOrderThreads) void mk_order_leaf_kernel(const uint
         }
     }
     // keys -> tuples, in their final place
-    const uint64_t mask_b = (1ull << L.bits_b) - 1ull, mask_a = (1ull << L.bits_a) - 1ull;  // widths 1..63
+    const uint64_t mask_blo = (1ull << L.b_lo) - 1ull, mask_a = (1ull << L.bits_a) - 1ull;  // widths <= 63
+    const uint64_t bin_g = (uint64_t)bin >> L.b_hi, bin_b = (uint64_t)bin & ((1ull << L.b_hi) - 1ull);
     uint4 *__restrict__ ov = reinterpret_cast<uint4 *>(out);
     for (uint32_t i = tid; i < cnt; i += T) {
         const uint64_t k = sk[padi(i)];
-        const uint64_t g = ((uint64_t)bin << L.shift) | (k >> L.bits_b);
-        const uint64_t b = k & mask_b, a = g & mask_a, rec = (g >> L.bits_a) + L.rec_base;
+        const uint64_t g = (bin_g << L.shift) | (k >> L.b_lo);
+        const uint64_t b = (bin_b << L.b_lo) | (k & mask_blo), a = g & mask_a, rec = (g >> L.bits_a) + L.rec_base;
         uint32_t pat, pos;
         if (L.ac) {
             pat = L.unrank ? L.unrank[(uint32_t)b] : (uint32_t)b;

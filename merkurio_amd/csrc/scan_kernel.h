@@ -85,7 +85,8 @@ void launch_flag_scatter(const uint32_t *flag_list, const uint32_t *flag_counts,
 void launch_rec_index(const uint64_t *rec_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *rec_index, hipStream_t stream);
 // ---- emission order (order_hits.hip: hand-written bin + LDS-sort kernels; order_hits_fallback.hip: library sort) ----
 // How a tuple maps to its sort key (see order_hits.hip): fields (record, A, B); G = record << bits_a | A;
-// bin = G >> shift; 8-byte key = (G mod 2^shift) << bits_b | B.
+// bin = G >> shift; 8-byte key = (G mod 2^shift) << bits_b | B (or, binning on the whole triple: shift 0, the top
+// b_hi bits of B in the bin index, the key = the low b_lo bits of B).
 struct OrderKey {
     const uint32_t *pat_off;  // device: pattern i is pat_off[i+1] - pat_off[i] bytes long
     uint32_t uniform_len;     // != 0: every pattern has this length (no lookup)
@@ -94,7 +95,9 @@ struct OrderKey {
     uint64_t rec_base;        // subtracted from every record index (the smallest one when re-binning; else 0)
     uint32_t ac;              // 1: Aho-Corasick order, 0: BNDMq order
     uint32_t bits_a;          // width of A inside G; 0 = histogram on the record alone (field widths not known yet)
-    uint32_t bits_b;          // width of B inside the key (1..63)
+    uint32_t bits_b;          // width of B (1..63)
+    uint32_t b_hi;            // top bits of B that are part of the bin index (only with shift == 0; else 0)
+    uint32_t b_lo;            // bits of B inside the key = bits_b - b_hi
     uint32_t shift;           // bin = G >> shift (<= 63)
     uint32_t n_bins;          // <= kOrderMaxBins
 };

@@ -2,7 +2,7 @@
 with numpy on the host: Aho-Corasick order (record, end ascending, longer pattern first, pattern id --
 src/cmd_extract.rs:332-351) and BNDMq order (record, pattern, start -- src/cmd_extract.rs:365-384), on tuple
 sets that walk every path of the device code: bins of consecutive records, re-binning on (record, end) for few
-huge records, the library fallback, shuffled input, tuples of a batch the handle has not scanned, and every
+huge records, the re-binning on the whole key, the library fallback, shuffled input, tuples of a batch the handle has not scanned, and every
 small size around the leaf-sort geometry.  The scan-produced tuples of real batches are covered by
 test_gpu_parity.py::test_emission_order_on_the_device and test_gpu_configs.py (10^8 tuples)."""
 import random
@@ -131,9 +131,10 @@ def test_order_clustered_hits_and_foreign_batches(mk):
     assert m.order_info()["path"] == 2
 
 
-def test_order_library_fallback(mk):
-    """more than 16384 tuples that share record AND end position cannot be split by any binning: the library
-    sort takes over (and says so)"""
+def test_order_bins_on_the_whole_key_when_record_and_end_do_not_split(mk):
+    """tuples that share record AND end position (here 20 000 patterns ending on one byte), or one pattern all over one
+    long record under BNDMq order (record and pattern constant): the re-binning takes the top bits of the whole
+    (record, A, B) triple, so the last field splits them"""
     rnd = random.Random(3)
     pats = _patterns(rnd, 20_000, [12])
     m = mk.Matcher(pats)
@@ -144,4 +145,29 @@ def test_order_library_fallback(mk):
     np.random.default_rng(1).shuffle(h)
     got = _order_on_device(mk, m, h)
     assert np.array_equal(got, _expected(h, True, plen))
-    assert m.order_info()["path"] == 3
+    assert m.order_info()["path"] == 2 and m.order_info()["max_bin"] <= 16384, m.order_info()
+    # one pattern, one record, 100 000 positions, BNDMq order
+    mb = mk.Matcher([b"AAC"], algo=mk.MK_ALGO_BNDMQ)
+    pos = np.random.default_rng(2).choice(3_000_000, size=100_000, replace=False).astype(np.uint32)
+    h = np.zeros(len(pos), dtype=mk.HIT_DTYPE)
+    h["pos"] = pos
+    got = _order_on_device(mk, mb, h)
+    assert np.array_equal(got, _expected(h, False, np.array([3], dtype=np.int64)))
+    assert mb.order_info()["path"] == 2, mb.order_info()
+
+
+def test_order_library_fallback(mk):
+    """a batch that defeats both binning attempts -- 20 000 tuples in record 0 and a single one in record 2^40: the
+    top bits of the 59-bit key cannot separate the 20 000 -- is ordered by the library sort (and says so)"""
+    rnd = random.Random(4)
+    pats = _patterns(rnd, 700, [31])
+    m = mk.Matcher(pats)
+    plen = np.array([31] * len(pats), dtype=np.int64)
+    h = _tuples(mk, rnd, 20_000, 1, 200, len(pats))
+    far = np.zeros(1, dtype=mk.HIT_DTYPE)
+    far["rec"], far["pat"], far["pos"] = 1 << 40, 5, 9
+    h = np.concatenate([h, far])
+    np.random.default_rng(1).shuffle(h)
+    got = _order_on_device(mk, m, h)
+    assert np.array_equal(got, _expected(h, True, plen))
+    assert m.order_info()["path"] == 3, m.order_info()
