@@ -252,13 +252,14 @@ int mk_order_hits(const mk_matcher *m, mk_hit *hits, uint64_t n_hits);
  * tuples and one over the keys (order_hits.hip).  The call waits ONCE for the stream (32 bytes of histogram
  * statistics fix the key layout; the caller has just read n_hits the same way) and returns with the rest enqueued.
  * Bins use the record count of the handle's last mk_scan_device; tuples of another batch are still ordered
- * correctly.  Batches that defeat the binning (a bin above 16384 tuples after re-binning on record and position,
+ * correctly.  Batches that defeat the binning (a bin above 16384 tuples after re-binning on the top bits of the whole
+ * record / end / pattern key,
  * more than 2^32 - 1 tuples, or record / end / pattern fields that do not fit 64 bits together) are ordered by a
  * library merge sort instead.  mk_scan_batch uses this by itself.  The scratch buffer (8 bytes per tuple) lives in
  * the handle (growing it synchronises the device; one call in flight per handle). */
 int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *stream);
 /* what the last mk_order_hits_device on this handle did: *path = 0 nothing (fewer than two tuples), 1 bins of
- * consecutive records, 2 bins on the top bits of (record, end | pattern), 3 library merge sort; the number of
+ * consecutive records, 2 bins on the top bits of the whole (record, end, pattern) key, 3 library merge sort; the number of
  * bins and the largest bin (paths 1 and 2) */
 int mk_matcher_order_info(const mk_matcher *m, uint32_t *path, uint32_t *n_bins, uint32_t *max_bin);
 
