@@ -500,6 +500,9 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
         mk._check(lib.mk_synth_reads_device_range(m0.handle, seed, 0, n_rec0, L0, pe, d_seq.data_ptr(), d_off.data_ptr(), st))
         run(f"headline batch, {what}: {n_rec0} x {L0} bp, {len(m0.patterns)} 31-mers, any-hit flags", m0, d_seq, d_off, d_flags,
             n_rec0, L0, len(m0.patterns), False, pe)
+        if pe == 1:  # tag / extract -l on already extracted reads: every tuple, in emission order
+            run(f"headline batch, {what}: {n_rec0} x {L0} bp, {len(m0.patterns)} 31-mers, every hit tuple in emission order", m0, d_seq,
+                d_off, d_flags, n_rec0, L0, len(m0.patterns), True, pe)
     del d_seq, d_off, d_flags
 
     def fresh(n_rec, L, n_pat, k, rc, plant_every, s):
