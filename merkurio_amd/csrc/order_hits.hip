@@ -22,7 +22,7 @@
 //
 //   1. mk_order_hist_kernel     reads the tuples once: tuples per bin (LDS histogram per workgroup, one
 //                               global atomic per non-empty bin) and the maxima of record, A and B;
-//      mk_order_scan_kernel     bin starts (one workgroup) and the largest bin; the host reads 32 bytes
+//      mk_order_scan_kernel     bin starts (one workgroup) and the largest bin; the host reads 48 bytes
 //                               back and fixes the field widths and the leaf geometry -- the only host
 //                               round trip (the caller has just read the tuple count the same way);
 //   2. mk_order_scatter_kernel  reads the tuples again, packs each into its 8-byte key and stores it in
