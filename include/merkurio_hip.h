@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 3
+#define MK_ABI_VERSION 4
 
 /* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
 #define MK_OK 0
@@ -152,9 +152,20 @@ typedef struct {
     uint32_t gbloom_log2_blocks;  /* 0 = rule; else log2 of the number of 64-bit blocks of a global filter */
     uint32_t tile_run;            /* 0 = rule; else 1..8 consecutive 31 KiB tiles a scan wave takes before it jumps ahead */
     uint32_t gbloom_kib;          /* 0 = rule; else size of a global filter in KiB (any size, overrides gbloom_log2_blocks) */
+    /* length classes (ABI 4).  A set whose shortest pattern is much shorter than the rest is split by length: the
+     * short patterns get their own stride and q-gram table next to the main filter (one pass, one kernel). */
+    uint32_t length_classes;      /* 0 = rule (split where the cost model says it pays); 1 = never split; 2 = split */
+    uint32_t force_split_len;     /* 0 = rule; else patterns shorter than this form the short class */
+    uint32_t force_stride2;       /* 0 = rule; else stride of the short class: 1, 2, 4 or 8 */
+    uint32_t force_q2;            /* 0 = rule; else q-gram length of the short class, 1..8 (clamped to what its shortest pattern admits) */
 } mk_matcher_options;
 int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
                          uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out);
+/* The filter geometry mk_matcher_create_ex would choose for patterns of these lengths, without creating anything (host
+ * only, no device needed): main-class q-gram length and stride, whether the level-1 filter fits LDS, and the length
+ * classes (see mk_matcher_class_info).  Any output pointer may be NULL. */
+int mk_plan_geometry(const uint32_t *pat_len, uint32_t n_pat, const mk_matcher_options *options, uint32_t *q_gram, uint32_t *stride,
+                     uint32_t *in_lds, uint32_t *split_len, uint32_t *n_short, uint32_t *q_gram2, uint32_t *stride2);
 void mk_matcher_destroy(mk_matcher *m);
 /* MK_ALGO_AC or MK_ALGO_BNDMQ after the auto rule was applied */
 uint32_t mk_matcher_algo(const mk_matcher *m);
@@ -162,6 +173,10 @@ uint32_t mk_matcher_num_patterns(const mk_matcher *m);
 /* filter geometry chosen at create time: q-gram length, sampling stride, table entries */
 int mk_matcher_filter_info(const mk_matcher *m, uint32_t *q_gram, uint32_t *stride, uint64_t *entries,
                            uint64_t *table_bytes);
+/* length classes chosen at create time: *split_len = 0 (one class: mk_matcher_filter_info describes it) or the
+ * length below which a pattern belongs to the short class, the number of such patterns, and the short class's
+ * q-gram length and stride (mk_matcher_filter_info then describes the main class; `entries` counts both) */
+int mk_matcher_class_info(const mk_matcher *m, uint32_t *split_len, uint32_t *n_short, uint32_t *q_gram2, uint32_t *stride2);
 /* where the level-1 filter lives: *in_lds = 1 (128 KiB image staged in LDS by every workgroup)
  * or 0 (large pattern sets: blocks in global memory, L2 / Infinity-Cache resident), and its size */
 int mk_matcher_filter_mode(const mk_matcher *m, uint32_t *in_lds, uint64_t *filter_bytes);

@@ -122,6 +122,19 @@ MK_HD uint32_t ctx_of_pattern(const uint8_t *p, uint32_t o, uint32_t q, uint32_t
     return c;
 }
 
+// ---- two length classes (matcher.cpp: plan_classes; scan_kernel_impl.hpp: MC kernels) ---------------------------
+// A pattern set whose shortest pattern is much shorter than the rest would drag the whole set down to the stride
+// and q-gram length that pattern admits (10 000 31-mers + one 8-mer: S = 1, q = 8 for everybody).  Such a set is split
+// by length: the long patterns keep the hashed q-gram filter above, the short ones get their own stride S2 and
+// q-grams of q2 <= 8 bases looked up in a plain bitmap over the 4^q2 packed keys (8 KiB of LDS).  Both classes'
+// entries live in one exact table; bit 0 of an entry's fingerprint is its class, so that a sample of one class can
+// never verify an entry of the other (every occurrence is still discovered exactly once).
+constexpr uint32_t kShortMaxQ = 8;
+constexpr uint32_t kShortByteMaxQ = 6;  // up to here the table holds a byte per key (4 KiB), above a bit per key
+constexpr uint32_t kShortBitmapWords = (1u << (2 * kShortMaxQ)) / 32;  // 2048 words
+MK_HD uint32_t short_fp(uint32_t key) { return (key * 0x9E3779B1u) | 1u; }
+MK_HD uint32_t main_fp(uint32_t h) { return h & ~1u; }
+
 MK_HD uint8_t fold_ascii(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c | 0x20) : c; }
 
 // counter-based synthetic read generator (bench / full-size parity tests)

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -48,20 +49,30 @@ int hip_fail(hipError_t e, const char *what) {
 // more filter entries, i.e. more false positives to verify.  Measured on MI355X with 10 k
 // 31-mers (profiles/r01_stride_sweep.txt): S=8 (80 k entries, 0.2 % of bases become
 // candidates) beats S=4 by 14 % and S=16 by 60 %.  Rule: largest S with <= 96 k entries and
-// q >= 14.
+// q-grams long enough that random text matches one of them less than once per 1024 bases
+// (n / 4^q: the true q-gram matches, which no filter removes): q >= 12 for 10 k patterns, 14 for
+// the largest sets an LDS filter holds.  (Until r04 the floor was 14 for every set: 10 000
+// patterns of 15..31 bases sampled at S=2, 4.15 ms per 15 GB, where S=4 / q=12 costs one sample
+// in two and 9 M more candidates; profiles/r04_mixed_sets.txt.)
+constexpr uint64_t kMaxLdsEntries = 98304;
+static uint32_t min_q_for(uint64_t n_pat) {
+    uint32_t q = 1;
+    while (q < 14 && (1ull << (2 * q)) < 1024 * n_pat) ++q;
+    return q;
+}
 static void choose_geometry(uint32_t lmin, uint64_t n_pat, const mk_matcher_options &opt, uint32_t *q, uint32_t *S,
                             uint32_t *gblocks) {
     const int forced = (int)opt.force_stride;  // tuning / test hooks: mk_matcher_create_ex only
     const bool force_global = opt.force_global_filter != 0;
     *gblocks = 0;
-    constexpr uint64_t kMaxLdsEntries = 98304;
     if (n_pat <= kMaxLdsEntries && !force_global) {  // LDS filter
+        const uint32_t q_floor = min_q_for(n_pat);
         for (uint32_t s : {16u, 8u, 4u, 2u, 1u}) {
             if (s > lmin) continue;
             uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
             if (forced) {
                 if ((int)s != forced) continue;
-            } else if (s > 1 && (qq < 14 || n_pat * s > kMaxLdsEntries)) {
+            } else if (s > 1 && (qq < q_floor || n_pat * s > kMaxLdsEntries)) {
                 continue;
             }
             *q = qq;
@@ -118,6 +129,82 @@ uint64_t pack_qgram(const uint8_t *p, uint32_t q) {
     return k;
 }
 
+// ---- length classes ---------------------------------------------------------------------------
+// One geometry for the whole set is dictated by its SHORTEST pattern: 10 000 31-mers next to one
+// 8-mer scan at S=1, q=8 -- 71.7 ms per 15 GB instead of 2.4 (profiles/r04_mixed_sets.txt), where
+// the reference's DFA (src/cmd_extract.rs:260-265) scans any list at one speed.  The set is
+// therefore split by length where that pays: patterns shorter than `split` form a SHORT class with
+// its own stride S2 and q-grams of q2 <= 8 bases looked up in a plain table in LDS (filter.hpp,
+// scan_kernel_impl.hpp: MC kernels), the others keep the hashed filter with the geometry THEIR
+// shortest pattern admits.  The split is chosen with a cost model fitted to the stride sweep of
+// the headline set (ms per 15 GB launch on an MI355X, same file): 1.13 + 0.42 per hashed sample
+// per 16 bases + 0.13 / 0.25 per byte- / bit-table sample + 0.0152 per million candidates.
+struct ClassPlan {
+    uint32_t split = 0;  // 0 = one class; else patterns shorter than this are the short class
+    uint32_t S2 = 0, q2 = 0;
+    uint32_t lmin_main = 0;
+    uint64_t n_main = 0, n_short = 0;
+    double cost = 0;
+};
+static double bloom_fp(double entries) {  // blocked filter of filter.hpp: bit a in the low word, b and c in the high word
+    const double lo = 1.0 - exp(-entries / (kBloomBlocks * 32.0)), hi = 1.0 - exp(-2.0 * entries / (kBloomBlocks * 32.0));
+    return lo * hi * hi;
+}
+static double main_cost(uint32_t lmin, uint64_t n, const mk_matcher_options &opt) {
+    uint32_t q, S, gb;
+    choose_geometry(lmin, n, opt, &q, &S, &gb);
+    const double per_base = std::min(1.0 / S, (double)n / pow(4.0, (double)std::min(q, 30u))) + bloom_fp((double)n * S) / S;
+    return 0.42 * (16.0 / S) + 15000.0 * 0.0152 * per_base;
+}
+static double short_cost(uint32_t S2, uint32_t q2, uint64_t n) {
+    const double per_sample = std::min(1.0, (double)n * S2 / pow(4.0, (double)q2));
+    return (q2 <= kShortByteMaxQ ? 0.13 : 0.25) * (16.0 / S2) + 15000.0 * 0.0152 * per_sample / S2;
+}
+// lens: pattern lengths (any order).  Only sets whose main class fits the LDS filter are split.
+static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_options &opt) {
+    ClassPlan best;
+    std::sort(lens.begin(), lens.end());
+    const uint64_t n = lens.size();
+    best.n_main = n;
+    best.lmin_main = lens[0];
+    if (opt.length_classes == 1 || opt.force_global_filter || n > kMaxLdsEntries || lens[0] == lens[n - 1]) return best;
+    if (opt.force_stride && opt.length_classes != 2 && !opt.force_split_len) return best;  // a forced stride means the whole set
+    best.cost = main_cost(lens[0], n, opt);
+    const double single = best.cost;
+    for (uint64_t i = 1; i < n; ++i) {  // short class = lens[0 .. i), split at every distinct length
+        if (lens[i] == lens[i - 1]) continue;
+        const uint32_t split = lens[i];
+        if (opt.force_split_len && split != opt.force_split_len) continue;
+        if (lens[0] > 64 && !opt.force_split_len) break;  // (such a set is sampled at S=16 as one class anyway)
+        {  // a main class that itself needs stride 1 is not split (no such kernel: 16 + 16 samples per lane spill)
+            uint32_t q, S, gb;
+            choose_geometry(split, n - i, opt, &q, &S, &gb);
+            if (S < 2) continue;
+        }
+        const double mc = main_cost(split, n - i, opt);
+        for (uint32_t s2 : {8u, 4u, 2u, 1u}) {
+            if (s2 > lens[0] || (opt.force_stride2 && s2 != opt.force_stride2)) continue;
+            const uint32_t qmax = std::min<uint32_t>(kShortMaxQ, lens[0] - s2 + 1);
+            for (uint32_t q2 : {qmax, std::min(qmax, kShortByteMaxQ)}) {
+                if (opt.force_q2 && q2 != std::min<uint32_t>(opt.force_q2, qmax)) continue;
+                const double c = mc + short_cost(s2, q2, i);
+                const bool forced = opt.length_classes == 2 || opt.force_split_len;
+                // a split must pay for the second code path: 10 % below the single class
+                if ((best.split == 0 && (forced || c < 0.9 * single)) || (best.split != 0 && c < best.cost)) {
+                    best.split = split;
+                    best.S2 = s2;
+                    best.q2 = q2;
+                    best.lmin_main = split;
+                    best.n_main = n - i;
+                    best.n_short = i;
+                    best.cost = c;
+                }
+            }
+        }
+    }
+    return best;
+}
+
 }  // namespace mk
 
 using namespace mk;
@@ -136,28 +223,8 @@ int mk::ensure_device(void **p, size_t *cap, size_t need) {
 
 static int ensure(void **p, size_t *cap, size_t need) { return ensure_device(p, cap, need); }
 
-extern "C" {
-
-int mk_abi_version(void) { return MK_ABI_VERSION; }
-const char *mk_last_error(void) { return g_last_error; }
-
-int mk_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-void mk_free(void *p) { free(p); }
-
-int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
-                      uint32_t flags, int32_t device, mk_matcher **out) {
-    return mk_matcher_create_ex(pat_bytes, pat_off, n_pat, algo, q, flags, device, nullptr, out);
-}
-
-int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
-                         uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out) {
-    if (!out) return fail(MK_E_INVALID_ARG, "out is null");
-    *out = nullptr;
+// options of mk_matcher_create_ex / mk_plan_geometry -> a complete, validated struct (NULL = defaults)
+static int read_options(const mk_matcher_options *options, mk_matcher_options *out) {
     mk_matcher_options opt;
     memset(&opt, 0, sizeof(opt));
     if (options) {  // a caller built against an older, shorter struct passes its own size
@@ -171,7 +238,64 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
             return fail(MK_E_INVALID_ARG, "gbloom_log2_blocks %u out of range (10..25)", opt.gbloom_log2_blocks);
         if (opt.tile_run > 8) return fail(MK_E_INVALID_ARG, "tile_run %u out of range (0..8)", opt.tile_run);
         if (opt.gbloom_kib > (1u << 18)) return fail(MK_E_INVALID_ARG, "gbloom_kib %u out of range (<= 256 MiB)", opt.gbloom_kib);
+        if (opt.length_classes > 2) return fail(MK_E_INVALID_ARG, "length_classes %u: must be 0 (rule), 1 or 2", opt.length_classes);
+        const uint32_t f2 = opt.force_stride2;
+        if (f2 != 0 && f2 != 1 && f2 != 2 && f2 != 4 && f2 != 8)
+            return fail(MK_E_INVALID_ARG, "force_stride2 %u: must be 0, 1, 2, 4 or 8", f2);
+        if (opt.force_q2 > kShortMaxQ) return fail(MK_E_INVALID_ARG, "force_q2 %u: must be 0..%u", opt.force_q2, kShortMaxQ);
     }
+    *out = opt;
+    return MK_OK;
+}
+
+extern "C" {
+
+int mk_abi_version(void) { return MK_ABI_VERSION; }
+const char *mk_last_error(void) { return g_last_error; }
+
+int mk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mk_free(void *p) { free(p); }
+
+int mk_plan_geometry(const uint32_t *pat_len, uint32_t n_pat, const mk_matcher_options *options, uint32_t *q_gram, uint32_t *stride,
+                     uint32_t *in_lds, uint32_t *split_len, uint32_t *n_short, uint32_t *q_gram2, uint32_t *stride2) {
+    if (!pat_len || n_pat == 0) return fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
+    mk_matcher_options opt;
+    int rc = read_options(options, &opt);
+    if (rc) return rc;
+    MK_ABI_BEGIN
+    std::vector<uint32_t> lens(pat_len, pat_len + n_pat);
+    if (*std::min_element(lens.begin(), lens.end()) == 0) return fail(MK_E_EMPTY_PATTERN, "Pattern is empty.");
+    const ClassPlan plan = plan_classes(std::move(lens), opt);
+    uint32_t q = 0, S = 1, gb = 0;
+    choose_geometry(plan.lmin_main, plan.n_main, opt, &q, &S, &gb);
+    if (q_gram) *q_gram = q;
+    if (stride) *stride = S;
+    if (in_lds) *in_lds = gb ? 0 : 1;
+    if (split_len) *split_len = plan.split;
+    if (n_short) *n_short = (uint32_t)plan.n_short;
+    if (q_gram2) *q_gram2 = plan.q2;
+    if (stride2) *stride2 = plan.S2;
+    return MK_OK;
+    MK_ABI_END
+}
+
+int mk_matcher_create(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
+                      uint32_t flags, int32_t device, mk_matcher **out) {
+    return mk_matcher_create_ex(pat_bytes, pat_off, n_pat, algo, q, flags, device, nullptr, out);
+}
+
+int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
+                         uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out) {
+    if (!out) return fail(MK_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    mk_matcher_options opt;
+    int rc_opt = read_options(options, &opt);
+    if (rc_opt) return rc_opt;
     MK_ABI_BEGIN
     if (n_pat == 0 || !pat_off || !pat_bytes) return fail(MK_E_NO_PATTERNS, "No k-mers found in file or provided sequence.");
     if (algo > MK_ALGO_BNDMQ) return fail(MK_E_INVALID_ARG, "unknown algo %u", algo);
@@ -230,12 +354,26 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
 
     m->uniform_len = (lmin == lmax) ? lmin : 0;
     m->tile_run = opt.tile_run;
-    // ---- compile the pattern set: Bloom filter + exact table
-    choose_geometry(lmin, n_pat, opt, &m->q, &m->S, &m->gbloom_blocks);
+    // ---- compile the pattern set: length classes, Bloom filter + exact table
+    ClassPlan plan;
+    {
+        std::vector<uint32_t> lens(n_pat);
+        for (uint32_t i = 0; i < n_pat; ++i) lens[i] = pat_off[i + 1] - pat_off[i];
+        plan = plan_classes(std::move(lens), opt);
+    }
+    if ((opt.length_classes == 2 || opt.force_split_len) && !plan.split)
+        return fail(MK_E_INVALID_ARG, "the pattern set cannot be split into two length classes as the options ask "
+                                      "(split length %u, stride %u, shortest pattern %u, longest %u)",
+                    opt.force_split_len, opt.force_stride2, lmin, lmax);
+    m->split_len = plan.split;
+    m->S2 = plan.S2;
+    m->q2 = plan.q2;
+    m->n_short = (uint32_t)plan.n_short;
+    choose_geometry(plan.lmin_main, plan.n_main, opt, &m->q, &m->S, &m->gbloom_blocks);
     if (opt.force_stride && m->S != opt.force_stride)
-        return fail(MK_E_INVALID_ARG, "force_stride %u is longer than the shortest pattern (%u)", opt.force_stride, lmin);
+        return fail(MK_E_INVALID_ARG, "force_stride %u is longer than the shortest pattern (%u)", opt.force_stride, plan.lmin_main);
     const uint32_t q_f = m->q, S = m->S;
-    m->entries = (uint64_t)n_pat * S;
+    m->entries = plan.n_main * S + plan.n_short * plan.S2;
     // load <= 0.5 while the table shares L2 with the text stream; a global-filter set's table is
     // HBM-resident anyway, and at load <= 0.25 a lookup all but never has to walk to a second bucket
     uint64_t slots = 64;
@@ -256,15 +394,25 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     }
     const uint32_t bmask = m->table_slots / kBucketEntries - 1;  // bucket index mask
     const bool gf_ctx = m->gbloom_blocks != 0 && gf_has_ctx(S, q_f);
+    const bool two = plan.split != 0;
+    std::vector<uint32_t> short_table(two ? kShortBitmapWords : 0, 0);
     for (uint32_t pi = 0; pi < n_pat; ++pi) {
         const uint8_t *p = pat_bytes + pat_off[pi];
-        for (uint32_t o = 0; o < S; ++o) {
-            const uint64_t key = pack_qgram(p + o, q_f);
-            const uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
+        const bool is_short = two && pat_off[pi + 1] - pat_off[pi] < plan.split;
+        for (uint32_t o = 0; o < (is_short ? plan.S2 : S); ++o) {
+            const uint64_t key = pack_qgram(p + o, is_short ? plan.q2 : q_f);
+            uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
             // level-2 fingerprint: the filter hash, or (context kernels) that hash mixed with the
-            // pattern bases around the q-gram
-            const uint32_t fp = gf_ctx ? ctx_fp(h, ctx_of_pattern(p, o, q_f, S) & ctx_mask(o, S)) : h;
-            if (m->gbloom_blocks) {
+            // pattern bases around the q-gram; two classes: bit 0 says which class's samples may verify it
+            uint32_t fp = gf_ctx ? ctx_fp(h, ctx_of_pattern(p, o, q_f, S) & ctx_mask(o, S)) : h;
+            if (two) fp = is_short ? short_fp((uint32_t)key) : main_fp(h);
+            if (is_short) {  // level 1 of the short class: the table over its packed keys, nothing in the Bloom filter
+                if (plan.q2 <= kShortByteMaxQ)
+                    reinterpret_cast<uint8_t *>(short_table.data())[key] = 1;
+                else
+                    short_table[key >> 5] |= 1u << (key & 31);
+                h = fp;  // (home bucket below)
+            } else if (m->gbloom_blocks) {
                 const size_t blk = (size_t)gbloom_block(h, gmask) * 2;
                 const uint32_t hb = gbloom_bits(h);
                 bloom[blk] |= (1u << bloom_bit_a(hb)) | (1u << bloom_bit_d(hb));
@@ -274,7 +422,7 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
                 bloom[blk] |= 1u << bloom_bit_a(h);
                 bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
             }
-            uint32_t b = table_bucket(h, bmask);
+            uint32_t b = table_bucket(two ? fp : h, bmask);
             for (;;) {  // first bucket from the home bucket on with a free entry
                 TableEntry *e = &table[(size_t)b * kBucketEntries];
                 uint32_t k = 0;
@@ -307,6 +455,10 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     MK_HIP(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (two) {
+        MK_HIP(hipMalloc((void **)&m->d_short_table, kShortBitmapWords * sizeof(uint32_t)));
+        MK_HIP(hipMemcpy(m->d_short_table, short_table.data(), kShortBitmapWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (use == MK_ALGO_AC && !m->uniform_len) {
         // matches that end on one byte are emitted longest first, then by pattern id (aho-corasick's overlapping
         // DFA walk, src/cmd_extract.rs:332-351): that tie order as a rank the device sort can use as a key field
@@ -336,7 +488,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
                     (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp,
-                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux, m->d_pair})
+                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux, m->d_pair, (void *)m->d_short_table})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -352,6 +504,15 @@ int mk_matcher_filter_info(const mk_matcher *m, uint32_t *q_gram, uint32_t *stri
     if (stride) *stride = m->S;
     if (entries) *entries = m->entries;
     if (table_bytes) *table_bytes = (uint64_t)m->table_slots * sizeof(TableEntry);
+    return MK_OK;
+}
+
+int mk_matcher_class_info(const mk_matcher *m, uint32_t *split_len, uint32_t *n_short, uint32_t *q_gram2, uint32_t *stride2) {
+    if (!m) return fail(MK_E_INVALID_ARG, "null matcher");
+    if (split_len) *split_len = m->split_len;
+    if (n_short) *n_short = m->n_short;
+    if (q_gram2) *q_gram2 = m->q2;
+    if (stride2) *stride2 = m->S2;
     return MK_OK;
 }
 
@@ -403,6 +564,10 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.key_mask_lo = (uint32_t)kmask;
     p.key_mask_hi = (uint32_t)(kmask >> 32);
     p.case_insensitive = (m->flags & MK_FLAG_ASCII_CASE_INSENSITIVE) ? 1 : 0;
+    p.s2 = m->split_len ? m->S2 : 0;
+    p.key2_mask = (1u << (2 * m->q2)) - 1u;
+    p.short_bytes = m->q2 <= kShortByteMaxQ;
+    p.short_bitmap = m->d_short_table;
     p.uniform_len = m->uniform_len;
     p.rec_flags32 = (uint32_t *)d_rec_flags;
     p.hits = (mk_hit *)d_hits;
@@ -442,7 +607,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     // r03 (dense flavour probing / resolving early, profiles/r03_crossover.txt): flags only 1 in 8 records sparse 3.24 vs
     // dense 3.32 ms, 1 in 6 3.68 vs 3.44; with tuples 1 in 12 3.29 vs 3.39, 1 in 10 3.49 vs 3.43
     const uint32_t kDensePerMille = mode == MK_MODE_HITS ? 95 : 145;
-    const bool plain_loads = m->hit_density_pm >= kDensePerMille;
+    const bool plain_loads = m->hit_density_pm >= kDensePerMille && !m->split_len;  // (two-class kernels: one flavour)
     // (r03: a third flavour -- the sparse kernel with 16-byte compare loads as its own instantiation, for 2-12 % of
     // the records hitting -- gained nothing at any density: profiles/r03_cmp16_mid.txt)
     const int flavour = plain_loads ? 0 : 1;

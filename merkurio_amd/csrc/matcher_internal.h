@@ -19,6 +19,10 @@ struct mk_matcher {
     // filter
     uint32_t uniform_len = 0;  // > 0: all patterns share this length
     uint32_t q = 0, S = 1;
+    // two length classes (matcher.cpp: plan_classes): patterns shorter than split_len (0 = one class) are the short
+    // class -- stride S2, q-grams of q2 <= 8 bases, level 1 = d_short_table (byte or bit per packed key)
+    uint32_t split_len = 0, S2 = 0, q2 = 0, n_short = 0;
+    uint32_t *d_short_table = nullptr;
     uint64_t entries = 0;
     uint32_t table_slots = 0;
     uint32_t *d_bloom = nullptr;

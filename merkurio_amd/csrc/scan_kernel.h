@@ -28,6 +28,12 @@ struct ScanParams {
     uint32_t q;           // q-gram length (1..32)
     uint32_t key_mask_lo;  // low / high 32 bits of the 2q-bit key mask
     uint32_t key_mask_hi;
+    // second length class (MC kernels; s2 == 0: none): stride, key mask of its q2 <= 8 base q-grams, table over the
+    // packed keys (kShortBitmapWords words, device memory; staged in LDS by every workgroup)
+    uint32_t s2;
+    uint32_t key2_mask;
+    uint32_t short_bytes;  // 1: the table holds one byte per key (q2 <= 6), 0: one bit per key
+    const uint32_t *short_bitmap;
     uint32_t case_insensitive;
     uint32_t uniform_len;  // > 0: every pattern has this length (pattern i starts at i * uniform_len)
     double rec_per_byte;  // n_rec / n_bytes: record-index estimate for the lookup in resolve_one
@@ -61,11 +67,12 @@ struct ScanParams {
 // S = sampling stride (1,2,4,8,16); wide = q > 16 (64-bit keys); emit = write mk_hit tuples.
 // Returns the kernel's name (static storage) or nullptr for an unsupported S.
 // flavour: 1 sparse hits, 0 hit-dense text (scan_kernel_impl.hpp: FL; honoured by the kernels with the filter in LDS)
+// p.s2 != 0 selects the two-class twin of the variant (filter in LDS only)
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream);
 
 // host-side launcher of one kernel variant; defined (explicitly instantiated) in scan_variants.hip
-template <int S, int QC, bool EMIT, bool GF, int FL>
+template <int S, int QC, bool EMIT, bool GF, int FL, bool MC = false>
 void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream);
 
 // static LDS bytes of one scan workgroup (filter + candidate rings + pattern counters)

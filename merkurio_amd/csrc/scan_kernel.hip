@@ -162,9 +162,9 @@ void launch_add_u64(unsigned long long *dst, const unsigned long long *src, size
 
 // the kernel variants are instantiated in groups by scan_variants.hip (one translation unit per
 // group, compiled in parallel); launch_variant<...> is the host-side launcher of one of them
-template <int S, int QC, bool EMIT, bool GF, int FL = 1>
+template <int S, int QC, bool EMIT, bool GF, int FL = 1, bool MC = false>
 static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
-    launch_variant<S, QC, EMIT, GF, FL>(p, grid, st);
+    launch_variant<S, QC, EMIT, GF, FL, MC>(p, grid, st);
     return name;
 }
 
@@ -175,11 +175,34 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
 #define MK_VARIANT_PLAIN(S_, QC_)                                                                                       \
     return emit ? launch_one<S_, QC_, true, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,plain>") \
                 : launch_one<S_, QC_, false, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,plain>")
-
+#define MK_VARIANT_MC(S_, QC_)                                                                                              \
+    return emit ? launch_one<S_, QC_, true, false, 1, true>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,2-class>") \
+                : launch_one<S_, QC_, false, false, 1, true>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,2-class>")
 
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream) {
     const bool plain_loads = flavour == 0;
+    if (p.s2) {  // two length classes (filter.hpp): main filter in LDS + the short class's bitmap; one load flavour
+        if (global_filter) return nullptr;
+        if (S == 16 && p.q == 16) MK_VARIANT_MC(16, 16);
+        if (S == 8 && p.q == 24) MK_VARIANT_MC(8, 24);
+        if (S == 4 && p.q == 28) MK_VARIANT_MC(4, 28);
+        if (S == 4 && p.q == 18) MK_VARIANT_MC(4, 18);
+        if (wide) switch (S) {
+                case 2: MK_VARIANT_MC(2, -1);
+                case 4: MK_VARIANT_MC(4, -1);
+                case 8: MK_VARIANT_MC(8, -1);
+                case 16: MK_VARIANT_MC(16, -1);
+                default: return nullptr;
+            }
+        switch (S) {
+            case 2: MK_VARIANT_MC(2, 0);
+            case 4: MK_VARIANT_MC(4, 0);
+            case 8: MK_VARIANT_MC(8, 0);
+            case 16: MK_VARIANT_MC(16, 0);
+            default: return nullptr;
+        }
+    }
     if (global_filter) {  // large pattern sets: filter blocks in global memory
         if (S == 8 && p.q == 14) MK_VARIANT(8, 14, true);  // 21-mers
         if (S == 4 && p.q == 18) MK_VARIANT(4, 18, true);
@@ -249,6 +272,7 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
 }
 #undef MK_VARIANT
 #undef MK_VARIANT_PLAIN
+#undef MK_VARIANT_MC
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
 // byte0 = global position of seq[0] in the synthetic stream (a multiple of 32)

@@ -73,10 +73,13 @@ struct alignas(8) CandEntry {
 };
 constexpr uint32_t kRingEntries = 128;  // per wave; <= 64 pending before an append round of <= 64
 constexpr uint32_t kHitSlots = 64;  // per wave: verified-q-gram hits waiting for level 3 (one per lane)
-constexpr uint32_t kLdsSumWords = 4;  // per-workgroup sums of the summary counters (candidates, occurrences)
+constexpr uint32_t kLdsSumWords = 4;  // per-workgroup sums of the summary counters (candidates, occurrences): they take
+                                      // the place of wave 0's candidate ring once every wave has drained its own
 constexpr uint32_t kLdsBytes = kBloomBytes + (kBlockThreads / 64) * kRingEntries * sizeof(CandEntry) +
-                               (kBlockThreads / 64) * kHitSlots * 8 + kLdsSumWords * 4;  // 152 KiB
-static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
+                               (kBlockThreads / 64) * kHitSlots * 8;  // 152 KiB
+// two length classes (MC kernels): the short class's q-gram bitmap, one bit per 2-bit-packed key of up to 8 bases
+constexpr uint32_t kShortBitmapBytes = kShortBitmapWords * 4;  // 8 KiB
+static_assert(kLdsBytes + kShortBitmapBytes <= 160 * 1024, "one workgroup per CU");
 
 // compile-time ablation switches for profiling builds (hipcc -DMK_ABLATE=<bits>):
 //   1 = drop every filter positive, 2 = no LDS probe, 4 = loads + pack only,
@@ -422,13 +425,41 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 // Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
 // sizes that matter get their own kernels: no runtime masks, no unused halo words);
 // QC == 0: runtime q <= 16 (32-bit keys); QC == -1: runtime q in 17..32.
-template <int S, int QC, bool CTX>
+template <int S, int QC, bool CTX, bool MC = false>
 struct Geo {
     static constexpr bool kFixed = QC > 0;
     static constexpr int kNS = 16 / S;                                     // samples per lane per chunk
     static constexpr int kSpan = kFixed ? (kNS - 1) * S + QC + (CTX ? 7 : 0) : 48;  // bases a lane looks at
-    static constexpr bool kNeedW1 = kSpan > 16, kNeedW2 = kSpan > 32;      // halo words
+    // (the short class of an MC kernel looks at up to 15 + 8 bases)
+    static constexpr bool kNeedW1 = kSpan > 16 || MC, kNeedW2 = kSpan > 32;      // halo words
 };
+
+// ---- second length class (MC kernels; matcher.cpp: plan_classes) ------------------------------------------------
+// Patterns too short for the main class's q-grams form a class of their own: stride S2 in {1, 2, 4, 8}, q-grams of
+// q2 <= 8 bases, level 1 = a plain table over the 4^q2 packed keys in LDS (exact on the 2-bit codes, no hash): one
+// BYTE per key for q2 <= 6 (4 KiB; bit-field extract, ds_read_u8, shift-or: 3 vector operations per sample against the
+// ~10 of a hashed Bloom probe) or one BIT per key for q2 = 7, 8 (8 KiB, ~6 operations).  Both classes are probed from
+// the same packed registers in the same pass; their candidates share the ring, the exact table and level 3 (a class
+// bit in the fingerprint keeps an occurrence from being found through the other class's samples a second time:
+// filter.hpp, short_fp).
+template <int S2, bool BYTES>
+__device__ __forceinline__ uint32_t short_filter(const uint32_t *__restrict__ bm, uint32_t w0, uint32_t w1, uint32_t kmask) {
+    uint32_t cand = 0;
+#pragma unroll
+    for (int j = 0; j < 16 / S2; ++j) {
+        const int sh = 2 * j * S2;  // < 32
+        // (keys of the byte table have at most 12 bits: those that end inside w0 need no alignbit)
+        const uint32_t x = sh == 0 ? w0 : (BYTES && sh <= 20) ? (w0 >> sh) : __builtin_amdgcn_alignbit(w1, w0, sh);
+        const uint32_t key = x & kmask;
+        if constexpr (BYTES) {
+            cand |= (uint32_t) reinterpret_cast<const uint8_t *>(bm)[key] << j;
+        } else {
+            const uint32_t word = bm[key >> 5];
+            cand |= ((word >> (key & 31u)) & 1u) << j;
+        }
+    }
+    return cand;
+}
 
 // bits [bit, bit+32) of the packed stream w0 | w1<<32 | w2<<64, bit a run-time value below 96
 __device__ __forceinline__ uint32_t stream32_rt(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t bit) {
@@ -481,24 +512,29 @@ __device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32
 }
 
 // ---- main kernel -----------------------------------------------------------------------
-template <int S, int QC, bool EMIT, bool GF, int FL>
+template <int S, int QC, bool EMIT, bool GF, int FL, bool MC = false>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
+    static_assert(!(MC && GF), "two length classes: kernels with the main filter in LDS only");
     constexpr bool NTL = FL != 0;  // non-temporal stream loads
     // context kernels: global filter with a compile-time q (filter.hpp: gf_has_ctx); kPipe: their
     // filter probes run one chunk ahead of their use (two samples per lane keeps that in registers)
     constexpr bool kCtx = GF && QC > 0;
     constexpr int CS = kCtx ? S : 0;
-    using G = Geo<S, QC, kCtx>;
+    using G = Geo<S, QC, kCtx, MC>;
     constexpr bool kPipe = kCtx && G::kNS <= 2 && (MK_ABLATE & 7) == 0;
     constexpr bool kWide = FL == 0;  // hit-dense flavour: flags stored directly (drain_hits)
-    __shared__ __attribute__((aligned(16))) uint32_t bloom[kLdsBytes / 4];  // filter + candidate rings
-    uint32_t *lds_sums = bloom + kLdsBytes / 4 - kLdsSumWords;
-    if (threadIdx.x < kLdsSumWords) lds_sums[threadIdx.x] = 0;
-    if constexpr (GF) __syncthreads();
+    __shared__ __attribute__((aligned(16))) uint32_t bloom[(kLdsBytes + (MC ? kShortBitmapBytes : 0)) / 4];  // filter + candidate rings (+ short-class bitmap)
+    uint32_t *lds_sums = bloom + kBloomWords;  // wave 0's candidate ring, once every wave is done with its own
+    const uint32_t *short_bm = bloom + kLdsBytes / 4;  // MC
     if constexpr (!GF) {  // stage the filter image of the pattern set in LDS
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
         for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
+        if constexpr (MC) {
+            const uint4 *src2 = reinterpret_cast<const uint4 *>(P.short_bitmap);
+            uint4 *dst2 = reinterpret_cast<uint4 *>(bloom + kLdsBytes / 4);
+            for (uint32_t i = threadIdx.x; i < kShortBitmapWords / 4; i += kBlockThreads) dst2[i] = src2[i];
+        }
         __syncthreads();
     }
     const uint2 *__restrict__ gbloom = reinterpret_cast<const uint2 *>(P.bloom);  // GF: filter blocks in global memory
@@ -577,6 +613,25 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             uint32_t m = (blk.x >> (h >> 27)) & (blk.y >> (h >> 22)) & (blk.y >> (h >> 17));
             if constexpr (GF) m &= blk.x >> (h >> 12);  // the global filter's fourth bit (d)
             cand |= (m & 1u) << j;
+        }
+        if constexpr (MC) {  // the short class's samples: bits 16.. of the mask (wave-uniform stride)
+            uint32_t c2;
+            if (P.short_bytes) {
+                switch (P.s2) {
+                    case 1: c2 = short_filter<1, true>(short_bm, w0, w1, P.key2_mask); break;
+                    case 2: c2 = short_filter<2, true>(short_bm, w0, w1, P.key2_mask); break;
+                    case 4: c2 = short_filter<4, true>(short_bm, w0, w1, P.key2_mask); break;
+                    default: c2 = short_filter<8, true>(short_bm, w0, w1, P.key2_mask); break;
+                }
+            } else {
+                switch (P.s2) {
+                    case 1: c2 = short_filter<1, false>(short_bm, w0, w1, P.key2_mask); break;
+                    case 2: c2 = short_filter<2, false>(short_bm, w0, w1, P.key2_mask); break;
+                    case 4: c2 = short_filter<4, false>(short_bm, w0, w1, P.key2_mask); break;
+                    default: c2 = short_filter<8, false>(short_bm, w0, w1, P.key2_mask); break;
+                }
+            }
+            cand |= c2 << 16;
         }
         if constexpr ((MK_ABLATE & 1) != 0) {  // keep the filter work alive, drop its result
             abl_acc += cand;
@@ -662,7 +717,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t wm1, uint32_t cand, uint64_t cpos, uint32_t h0, uint32_t h1) __attribute__((always_inline)) {
         const uint32_t w0 = pk_cur;
         uint32_t w1 = 0, w2 = 0;
-        if constexpr (NS > 2 || kCtx) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below / the context needs the halo
+        if constexpr (NS > 2 || kCtx || MC) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below / the context needs the halo
         newest_end = cpos + kChunkBytes;  // parked and queued positions are all below it
         const uint32_t t_base = (uint32_t)cpos + lane * 16;
         do {  // wave-uniform; one iteration unless a lane has several positives in this chunk
@@ -670,7 +725,10 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             if (cand != 0) {
                 const uint32_t j = (uint32_t)__ffs(cand) - 1u;
                 cand &= cand - 1;
-                if constexpr (NS <= 2) {
+                if (MC && j >= 16u) {  // a sample of the short class: its fingerprint is its packed key (filter.hpp)
+                    const uint32_t sh = 2u * (j - 16u) * P.s2;
+                    slot_h = short_fp(__builtin_amdgcn_alignbit(w1, w0, sh) & P.key2_mask);
+                } else if constexpr (NS <= 2) {
                     slot_h = j ? h1 : h0;
                 } else {  // same value as sample_hash / filter.hpp's bloom_hash of the masked key
                     const uint32_t sh = 2u * j * S;
@@ -686,6 +744,12 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     slot_c = (prev7 & 0x3FFFu) | ((next7 & 0x3FFFu) << 14);
                 }
                 slot_t = t_base + j * S;
+                if constexpr (MC) {
+                    if (j >= 16u)
+                        slot_t = t_base + (j - 16u) * P.s2;
+                    else
+                        slot_h = main_fp(slot_h);
+                }
                 slot_full = true;
             }
         } while (__ballot(cand != 0));
@@ -909,6 +973,9 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         // One global atomic per WORKGROUP and counter: a single address retires an atomic every ~11 ns,
         // so one per wave (4096 x 2 on one cache line) kept every launch alive for 80 us after its
         // last wave had finished -- a quarter of the kernel time of a 1.5 GB batch (r02_small_ablate).
+        __syncthreads();  // every wave has drained its rings: wave 0's becomes the sums
+        if (threadIdx.x < kLdsSumWords) lds_sums[threadIdx.x] = 0;
+        __syncthreads();
         if (lane == 0 && n_cand) atomicAdd(&lds_sums[0], n_cand);
         if (n_true) atomicAdd(&lds_sums[1], n_true);  // per-wave totals stay far below 2^32
         __syncthreads();

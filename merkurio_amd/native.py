@@ -45,8 +45,8 @@ ROW_DTYPE = np.dtype([("rec", "<u8"), ("pat", "<u4"), ("pos", "<u4"), ("file", "
 EXPORTS = [
     "mk_abi_version", "mk_last_error", "mk_device_count", "mk_read_kmers_from_text", "mk_parse_pattern_list",
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
-    "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
-    "mk_matcher_filter_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
+    "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_plan_geometry", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
+    "mk_matcher_filter_info", "mk_matcher_class_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
@@ -73,11 +73,15 @@ class PatternError(MerkurioError):
 class MatcherOptions(C.Structure):
     """mk_matcher_options (include/merkurio_hip.h): tuning / test hooks of mk_matcher_create_ex"""
     _fields_ = [("struct_size", C.c_uint32), ("force_stride", C.c_uint32), ("force_global_filter", C.c_uint32),
-                ("gbloom_log2_blocks", C.c_uint32), ("tile_run", C.c_uint32), ("gbloom_kib", C.c_uint32)]
+                ("gbloom_log2_blocks", C.c_uint32), ("tile_run", C.c_uint32), ("gbloom_kib", C.c_uint32),
+                ("length_classes", C.c_uint32), ("force_split_len", C.c_uint32), ("force_stride2", C.c_uint32),
+                ("force_q2", C.c_uint32)]
 
-    def __init__(self, force_stride=0, force_global_filter=False, gbloom_log2_blocks=0, tile_run=0, gbloom_kib=0):
+    def __init__(self, force_stride=0, force_global_filter=False, gbloom_log2_blocks=0, tile_run=0, gbloom_kib=0,
+                 length_classes=0, force_split_len=0, force_stride2=0, force_q2=0, force_single_class=False):
         super().__init__(C.sizeof(MatcherOptions), int(force_stride), int(bool(force_global_filter)),
-                         int(gbloom_log2_blocks), int(tile_run), int(gbloom_kib))
+                         int(gbloom_log2_blocks), int(tile_run), int(gbloom_kib),
+                         1 if force_single_class else int(length_classes), int(force_split_len), int(force_stride2), int(force_q2))
 
 
 class Counters(C.Structure):
@@ -173,6 +177,9 @@ def load(build_if_missing=True):
     L.mk_matcher_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mk_matcher_filter_mode.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.mk_plan_geometry.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(MatcherOptions)] + [C.POINTER(C.c_uint32)] * 7
+    L.mk_matcher_class_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32)]
     L.mk_extract_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -304,6 +311,16 @@ def generate_masks(pattern: bytes):
     return masks.tolist(), accept.value
 
 
+def plan_geometry(lengths, options=None):
+    """mk_plan_geometry: the filter geometry / length classes a matcher for patterns of these lengths would get"""
+    lens = np.ascontiguousarray(lengths, dtype=np.uint32)
+    opt = None if options is None else (options if isinstance(options, MatcherOptions) else MatcherOptions(**options))
+    v = [C.c_uint32() for _ in range(7)]
+    _check(load().mk_plan_geometry(lens.ctypes.data, len(lens), None if opt is None else C.byref(opt), *[C.byref(x) for x in v]))
+    keys = ("q_gram", "stride", "in_lds", "split_len", "n_short", "q_gram2", "stride2")
+    return dict(zip(keys, (x.value for x in v)))
+
+
 # ------------------------------------------------------------------ matcher handle
 class Matcher:
     """The matcher bundle the reference drivers hold (src/cmd_extract.rs:259): construction
@@ -385,6 +402,12 @@ class Matcher:
         q, s, e, tb = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
         _check(load().mk_matcher_filter_info(self._h, C.byref(q), C.byref(s), C.byref(e), C.byref(tb)))
         return {"q_gram": q.value, "stride": s.value, "entries": e.value, "table_bytes": tb.value}
+
+    def class_info(self):
+        """length classes (matcher.cpp: plan_classes): split_len 0 = one class"""
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(load().mk_matcher_class_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"split_len": a.value, "n_short": b.value, "q_gram2": c.value, "stride2": d.value}
 
     def filter_mode(self):
         lds, fb = C.c_uint32(), C.c_uint64()

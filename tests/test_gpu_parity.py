@@ -354,7 +354,7 @@ _LENS31 = [31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 100, 257]
 @pytest.mark.parametrize("lens,options", [
     (_LENS31, dict(force_stride=16)), (_LENS31, dict(force_stride=8)), (_LENS31, dict(force_stride=4)),
     ([21, 23, 24, 25, 31, 32, 33, 48, 70], dict(force_stride=4)),
-    ([8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 65], None),          # runtime q <= 16
+    ([8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 65], dict(length_classes=1)),  # runtime q <= 16 (one class: two flavours)
     ([8, 9, 15, 16, 17, 31, 32, 33, 65], dict(force_stride=2)),
     ([25, 26, 31, 32, 33, 40, 48, 49, 65], dict(force_stride=4)),                 # runtime q in 17..32
     ([27, 31, 32, 33, 64, 65, 100], dict(force_stride=1)),

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = mk.load()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.mk_abi_version() == 3
+    assert L.mk_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -140,3 +140,35 @@ print("rc", rc, L.mk_last_error().decode())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert f"rc {mk.MK_E_NOMEM} " in r.stdout, r.stdout
+
+
+def test_geometry_plan_and_length_classes():
+    """mk_plan_geometry (host only): the filter geometry / length classes a matcher would get.  The headline set keeps
+    its geometry when one 8-mer joins it (the round-3 rule scanned that set at S = 1, q = 8); uniform sets, forced
+    strides and sets too large for the LDS filter stay one class; option validation."""
+    rnd = random.Random(7)
+    head = mk.plan_geometry([31] * 10_000)
+    assert head == {"q_gram": 24, "stride": 8, "in_lds": 1, "split_len": 0, "n_short": 0, "q_gram2": 0, "stride2": 0}
+    plus8 = mk.plan_geometry([31] * 10_000 + [8])
+    assert (plus8["q_gram"], plus8["stride"]) == (24, 8)
+    assert (plus8["split_len"], plus8["n_short"], plus8["q_gram2"], plus8["stride2"]) == (31, 1, 5, 4)
+    assert mk.plan_geometry([31] * 10_000 + [8], dict(length_classes=1))["stride"] == 1
+    assert mk.plan_geometry([31] * 10_000 + [8], dict(force_stride=1))["split_len"] == 0
+    assert mk.plan_geometry([31] * 2048)["stride"] == 16 and mk.plan_geometry([21] * 10_000)["q_gram"] == 14
+    # q-gram floor: less than one true q-gram match per 1024 random bases -> q >= 12 for 10 k patterns
+    mixed = mk.plan_geometry([rnd.randrange(15, 32) for _ in range(10_000)])
+    assert (mixed["stride"], mixed["q_gram"], mixed["split_len"]) == (4, 12, 0)
+    big = mk.plan_geometry([21] * 500_000 + [8])
+    assert big["in_lds"] == 0 and big["split_len"] == 0
+    many = mk.plan_geometry([31] * 10_000 + [10] * 100)
+    assert many["split_len"] == 31 and many["n_short"] == 100 and many["q_gram2"] >= 7
+    # a short class never samples past its shortest pattern: stride + q - 1 <= length
+    for lens in ([31] * 50 + [3], [31] * 50 + [1], [40] * 50 + [5, 9], [20] * 500 + [6] * 3):
+        g = mk.plan_geometry(lens, dict(length_classes=2))
+        assert g["split_len"] == max(lens) and g["stride2"] + g["q_gram2"] - 1 <= min(lens), (lens[-3:], g)
+    with pytest.raises(mk.MerkurioError):
+        mk.plan_geometry([31, 8], dict(force_stride2=3))
+    with pytest.raises(mk.MerkurioError):
+        mk.plan_geometry([31, 8], dict(length_classes=3))
+    with pytest.raises(mk.MerkurioError):
+        mk.plan_geometry([31, 8], dict(force_q2=9))
