@@ -304,7 +304,10 @@ def main():
     if use_dist and not rehearsal:
         ok, why = sharding.agree_on_communicator(lib, m.handle, rank, world, dev)
         if ok:
-            reduce_via = "mk_comm_reduce_counters (RCCL ncclAllReduce, C ABI)"
+            import ctypes
+            seen = ctypes.c_int(0)  # what RCCL itself says about the communicator (ncclCommCount)
+            mk._check(lib.mk_comm_size(m.handle, ctypes.byref(seen)))
+            reduce_via = f"mk_comm_reduce_counters (RCCL ncclAllReduce, C ABI; RCCL saw {seen.value} ranks)"
         else:  # same sum either way; say which path ran and why
             reduce_via = f"torch.distributed all_reduce over RCCL (C-ABI communicator unavailable: {why})"
     elif use_dist:
@@ -457,8 +460,10 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
                                          d_hits.data_ptr() if emit else None, cap, d_nh.data_ptr(), d_cnt.data_ptr(), st))
             if emit:
                 nh = int(d_nh.item())
+                if nh > cap:
+                    raise RuntimeError(f"{label}: {nh} tuples do not fit the buffer of {cap}")
                 t_o = time.perf_counter()
-                mk._check(lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), min(nh, cap), st))
+                mk._check(lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), nh, st))
                 torch.cuda.synchronize()
                 order_s.append(time.perf_counter() - t_o)
 

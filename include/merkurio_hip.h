@@ -230,10 +230,11 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
                    void *d_counters, void *stream);
 
 /* mk_scan_device only enqueues, so what a kernel finds wrong with its input comes back later: waits for `stream`,
- * then returns MK_E_UNSUPPORTED if a MK_MODE_HITS scan on this handle since the last check met an occurrence 4 GiB
- * or more into its record (mk_hit.pos cannot hold it; the flags of that scan are valid, its tuples are not), else
- * MK_OK.  mk_order_hits_device makes the same check at its own round trip; mk_scan_batch refuses such a record
- * before it scans.  The condition is cleared by the call that reports it. */
+ * then returns MK_E_UNSUPPORTED if the handle's LAST MK_MODE_HITS scan met an occurrence 4 GiB or more into its
+ * record (mk_hit.pos cannot hold it; the flags of that scan are valid, its tuples are not), else MK_OK.
+ * mk_order_hits_device makes the same check at its own round trip (from two tuples up: fewer need no ordering and are
+ * not checked there); mk_scan_batch refuses such a record before it scans.  The condition is cleared by the call that
+ * reports it and by the next MK_MODE_HITS scan on the handle. */
 int mk_matcher_check_device(mk_matcher *m, void *stream);
 
 /* Performance hint for mk_scan_device (never changes results): how many of 1000 records the caller
@@ -356,6 +357,9 @@ int mk_synth_reads_device_range(mk_matcher *m, uint64_t seed, uint64_t rec0, uin
  * copies it to host_sum (may be NULL).  d_counters[i] is a device pointer on handles[i]'s
  * device.  Handles that share a device are added on that device first; the all-reduce runs
  * over the distinct devices.  Blocking: waits for all work enqueued on those devices.
+ * Failure is total: if ncclCommInitAll fails nothing is cached; if the grouped all-reduce fails the communicators
+ * of that device list are destroyed and the next call creates them again (MK_E_RCCL either way; the vectors of
+ * handles that share a device may already hold their device-local sum).
  *
  * One process per GPU:  rank 0 calls mk_comm_unique_id and hands the id bytes to the other
  * ranks (file, MPI, torch.distributed, ...); every rank calls mk_comm_init (collective), then
@@ -368,6 +372,8 @@ int mk_comm_available(void);
 int mk_comm_unique_id(uint8_t id[MK_COMM_ID_BYTES]);
 int mk_comm_init(mk_matcher *m, const uint8_t id[MK_COMM_ID_BYTES], int rank, int n_ranks);
 int mk_comm_reduce_counters(mk_matcher *m, void *d_counters, size_t len, void *stream);
+/* ranks of the handle's communicator as RCCL reports them (ncclCommCount) */
+int mk_comm_size(const mk_matcher *m, int *n_ranks);
 int mk_comm_destroy(mk_matcher *m);
 
 #ifdef __cplusplus

@@ -50,6 +50,7 @@ def _units():
     units.append(("order_hits.o", "order_hits.hip", []))
     units.append(("order_hits_fallback.o", "order_hits_fallback.hip", []))
     units.append(("sets.o", "sets.hip", []))
+    units.append(("build_tables.o", "build_tables.hip", []))
     units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     return units
 
@@ -80,10 +81,12 @@ def _parse_resource_remarks(stderr):
     out = []
     for r in rows:
         name = r["name"]
-        try:  # readable names where binutils is installed; the mangled one otherwise
-            name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
-        except OSError:
-            pass
+        for tool in ("c++filt", "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):  # readable names; the mangled one if neither exists
+            try:
+                name = subprocess.run([tool, name], capture_output=True, text=True).stdout.strip() or name
+                break
+            except OSError:
+                continue
         out.append((name, r.get("VGPRs", "?"), r.get("AGPRs", "?"), r.get("TotalSGPRs", r.get("SGPRs", "?")),
                     r.get("ScratchSize [bytes/lane]", "?"), r.get("LDS Size [bytes/block]", "?"), r.get("Occupancy [waves/SIMD]", "?")))
     return out, "\n".join(rest) + ("\n" if rest else "")
@@ -106,7 +109,8 @@ def isa_resources(obj_dir, out_file, strict=True):
         for r in rows:
             f.write("\t".join(r) + "\n")
     # (the library sort of the fallback path, rocPRIM's merge sort, spills by itself: recorded, not refused)
-    spilled = [r[0] for r in rows if r[4] not in ("0", "?") and "rocprim::" not in r[0]]
+    # (matched in both forms: a host without a demangler keeps the mangled name, _ZN7rocprim...)
+    spilled = [r[0] for r in rows if r[4] not in ("0", "?") and "rocprim" not in r[0]]
     if spilled and strict:
         raise RuntimeError("kernels with scratch memory (register spills): " + "; ".join(spilled))
     if spilled:  # A/B and ablation builds (--tag): say so, keep going

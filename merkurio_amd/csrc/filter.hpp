@@ -132,7 +132,8 @@ MK_HD uint32_t ctx_of_pattern(const uint8_t *p, uint32_t o, uint32_t q, uint32_t
 constexpr uint32_t kShortMaxQ = 8;
 constexpr uint32_t kShortByteMaxQ = 6;  // up to here the table holds a byte per key (4 KiB), above a bit per key
 constexpr uint32_t kShortBitmapWords = (1u << (2 * kShortMaxQ)) / 32;  // 2048 words
-MK_HD uint32_t short_fp(uint32_t key) { return (key * 0x9E3779B1u) | 1u; }
+// (keys have at most 16 bits: a 24-bit multiply -- full rate on the device -- is the same product)
+MK_HD uint32_t short_fp(uint32_t key) { return ((key & 0xFFFFFFu) * 0x9E3779u) | 1u; }
 MK_HD uint32_t main_fp(uint32_t h) { return h & ~1u; }
 
 MK_HD uint8_t fold_ascii(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c | 0x20) : c; }

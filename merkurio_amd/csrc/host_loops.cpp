@@ -101,8 +101,11 @@ struct DeviceLoop {
         if ((rc = batch_upload(m, seq, off, n_rec, n_bytes, &batch_len))) return rc;
         if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload failed");
         mark(1);
-        // all tuples stay on the device: no caller-side limit
-        if ((rc = batch_scan(m, n_bytes, n_rec, mode, batch_len, std::max<uint64_t>(4096, n_rec / 8), ~0ull, &found))) return rc;
+        // all tuples stay on the device: no caller-side limit.  The scan starts with the room the handle already has
+        // (hit-dense batches -- tag / extract -l on already extracted reads -- overflowed n_rec / 8 on EVERY batch and
+        // ran their scan twice; after the first such batch one scan suffices)
+        const uint64_t cap0 = std::max<uint64_t>(std::max<uint64_t>(4096, n_rec / 8), m->d_hits_cap / sizeof(mk_hit));
+        if ((rc = batch_scan(m, n_bytes, n_rec, mode, batch_len, cap0, ~0ull, &found))) return rc;
         mark(2);
         if ((rc = batch_flags(m, n_rec, flags, flagged))) return rc;
         mark(1);
@@ -195,6 +198,8 @@ struct DeviceLoop {
     // the distinct patterns of every record (tuples in set order).  found_off == nullptr: only the counts.
     int pattern_sets(uint64_t n_rec, uint64_t *found_off, uint32_t *found_pat, uint64_t found_cap, uint64_t *n_found, uint32_t *counts) {
         const uint32_t n_pat = m->n_pat;
+        // (the set kernels rank run heads and sum tiles in 32 bits, sets.hip)
+        if (found >= (1ull << 32)) return fail(MK_E_UNSUPPORTED, "%llu occurrences in one batch: the per-record pattern sets take at most 2^32 - 1", found);
         const size_t off_bytes = (n_rec + 1) * 8, pat_bytes = ((size_t)found * 4 + 15) & ~(size_t)15;
         const size_t tiles = std::max<size_t>((found + 4095) / 4096, (n_rec + 1 + 4095) / 4096) + 1;
         const size_t cnt_bytes = ((size_t)n_pat * 4 + 15) & ~(size_t)15;

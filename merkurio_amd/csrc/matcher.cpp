@@ -123,12 +123,6 @@ static void choose_geometry(uint32_t lmin, uint64_t n_pat, const mk_matcher_opti
     *gblocks = (uint32_t)blocks;
 }
 
-uint64_t pack_qgram(const uint8_t *p, uint32_t q) {
-    uint64_t k = 0;
-    for (uint32_t i = 0; i < q; ++i) k |= (uint64_t)code2(p[i]) << (2 * i);
-    return k;
-}
-
 // ---- length classes ---------------------------------------------------------------------------
 // One geometry for the whole set is dictated by its SHORTEST pattern: 10 000 31-mers next to one
 // 8-mer scan at S=1, q=8 -- 71.7 ms per 15 GB instead of 2.4 (profiles/r04_mixed_sets.txt), where
@@ -385,61 +379,12 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     if (slots > (1ull << 27))  // bucket index has 26 bits: at most 2^26 table entries (patterns x stride)
         return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", (unsigned long long)m->entries);
     m->table_slots = (uint32_t)slots;
-    const uint32_t gmask = m->gbloom_blocks;  // number of blocks
-    std::vector<uint32_t> bloom(m->gbloom_blocks ? (size_t)m->gbloom_blocks * 2 : (size_t)kBloomWords, 0);
-    std::vector<TableEntry> table(slots);
-    for (auto &e : table) {
-        e.fp = 0;
-        e.pat_off = kEmptyPat;
-    }
-    const uint32_t bmask = m->table_slots / kBucketEntries - 1;  // bucket index mask
     const bool gf_ctx = m->gbloom_blocks != 0 && gf_has_ctx(S, q_f);
     const bool two = plan.split != 0;
-    std::vector<uint32_t> short_table(two ? kShortBitmapWords : 0, 0);
-    for (uint32_t pi = 0; pi < n_pat; ++pi) {
-        const uint8_t *p = pat_bytes + pat_off[pi];
-        const bool is_short = two && pat_off[pi + 1] - pat_off[pi] < plan.split;
-        for (uint32_t o = 0; o < (is_short ? plan.S2 : S); ++o) {
-            const uint64_t key = pack_qgram(p + o, is_short ? plan.q2 : q_f);
-            uint32_t h = bloom_hash((uint32_t)key, (uint32_t)(key >> 32));
-            // level-2 fingerprint: the filter hash, or (context kernels) that hash mixed with the
-            // pattern bases around the q-gram; two classes: bit 0 says which class's samples may verify it
-            uint32_t fp = gf_ctx ? ctx_fp(h, ctx_of_pattern(p, o, q_f, S) & ctx_mask(o, S)) : h;
-            if (two) fp = is_short ? short_fp((uint32_t)key) : main_fp(h);
-            if (is_short) {  // level 1 of the short class: the table over its packed keys, nothing in the Bloom filter
-                if (plan.q2 <= kShortByteMaxQ)
-                    reinterpret_cast<uint8_t *>(short_table.data())[key] = 1;
-                else
-                    short_table[key >> 5] |= 1u << (key & 31);
-                h = fp;  // (home bucket below)
-            } else if (m->gbloom_blocks) {
-                const size_t blk = (size_t)gbloom_block(h, gmask) * 2;
-                const uint32_t hb = gbloom_bits(h);
-                bloom[blk] |= (1u << bloom_bit_a(hb)) | (1u << bloom_bit_d(hb));
-                bloom[blk + 1] |= (1u << bloom_bit_b(hb)) | (1u << bloom_bit_c(hb));
-            } else {
-                const uint32_t blk = bloom_block_byte(h) >> 2;  // index of the block's low word
-                bloom[blk] |= 1u << bloom_bit_a(h);
-                bloom[blk + 1] |= (1u << bloom_bit_b(h)) | (1u << bloom_bit_c(h));
-            }
-            uint32_t b = table_bucket(two ? fp : h, bmask);
-            for (;;) {  // first bucket from the home bucket on with a free entry
-                TableEntry *e = &table[(size_t)b * kBucketEntries];
-                uint32_t k = 0;
-                while (k < kBucketEntries && e[k].pat_off != kEmptyPat) ++k;
-                if (k < kBucketEntries) {
-                    e[k].fp = fp;
-                    e[k].pat_off = (pi << 4) | o;
-                    break;
-                }
-                e[0].pat_off |= kBucketOverflow;  // a lookup that reaches this bucket must look further
-                b = (b + 1) & bmask;
-            }
-        }
-    }
+    const size_t bloom_words = m->gbloom_blocks ? (size_t)m->gbloom_blocks * 2 : (size_t)kBloomWords;
     // (a failing MK_HIP returns; `owner` then releases whatever was allocated so far)
     MK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    MK_HIP(hipMalloc((void **)&m->d_bloom, bloom.size() * sizeof(uint32_t)));
+    MK_HIP(hipMalloc((void **)&m->d_bloom, bloom_words * sizeof(uint32_t)));
     MK_HIP(hipMalloc((void **)&m->d_table, slots * sizeof(TableEntry)));
     MK_HIP(hipMalloc((void **)&m->d_pat_bytes, m->pat_bytes.size() + 16));
     MK_HIP(hipMalloc((void **)&m->d_pat_off, (n_pat + 1) * sizeof(uint32_t)));
@@ -451,22 +396,52 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     MK_HIP(hipMalloc((void **)&m->d_stage, (size_t)m->num_cus * (kBlockThreads / 64) * kHitStage * sizeof(mk_hit)));
     MK_HIP(hipMalloc((void **)&m->d_flag_list, (size_t)m->num_cus * (kBlockThreads / 64) * kFlagListCap * sizeof(uint32_t)));
     MK_HIP(hipMalloc((void **)&m->d_flag_counts, (size_t)m->num_cus * (kBlockThreads / 64) * sizeof(uint32_t)));
-    MK_HIP(hipMemcpy(m->d_bloom, bloom.data(), bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    MK_HIP(hipMemcpy(m->d_table, table.data(), slots * sizeof(TableEntry), hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(m->d_pat_bytes, m->pat_bytes.data(), m->pat_bytes.size(), hipMemcpyHostToDevice));
+    MK_HIP(hipMemsetAsync(m->d_pat_bytes + m->pat_bytes.size(), 0, 16, m->stream));  // (level 3 may read up to 15 bytes past a pattern)
     MK_HIP(hipMemcpy(m->d_pat_off, m->pat_off.data(), (n_pat + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // filter images + exact table: built on the device from the patterns just uploaded (build_tables.hip; r04 --
+    // one host thread took 0.43 s for the 4 M entries of 500 k 21-mers, profiles/r02_compile_time.txt)
+    MK_HIP(hipMemsetAsync(m->d_bloom, 0, bloom_words * sizeof(uint32_t), m->stream));
     if (two) {
         MK_HIP(hipMalloc((void **)&m->d_short_table, kShortBitmapWords * sizeof(uint32_t)));
-        MK_HIP(hipMemcpy(m->d_short_table, short_table.data(), kShortBitmapWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+        MK_HIP(hipMemsetAsync(m->d_short_table, 0, kShortBitmapWords * sizeof(uint32_t), m->stream));
+    }
+    {
+        BuildParams B;
+        memset(&B, 0, sizeof(B));
+        B.pat_bytes = m->d_pat_bytes;
+        B.pat_off = m->d_pat_off;
+        B.n_pat = n_pat;
+        B.S = S;
+        B.q = q_f;
+        B.split = plan.split;
+        B.S2 = plan.S2;
+        B.q2 = plan.q2;
+        B.gbloom_blocks = m->gbloom_blocks;
+        B.gf_ctx = gf_ctx ? 1 : 0;
+        B.bloom = m->d_bloom;
+        B.table = m->d_table;
+        B.bucket_mask = m->table_slots / kBucketEntries - 1;
+        B.short_table = m->d_short_table;
+        launch_build_tables(B, slots, m->stream);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipStreamSynchronize(m->stream));
     }
     if (use == MK_ALGO_AC && !m->uniform_len) {
         // matches that end on one byte are emitted longest first, then by pattern id (aho-corasick's overlapping
         // DFA walk, src/cmd_extract.rs:332-351): that tie order as a rank the device sort can use as a key field
         std::vector<uint32_t> unrank(n_pat), rank(n_pat);
-        for (uint32_t i = 0; i < n_pat; ++i) unrank[i] = i;
-        std::stable_sort(unrank.begin(), unrank.end(), [pat_off](uint32_t a, uint32_t b) {
-            return pat_off[a + 1] - pat_off[a] > pat_off[b + 1] - pat_off[b];
-        });
+        if (lmax <= (1u << 20)) {  // stable counting sort on the length, longest first
+            std::vector<uint32_t> start((size_t)lmax + 2, 0);
+            for (uint32_t i = 0; i < n_pat; ++i) start[lmax - (pat_off[i + 1] - pat_off[i]) + 1]++;
+            for (uint32_t l = 0; l <= lmax; ++l) start[l + 1] += start[l];
+            for (uint32_t i = 0; i < n_pat; ++i) unrank[start[lmax - (pat_off[i + 1] - pat_off[i])]++] = i;
+        } else {
+            for (uint32_t i = 0; i < n_pat; ++i) unrank[i] = i;
+            std::stable_sort(unrank.begin(), unrank.end(), [pat_off](uint32_t a, uint32_t b) {
+                return pat_off[a + 1] - pat_off[a] > pat_off[b + 1] - pat_off[b];
+            });
+        }
         for (uint32_t r = 0; r < n_pat; ++r) rank[unrank[r]] = r;
         MK_HIP(hipMalloc((void **)&m->d_pat_rank, n_pat * sizeof(uint32_t)));
         MK_HIP(hipMalloc((void **)&m->d_pat_unrank, n_pat * sizeof(uint32_t)));
@@ -542,6 +517,9 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     MK_HIP(hipSetDevice(m->device));
     launch_clear((uint32_t *)d_rec_flags, (n_rec + 3) / 4, (unsigned long long *)d_n_hits, st);  // also clears *d_n_hits
     MK_HIP(hipGetLastError());
+    // the sticky error word belongs to the handle's LAST tuple scan: an earlier batch's condition must not make
+    // mk_order_hits_device refuse the tuples of this one (it is reported by whichever check comes first)
+    if (mode == MK_MODE_HITS) MK_HIP(hipMemsetAsync(m->d_error, 0, sizeof(uint32_t), st));
     m->last_n_rec = n_rec;
     if (n_rec == 0 || n_bytes == 0) return MK_OK;
     ScanParams p;
@@ -565,6 +543,7 @@ int mk_scan_device(mk_matcher *m, const void *d_seq, uint64_t n_bytes, const voi
     p.key_mask_hi = (uint32_t)(kmask >> 32);
     p.case_insensitive = (m->flags & MK_FLAG_ASCII_CASE_INSENSITIVE) ? 1 : 0;
     p.s2 = m->split_len ? m->S2 : 0;
+    p.s2_log2 = m->S2 >= 8 ? 3 : m->S2 >= 4 ? 2 : m->S2 >= 2 ? 1 : 0;
     p.key2_mask = (1u << (2 * m->q2)) - 1u;
     p.short_bytes = m->q2 <= kShortByteMaxQ;
     p.short_bitmap = m->d_short_table;

@@ -37,6 +37,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
 ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count);
 ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
                            hipStream_t stream);
 ncclResult_t ncclGroupStart(void);
@@ -76,6 +77,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;  // optional: only mk_comm_size asks for it
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -119,6 +121,7 @@ Rccl *rccl() {
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
     if (!ok) return nullptr;
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.lib = h;
     return &g_rccl;
 }
@@ -177,30 +180,46 @@ int mk_reduce_counters(mk_matcher *const *per_gpu, int n, void *const *d_counter
         launch_add_u64((unsigned long long *)d_counters[leader[i]], (const unsigned long long *)d_counters[i], len, L->stream);
         MK_HIP_R(hipGetLastError());
     }
-    std::vector<ncclComm_t> *comms;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_comm_sets.find(devs);
-        if (it == g_comm_sets.end()) {
-            std::vector<ncclComm_t> c(devs.size());
-            MK_NCCL(R, R->CommInitAll(c.data(), (int)devs.size(), devs.data()));
-            it = g_comm_sets.emplace(devs, std::move(c)).first;
-        }
-        comms = &it->second;
+    // The communicator set of this device list is created once and kept -- but only while it works: a set whose
+    // collective failed is destroyed and forgotten, so that the failure is total (nothing half-initialised stays
+    // cached) and the next call starts from ncclCommInitAll again.  A failing ncclCommInitAll caches nothing either:
+    // RCCL creates all ranks of the list or none.  One reduction at a time per process (g_mu).
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_comm_sets.find(devs);
+    if (it == g_comm_sets.end()) {
+        std::vector<ncclComm_t> c(devs.size(), nullptr);
+        MK_NCCL(R, R->CommInitAll(c.data(), (int)devs.size(), devs.data()));
+        it = g_comm_sets.emplace(devs, std::move(c)).first;
     }
-    MK_NCCL(R, R->GroupStart());
+    std::vector<ncclComm_t> *comms = &it->second;
+    auto drop_set = [&]() {
+        for (ncclComm_t c : *comms)
+            if (c) (void)R->CommDestroy(c);
+        g_comm_sets.erase(it);
+    };
+    ncclResult_t r = R->GroupStart();
+    if (r != ncclSuccess) {
+        drop_set();
+        return rccl_fail(R, r, "ncclGroupStart");
+    }
     for (size_t k = 0; k < devs.size(); ++k) {
         int li = 0;
         for (int i = 0; i < n; ++i)
             if (leader[i] == i && per_gpu[i]->device == devs[k]) li = i;
-        MK_HIP_R(hipSetDevice(devs[k]));
-        ncclResult_t r = R->AllReduce(d_counters[li], d_counters[li], len, ncclUint64, ncclSum, (*comms)[k], per_gpu[li]->stream);
-        if (r != ncclSuccess) {
-            (void)R->GroupEnd();
-            return rccl_fail(R, r, "ncclAllReduce");
+        hipError_t e = hipSetDevice(devs[k]);
+        if (e == hipSuccess)
+            r = R->AllReduce(d_counters[li], d_counters[li], len, ncclUint64, ncclSum, (*comms)[k], per_gpu[li]->stream);
+        if (e != hipSuccess || r != ncclSuccess) {
+            (void)R->GroupEnd();  // closes the group; whatever it launched belongs to communicators that are dropped now
+            drop_set();
+            return e != hipSuccess ? hip_fail(e, "hipSetDevice") : rccl_fail(R, r, "ncclAllReduce");
         }
     }
-    MK_NCCL(R, R->GroupEnd());
+    r = R->GroupEnd();
+    if (r != ncclSuccess) {
+        drop_set();
+        return rccl_fail(R, r, "ncclGroupEnd");
+    }
     // every vector holds the sum on return
     for (int i = 0; i < n; ++i) {
         if (leader[i] == i) continue;
@@ -261,6 +280,15 @@ int mk_comm_reduce_counters(mk_matcher *m, void *d_counters, size_t len, void *s
     if (!R) return fail(MK_E_RCCL, "%s", g_rccl.why);
     MK_HIP_R(hipSetDevice(m->device));
     MK_NCCL(R, R->AllReduce(d_counters, d_counters, len, ncclUint64, ncclSum, (ncclComm_t)m->comm, (hipStream_t)stream));
+    return MK_OK;
+}
+
+int mk_comm_size(const mk_matcher *m, int *n_ranks) {
+    if (!m || !n_ranks) return fail(MK_E_INVALID_ARG, "null argument");
+    if (!m->comm) return fail(MK_E_INVALID_ARG, "mk_comm_init has not been called on this matcher");
+    *n_ranks = m->comm_size;
+    Rccl *R = rccl();
+    if (R && R->CommCount) MK_NCCL(R, R->CommCount((ncclComm_t)m->comm, n_ranks));  // what RCCL itself says
     return MK_OK;
 }
 

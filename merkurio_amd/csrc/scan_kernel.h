@@ -31,6 +31,7 @@ struct ScanParams {
     // second length class (MC kernels; s2 == 0: none): stride, key mask of its q2 <= 8 base q-grams, table over the
     // packed keys (kShortBitmapWords words, device memory; staged in LDS by every workgroup)
     uint32_t s2;
+    uint32_t s2_log2;
     uint32_t key2_mask;
     uint32_t short_bytes;  // 1: the table holds one byte per key (q2 <= 6), 0: one bit per key
     const uint32_t *short_bitmap;
@@ -141,6 +142,23 @@ void launch_rows(const mk_hit *d_hits, uint64_t n, uint32_t file, mk_row *d_rows
 void launch_pair_mark(mk_hit *d_hits, uint64_t n, uint32_t mate, bool ac, hipStream_t st);
 void launch_rows_pair(const mk_hit *d_hits, uint64_t n, bool ac, mk_row *d_rows, hipStream_t st);
 void launch_count_pair_heads(const mk_hit *d_hits, uint64_t n, uint32_t *d_counts, uint32_t n_bins, hipStream_t st);
+
+// ---- build_tables.hip: the pattern set compiled into filter images + exact table on the device -----------------
+struct BuildParams {
+    const uint8_t *pat_bytes;  // device
+    const uint32_t *pat_off;   // device, n_pat + 1
+    uint32_t n_pat;
+    uint32_t S, q;             // main class
+    uint32_t split, S2, q2;    // length classes (split == 0: one class)
+    uint32_t gbloom_blocks;    // != 0: the filter is a global-memory image of this many 64-bit blocks
+    uint32_t gf_ctx;           // context fingerprints (filter.hpp: gf_has_ctx)
+    uint32_t *bloom;           // zeroed: kBloomWords words (LDS image) or 2 * gbloom_blocks
+    TableEntry *table;         // (bucket_mask + 1) * kBucketEntries slots; cleared by launch_build_tables
+    uint32_t bucket_mask;
+    uint32_t *short_table;     // zeroed kShortBitmapWords words (two classes only)
+};
+// clears the table and inserts every (pattern, offset) entry; the filter images must be zero
+void launch_build_tables(const BuildParams &B, uint64_t n_slots, hipStream_t st);
 
 // counts the flagged records of the scan into counters[n_pat + MK_SUM_RECORDS_HIT]
 void launch_count_flags(const ScanParams &p, hipStream_t stream);

@@ -248,8 +248,9 @@ __device__ __forceinline__ bool resolve_one(const ScanParams &P, uint32_t pat, u
         out.pat = pat;
         out.pos = (uint32_t)(p - rstart);
         // mk_hit.pos is 32 bits: an occurrence 4 GiB or more into its record cannot be reported -- say so instead of
-        // wrapping (the host returns MK_E_UNSUPPORTED at its next round trip: mk_matcher_check_device / mk_scan_batch
-        // / mk_order_hits_device)
+        // wrapping (the host returns MK_E_UNSUPPORTED at its next round trip: mk_matcher_check_device /
+        // mk_order_hits_device; mk_scan_batch refuses such a record before it scans.  The word is cleared at the
+        // start of every tuple scan: it describes the handle's last one)
         if (p - rstart > 0xFFFFFFFFull) atomicOr(P.error_word, 1u);
     }
     return true;
@@ -523,16 +524,20 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     using G = Geo<S, QC, kCtx, MC>;
     constexpr bool kPipe = kCtx && G::kNS <= 2 && (MK_ABLATE & 7) == 0;
     constexpr bool kWide = FL == 0;  // hit-dense flavour: flags stored directly (drain_hits)
-    __shared__ __attribute__((aligned(16))) uint32_t bloom[(kLdsBytes + (MC ? kShortBitmapBytes : 0)) / 4];  // filter + candidate rings (+ short-class bitmap)
+    // MC kernels: the short class's table comes FIRST (its ds_read_u8 / ds_read_b32 then carry their base as the
+    // instruction's 16-bit offset; behind the 128 KiB filter every probe paid a v_add for it), the filter behind it
+    constexpr uint32_t kShortWords = MC ? kShortBitmapWords : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[kShortWords + kLdsBytes / 4];  // (short-class table +) filter + candidate rings
+    uint32_t *const bloom = lds_all + kShortWords;
     uint32_t *lds_sums = bloom + kBloomWords;  // wave 0's candidate ring, once every wave is done with its own
-    const uint32_t *short_bm = bloom + kLdsBytes / 4;  // MC
+    const uint32_t *short_bm = lds_all;  // MC
     if constexpr (!GF) {  // stage the filter image of the pattern set in LDS
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
         for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
         if constexpr (MC) {
             const uint4 *src2 = reinterpret_cast<const uint4 *>(P.short_bitmap);
-            uint4 *dst2 = reinterpret_cast<uint4 *>(bloom + kLdsBytes / 4);
+            uint4 *dst2 = reinterpret_cast<uint4 *>(lds_all);
             for (uint32_t i = threadIdx.x; i < kShortBitmapWords / 4; i += kBlockThreads) dst2[i] = src2[i];
         }
         __syncthreads();
@@ -616,6 +621,11 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         }
         if constexpr (MC) {  // the short class's samples: bits 16.. of the mask (wave-uniform stride)
             uint32_t c2;
+#if defined(MK_MC_ABL) && MK_MC_ABL == 1  // profiling builds: the two-class kernel without its short-class samples
+            c2 = 0;
+#elif defined(MK_MC_ABL) && MK_MC_ABL == 2  // ... with one compile-time geometry instead of the switch
+            c2 = short_filter<4, true>(short_bm, w0, w1, P.key2_mask);
+#else
             if (P.short_bytes) {
                 switch (P.s2) {
                     case 1: c2 = short_filter<1, true>(short_bm, w0, w1, P.key2_mask); break;
@@ -631,6 +641,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     default: c2 = short_filter<8, false>(short_bm, w0, w1, P.key2_mask); break;
                 }
             }
+#endif
             cand |= c2 << 16;
         }
         if constexpr ((MK_ABLATE & 1) != 0) {  // keep the filter work alive, drop its result
@@ -725,10 +736,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             if (cand != 0) {
                 const uint32_t j = (uint32_t)__ffs(cand) - 1u;
                 cand &= cand - 1;
-                if (MC && j >= 16u) {  // a sample of the short class: its fingerprint is its packed key (filter.hpp)
-                    const uint32_t sh = 2u * (j - 16u) * P.s2;
-                    slot_h = short_fp(__builtin_amdgcn_alignbit(w1, w0, sh) & P.key2_mask);
-                } else if constexpr (NS <= 2) {
+                if constexpr (NS <= 2) {
                     slot_h = j ? h1 : h0;
                 } else {  // same value as sample_hash / filter.hpp's bloom_hash of the masked key
                     const uint32_t sh = 2u * j * S;
@@ -745,10 +753,14 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                 }
                 slot_t = t_base + j * S;
                 if constexpr (MC) {
-                    if (j >= 16u)
-                        slot_t = t_base + (j - 16u) * P.s2;
-                    else
-                        slot_h = main_fp(slot_h);
+                    // bits 16.. of the mask are the short class's samples: fingerprint = its packed key (filter.hpp).
+                    // Both forms are computed and one is selected: a branch here diverges (the lanes of a wave hold
+                    // candidates of both classes) and would run both sides anyway.
+                    const uint32_t j2 = (j - 16u) << P.s2_log2;  // base offset of the short sample inside the lane's 16
+                    const uint32_t fp2 = short_fp(__builtin_amdgcn_alignbit(w1, w0, 2u * j2) & P.key2_mask);
+                    const bool is2 = j >= 16u;
+                    slot_h = is2 ? fp2 : main_fp(slot_h);
+                    slot_t = is2 ? t_base + j2 : slot_t;
                 }
                 slot_full = true;
             }

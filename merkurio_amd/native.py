@@ -50,7 +50,7 @@ EXPORTS = [
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
     "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
-    "mk_comm_reduce_counters", "mk_comm_destroy",
+    "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
 ]
 
 
@@ -159,6 +159,7 @@ def load(build_if_missing=True):
     L.mk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.mk_comm_reduce_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.mk_comm_destroy.argtypes = [C.c_void_p]
+    L.mk_comm_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.mk_scan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_uint64, C.POINTER(C.c_uint64)]
     L.mk_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,

@@ -265,3 +265,82 @@ def test_ranks_set_up_the_rccl_communicator_or_fall_back_together(tmp_path):
         assert r0["total"] == r1["total"] and set(r0["total"]) == {3}
     else:
         assert not r0["ok"] and r0["why"], r0
+
+
+_FAKE_CHILD = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+os.environ["MERKURIO_SYSTEM_HIP"] = "1"  # no torch in this process: nothing has mapped the real librccl
+from merkurio_amd import native as mk
+lib = mk.load()
+fake = C.CDLL("librccl.so.1")
+assert hasattr(fake, "fake_rccl_live_comms"), "the real librccl was bound"
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+ms = [mk.Matcher([b"ACGTACGTACGTACGTACGTA"], device=0) for _ in range(3)]
+n = 9
+vec = []
+for i in range(3):
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), n * 8) == 0
+    v = np.arange(n, dtype=np.uint64) * (i + 1)
+    assert hip.hipMemcpy(p, v.ctypes.data, n * 8, 1) == 0
+    vec.append(p)
+handles = (C.c_void_p * 3)(*[m.handle for m in ms])
+ptrs = (C.c_void_p * 3)(*vec)
+out = np.zeros(n, dtype=np.uint64)
+def reduce():
+    return lib.mk_reduce_counters(handles, 3, ptrs, n, out.ctypes.data)
+# 1. ncclCommInitAll fails (having written garbage into the first slot): MK_E_RCCL, nothing cached, nothing destroyed
+os.environ["FAKE_RCCL_FAIL"] = "initall"
+assert reduce() == mk.MK_E_RCCL and b"CommInitAll" in lib.mk_last_error(), lib.mk_last_error()
+assert fake.fake_rccl_live_comms() == 0 and fake.fake_rccl_calls(2) == 0
+# 2. the grouped all-reduce fails: MK_E_RCCL, the communicator set is destroyed, not kept
+os.environ["FAKE_RCCL_FAIL"] = "allreduce"
+assert reduce() == mk.MK_E_RCCL and b"AllReduce" in lib.mk_last_error()
+assert fake.fake_rccl_live_comms() == 0 and fake.fake_rccl_calls(0) == 2
+os.environ["FAKE_RCCL_FAIL"] = "groupend"
+assert reduce() == mk.MK_E_RCCL and b"GroupEnd" in lib.mk_last_error()
+assert fake.fake_rccl_live_comms() == 0 and fake.fake_rccl_calls(0) == 3
+# 3. RCCL works again: a fresh set is created, kept and reused
+os.environ["FAKE_RCCL_FAIL"] = ""
+for v, p in zip(range(3), vec):  # (the failed attempts had already added the device-local vectors together)
+    a = np.arange(n, dtype=np.uint64) * (v + 1)
+    assert hip.hipMemcpy(p, a.ctypes.data, n * 8, 1) == 0
+assert reduce() == 0, lib.mk_last_error()
+assert out.tolist() == (np.arange(n) * 6).tolist()
+assert fake.fake_rccl_live_comms() == 1 and fake.fake_rccl_calls(0) == 4
+assert reduce() == 0 and fake.fake_rccl_calls(0) == 4  # cached
+# 4. one process per GPU: a failing ncclCommInitRank leaves the handle without a communicator; a good one reports its size
+ident = (C.c_uint8 * 128)()
+assert lib.mk_comm_unique_id(ident) == 0
+os.environ["FAKE_RCCL_FAIL"] = "initrank"
+assert lib.mk_comm_init(ms[0].handle, ident, 0, 1) == mk.MK_E_RCCL
+assert lib.mk_comm_reduce_counters(ms[0].handle, vec[0], n, None) == mk.MK_E_INVALID_ARG
+os.environ["FAKE_RCCL_FAIL"] = ""
+assert lib.mk_comm_init(ms[0].handle, ident, 0, 1) == 0
+k = C.c_int()
+assert lib.mk_comm_size(ms[0].handle, C.byref(k)) == 0 and k.value == 1
+os.environ["FAKE_RCCL_FAIL"] = "allreduce"
+assert lib.mk_comm_reduce_counters(ms[0].handle, vec[0], n, None) == mk.MK_E_RCCL
+os.environ["FAKE_RCCL_FAIL"] = ""
+assert lib.mk_comm_reduce_counters(ms[0].handle, vec[0], n, None) == 0
+assert lib.mk_comm_destroy(ms[0].handle) == 0 and fake.fake_rccl_live_comms() == 1
+print("fake-rccl ok")
+'''
+
+
+def test_reduction_failure_modes_are_total(tmp_path):
+    """mk_reduce_counters / mk_comm_* against a fake librccl with failure injection (tests/fake_rccl/fake_rccl.c, bound
+    through reduce.cpp's dlopen-by-soname seam in a child process): a failing ncclCommInitAll caches nothing, a failing
+    grouped ncclAllReduce / ncclGroupEnd destroys the communicator set instead of keeping it, the next call starts
+    over and succeeds; a failing ncclCommInitRank leaves the handle without a communicator.  (The multi-device
+    branches themselves have never run on hardware: the pool's boxes have one GPU, DESIGN.md §7.)"""
+    so = tmp_path / "librccl.so.1"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wl,-soname,librccl.so.1", "-o", str(so),
+                    os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.c")], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{tmp_path}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+    r = subprocess.run([sys.executable, "-c", _FAKE_CHILD, ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fake-rccl ok" in r.stdout, r.stdout + r.stderr

@@ -97,12 +97,20 @@ def main():
     lib = mk.load()
     sets = pattern_sets(mk, bench)
     names = ["headline", "plus8", "len15_31", "short1_3", "s16", "s8", "s4", "s2", "s1"]
+    # calibration of the short class's cost model: the same set at other strides / table kinds (only with --only)
+    variants = {"plus8_s2bit": dict(length_classes=2, force_stride2=2), "plus8_s2byte": dict(length_classes=2, force_stride2=2, force_q2=6),
+                "plus8_s1bit": dict(length_classes=2, force_stride2=1), "plus8_s1byte": dict(length_classes=2, force_stride2=1, force_q2=6),
+                "plus8_s4q4": dict(length_classes=2, force_stride2=4, force_q2=4)}
+    if args.only:
+        names += list(variants)
     if args.only:
         names = [n for n in names if n in args.only.split(",")]
     for name in names:
         opts = {}
         if name.startswith("s") and name[1:].isdigit():
             pats, opts = sets["headline"], {"force_stride": int(name[1:])}
+        elif name in variants:
+            pats, opts = sets["plus8"], dict(variants[name])
         else:
             pats = sets[name]
         if args.single_class and "force_single_class" in mk.MatcherOptions.__init__.__code__.co_varnames:
