@@ -488,10 +488,16 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
         k_ms = float(np.mean(m.kernel_times_ms()))
         algo = n_bytes + 9 * n_rec
         summ = d_cnt.cpu().numpy()[n_pat:]
-        r = {"workload": label, "kernel": m.kernel_name, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+        info = dict(m.filter_info(), **m.class_info())
+        r = {"workload": label, "kernel": m.kernel_name, "filter": info, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
              "value_gbases_per_s": round(n_bytes * steps / dt / 1e9, 1), "kernel_ms": round(k_ms, 4),
              "algorithmic_bytes_per_launch": algo, "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-             "records_hit_per_launch": int(summ[mk.MK_SUM_RECORDS_HIT]) // steps, "hits_per_launch": int(summ[mk.MK_SUM_HITS]) // steps}
+             "records_hit_per_launch": int(summ[mk.MK_SUM_RECORDS_HIT]) // steps, "hits_per_launch": int(summ[mk.MK_SUM_HITS]) // steps,
+             "filter_candidates_per_launch": int(summ[mk.MK_SUM_CANDIDATES]) // steps}
+        # counter traffic exists for workloads that were profiled under rocprofv3 with this kernel source (profiles/traffic_*.json)
+        r["traffic"], r["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, n_pat)
+        if r["traffic"] is None and r["traffic_source"] is None:
+            r["traffic_source"] = "no committed PMC profile of this workload (tools/profile_gpu.sh writes one per workload it is run on)"
         if emit:
             o_ms = float(np.mean(order_s)) * 1e3
             r["order_ms"] = round(o_ms, 4)
@@ -508,6 +514,23 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
         if pe == 1:  # tag / extract -l on already extracted reads: every tuple, in emission order
             run(f"headline batch, {what}: {n_rec0} x {L0} bp, {len(m0.patterns)} 31-mers, every hit tuple in emission order", m0, d_seq,
                 d_off, d_flags, n_rec0, L0, len(m0.patterns), True, pe)
+    # ---- pattern sets of MIXED lengths (the reference's DFA scans any list at one speed, src/cmd_extract.rs:260-265).
+    # Until r04 the whole set ran at the stride its SHORTEST pattern admits; now the short patterns form a class of
+    # their own next to the main filter (matcher.cpp: plan_classes) and the q-gram floor follows the pattern count.
+    import numpy as np
+    plus8 = mk.parse_pattern_list(kmer_seq=list(m0.patterns) + [b"GATTACAG"])
+    rng = np.random.default_rng(77)
+    mixed = mk.parse_pattern_list(kmer_seq=[p[:int(rng.integers(15, 32))] for p in make_patterns(10_000, 31, seed=5)])
+    tiny = mk.parse_pattern_list(kmer_seq=[b"A", b"AA", b"AC", b"AG", b"C", b"CT", b"CTC", b"G", b"GA", b"GAG", b"GT", b"T", b"TC", b"TT"])
+    for pats, n_r, what in (
+            (plus8, n_rec0, f"{len(m0.patterns)} 31-mers + ONE 8-mer (r03 geometry: S=1, q=8 for the whole set, 71.7 ms)"),
+            (mixed, n_rec0, f"{len(mixed)} patterns of 15..31 bases, uniform (r03 geometry: S=2, q=14, 4.15 ms)"),
+            (tiny, min(n_rec0, 10_000_000), "the 14 patterns of 1-3 bases of the reference's Aho-Corasick golden (tests/fixtures/extract/log.json): "
+                                           "1.5 occurrences per base, bound by the occurrence rate, not by the stream")):
+        mm = mk.Matcher(pats, device=dev_index)
+        mk._check(lib.mk_synth_reads_device_range(mm.handle, seed, 0, n_r, L0, 100, d_seq.data_ptr(), d_off.data_ptr(), st))
+        run(f"mixed lengths: {n_r} x {L0} bp, {what}, any-hit flags", mm, d_seq, d_off, d_flags, n_r, L0, len(pats), False, 100)
+        mm.close()
     del d_seq, d_off, d_flags
 
     def fresh(n_rec, L, n_pat, k, rc, plant_every, s):

@@ -157,11 +157,13 @@ static double short_cost(uint32_t S2, uint32_t q2, uint64_t n) {
 // lens: pattern lengths (any order).  Only sets whose main class fits the LDS filter are split.
 static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_options &opt) {
     ClassPlan best;
-    std::sort(lens.begin(), lens.end());
     const uint64_t n = lens.size();
+    const auto mm = std::minmax_element(lens.begin(), lens.end());
     best.n_main = n;
-    best.lmin_main = lens[0];
-    if (opt.length_classes == 1 || opt.force_global_filter || n > kMaxLdsEntries || lens[0] == lens[n - 1]) return best;
+    best.lmin_main = *mm.first;
+    // (k-mer lists -- one length -- and sets beyond the LDS filter leave here without sorting half a million lengths)
+    if (opt.length_classes == 1 || opt.force_global_filter || n > kMaxLdsEntries || *mm.first == *mm.second) return best;
+    std::sort(lens.begin(), lens.end());
     if (opt.force_stride && opt.length_classes != 2 && !opt.force_split_len) return best;  // a forced stride means the whole set
     best.cost = main_cost(lens[0], n, opt);
     const double single = best.cost;

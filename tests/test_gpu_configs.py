@@ -183,6 +183,85 @@ def test_headline_full_size_properties(mk):
         sel = (hits["rec"] >= rec0) & (hits["rec"] < rec0 + M)
         assert int(sel.sum()) == c["hits"][0]
 
+    # THE LAUNCH bench.py TIMES: the same batch as a fixed-length batch -- mk_matcher_set_fixed_record_length(150) and
+    # NO offsets array (d_seq_off = NULL).  Same flags as the offsets path (which the oracle has just checked on
+    # three 300 k-record slices), same counters, and the same tuples in emission order.
+    assert lib.mk_matcher_set_fixed_record_length(m.handle, L) == 0
+
+    def scan_fixed(mode, cap=0):
+        flags = torch.empty((n_rec + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        hits_t = torch.empty(max(cap, 1) * 2, dtype=torch.int64, device=dev)
+        nh_t = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(npat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        rc = lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes, None, n_rec, mode, flags.data_ptr(), hits_t.data_ptr(), cap,
+                                nh_t.data_ptr(), cnt.data_ptr(), st)
+        assert rc == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        return flags[:n_rec], hits_t, int(nh_t.item()), cnt.cpu().numpy()
+
+    del d_off
+    fx_any, _, _, cx_any = scan_fixed(mk.MK_MODE_ANY)
+    assert m.kernel_name == "mk_scan_kernel<8,24,false,false>"  # bench.py's headline kernel
+    assert torch.equal(fx_any, f_any) and np.array_equal(cx_any, c_any)
+    fx_hit, dx_hits, nhx, cx_hit = scan_fixed(mk.MK_MODE_HITS, cap)
+    assert torch.equal(fx_hit, f_any) and nhx == nh and np.array_equal(cx_hit, c_hit)
+    assert lib.mk_order_hits_device(m.handle, dx_hits.data_ptr(), nhx, st) == 0, lib.mk_last_error()
+    torch.cuda.synchronize()
+    hx = np.frombuffer(dx_hits[:2 * nhx].cpu().numpy().tobytes(), dtype=mk.HIT_DTYPE)
+    assert np.array_equal(hx, hits)  # `hits`: the offsets path's tuples in the host's emission order
+    with pytest.raises(AssertionError):  # a byte count that is not n_rec x 150 is refused, not scanned
+        assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_bytes - 1, None, n_rec, mk.MK_MODE_ANY, fx_any.data_ptr(), None, 0,
+                                  torch.zeros(1, dtype=torch.int64, device=dev).data_ptr(), None, st) == 0
+    assert lib.mk_matcher_set_fixed_record_length(m.handle, 0) == 0
+
+
+def test_two_length_classes_full_size(mk):
+    """the headline batch with ONE 8-mer added to the 10 000 31-mers (the set that used to drop to S = 1, q = 8): the
+    two-class kernel flags the same records and counts the same occurrences as the one-class kernel at full size
+    (15 GB), and the oracle agrees on a 300 k-record slice"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    lib = mk.load()
+    patterns = mk.parse_pattern_list(kmer_seq=_kmers(10_000, 31, 6) + [b"GATTACAG"])
+    npat = len(patterns)
+    n_rec, L, seed, every = 100_000_000, 150, 0xC1A55, 100
+    st = torch.cuda.current_stream().cuda_stream
+    d_seq = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    res = {}
+    for classes in (0, 1):
+        m = mk.Matcher(patterns, options=dict(length_classes=classes))
+        if classes == 0:
+            assert lib.mk_synth_reads_device(m.handle, seed, n_rec, L, every, d_seq.data_ptr(), d_off.data_ptr(), st) == 0
+            assert m.class_info() == {"split_len": 31, "n_short": 1, "q_gram2": 5, "stride2": 4}
+        flags = torch.empty((n_rec + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        nh = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(npat + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+        cap = 8_000_000
+        d_hits = torch.empty(2 * cap, dtype=torch.int64, device=dev)
+        assert lib.mk_scan_device(m.handle, d_seq.data_ptr(), n_rec * L, d_off.data_ptr(), n_rec, mk.MK_MODE_HITS, flags.data_ptr(),
+                                  d_hits.data_ptr(), cap, nh.data_ptr(), cnt.data_ptr(), st) == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        n = int(nh.item())
+        assert n <= cap
+        assert lib.mk_order_hits_device(m.handle, d_hits.data_ptr(), n, st) == 0, lib.mk_last_error()
+        torch.cuda.synchronize()
+        res[classes] = (m.kernel_name, flags[:n_rec].clone(), d_hits[:2 * n].clone(), cnt.cpu().numpy())
+        if classes == 0:
+            om = ob.Matcher(patterns, True, 0, False)
+            M, rec0 = 300_000, 61_234_560
+            seq = np.zeros(M * L, dtype=np.uint8)
+            off = np.zeros(M + 1, dtype=np.uint64)
+            assert lib.mk_synth_reads_host(m.handle, seed, rec0, M, L, every, seq.ctypes.data, off.ctypes.data) == 0
+            keep, c = ob.extract_single_packed(om, seq, off, logging=True, invert=False)
+            assert np.array_equal(flags[rec0:rec0 + M].cpu().numpy() != 0, keep != 0)
+            assert int(keep.sum()) > M // every  # the 8-mer hits by chance as well (150 / 65536 per read)
+        del m
+    assert res[0][0].endswith("2-class>") and not res[1][0].endswith("2-class>")
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    skip = npat + mk.MK_SUM_CANDIDATES  # (the filter candidates are the one counter that depends on the geometry)
+    assert np.array_equal(np.delete(res[0][3], skip), np.delete(res[1][3], skip))
+
 
 def test_every_read_hits_full_size(mk):
     """100 M x 150 bp with a k-mer planted in EVERY read (tag on already extracted reads, at the headline

@@ -171,3 +171,15 @@ def test_order_library_fallback(mk):
     got = _order_on_device(mk, m, h)
     assert np.array_equal(got, _expected(h, True, plen))
     assert m.order_info()["path"] == 3, m.order_info()
+
+
+def test_order_on_a_genome_like_batch(mk):
+    """one 200 Mbp record (a chromosome of a genome FASTA) with one repeat k-mer every ~2 kbp and 2 000 other k-mers
+    planted at random: the tuples of the real scan, ordered on the device, against the reference's comparator -- and
+    WHICH path of order_hits.hip ran (record bins cannot split one record; the question is whether the re-binning on
+    (record, end) holds or the library merge sort takes over: profiles/r04_order_skew.txt)"""
+    torch = pytest.importorskip("torch")
+    import order_skew
+    r = order_skew.run(mk, torch)
+    assert r["ordered_like_the_reference"] and r["tuples"] > 100_000
+    assert r["order"]["path"] == 2, r  # bins on the whole (record, end, pattern) key; no library sort

@@ -30,18 +30,19 @@ for f in find("kt/**/*kernel_stats.csv") + find("kt*kernel_stats.csv"):
 scan_name, scan_avg_us = None, None
 for f in find("kt/**/*kernel_trace.csv") + find("kt*kernel_trace.csv"):
     d = defaultdict(list)
-    last = None
-    for row in csv.DictReader(open(f)):
+    scan_row = None  # a launch of the scan kernel: ITS resources are the ones worth printing (r03 printed the last launch's,
+    for row in csv.DictReader(open(f)):  # i.e. those of whatever tiny kernel ran last)
         d[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-        last = row
+        if "mk_scan_kernel" in row["Kernel_Name"]:
+            scan_row = row
     print("== kernel trace:", os.path.relpath(f, out))
     for k, v in d.items():
         print("  {:60.60s} n={} avg_us={:.1f} min_us={:.1f} max_us={:.1f}".format(k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
         if "mk_scan_kernel" in k:
             scan_name, scan_avg_us = k, sum(v) / len(v) / 1e3
     for key in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"):
-        if last and key in last:
-            print("  last launch {}={}".format(key, last[key]))
+        if scan_row and key in scan_row:
+            print("  scan kernel launch {}={}".format(key, scan_row[key]))
 
 print("== PMC (per-launch average over launches of kernels matching 'mk_scan')")
 pmc = {}
@@ -65,6 +66,15 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and scan_name:
     if m5:
         short = m5.group(1) + (">" if m5.group(2) in ("true", "1") else ",plain>")
     fetch_kb, write_kb = pmc["FETCH_SIZE"], pmc["WRITE_SIZE"]
+    # gfx950 tallies a wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md, HBM): that correction
+    # applies to the kernel's TEXT STREAM only (16 B per lane, every byte once + one halo chunk per 31-chunk tile),
+    # not to its random 8- / 32-byte reads of filter blocks, table buckets and occurrence windows.  The stream's
+    # bytes are known, so: hbm = FETCH_SIZE + stream / 2 + WRITE_SIZE (r03 doubled all of FETCH_SIZE, which inflated
+    # the global-filter configuration, whose fetches are mostly random, from ~6.0 to 8.9 GB).
+    n_text = a.records * a.read_len
+    stream = n_text * 32 // 31
+    fetch_b = fetch_kb * 1024
+    stream_reported = min(fetch_b, stream / 2)
     j = {
         "source": "tools/profile_gpu.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, --kernel-trace only",
         "command": "python3 bench.py " + bench_args,
@@ -72,8 +82,13 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and scan_name:
         "kernel_source_sha16": bench.kernel_source_hash(),
         "records_per_gpu": a.records, "read_len": a.read_len, "patterns": a.patterns * (2 if a.rc else 1),
         "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
-        "correction": "FETCH_SIZE x2 on gfx950 (16 B/lane streaming reads are tallied at half size, MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
-        "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
+        "correction": "gfx950 tallies 16 B/lane streaming reads at half size (MI355X_MICROARCH.md HBM section): the text stream "
+                      "(records x read_len x 32/31 bytes, known) is counted twice, the random reads (the rest of FETCH_SIZE) once; WRITE_SIZE exact",
+        "text_stream_bytes": stream,
+        "random_fetch_bytes_per_launch": fetch_b - stream_reported,
+        "hbm_bytes_per_launch": fetch_b + stream_reported + write_kb * 1024,
+        "hbm_bytes_per_launch_all_doubled_r03": fetch_b * 2 + write_kb * 1024,
+        "raw_requests": {k: pmc[k] for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_BUBBLE_sum", "TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum") if k in pmc},
         "kernel_avg_us_rocprof": scan_avg_us,
     }
     json.dump(j, open(os.path.join(out, "traffic.json"), "w"), indent=1)
