@@ -316,6 +316,22 @@ int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint6
                    int filter_matching, int invert, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
                    mk_counters *counters, uint32_t *pattern_hit_counts, uint64_t *found_off, uint32_t *found_pat,
                    uint64_t found_cap);
+/* extract, single FASTQ file, from the window's RAW TEXT (replaces needletail's record parsing for
+ * this loop, src/cmd_extract.rs:281-282,321-328): text[0, n_text) starts at a record start and ends behind a whole
+ * record (n_text < 4 GiB).  The bytes are uploaded as they are (fastest from memory of mk_host_alloc), the records are
+ * indexed and their sequence lines gathered on the device, then the loop body of mk_extract_single runs.
+ * Outputs: *n_rec records; rec_start[i] = offset of record i's '@' (rec_start[n_rec] = n_text; room for rec_cap + 1);
+ * keep / rows / counters / pattern_hit_counts as mk_extract_single (row.rec indexes the window's records).
+ * Only plain 4-line FASTQ is taken ('@' line, sequence, '+' line, quality of the same length; LF or CRLF; no blank
+ * lines).  Anything else sets *status = 1 and produces nothing: the caller parses that window with its own reader
+ * (which also words the reference's parse errors).  More than rec_cap records: MK_E_CAPACITY, *n_rec = required. */
+int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap,
+                          uint64_t *n_rec, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
+                          mk_counters *counters, uint32_t *pattern_hit_counts, uint32_t *status);
+/* page-locked host memory for buffers that are uploaded (text windows, record batches): the DMA engines read it
+ * directly, pageable memory is staged through a bounce buffer by one runtime thread.  Release with mk_host_free. */
+int mk_host_alloc(size_t bytes, void **out);
+void mk_host_free(void *p);
 /* Where the last mk_extract_single / mk_tag_records call on this handle spent its time, in milliseconds:
  * ms[0] upload of the records (host -> device), ms[1] device work (scan, emission order, log rows, per-pattern
  * counts, per-record pattern sets -- all kernels), ms[2] download of the results, ms[3] host loops (flags -> keep,

@@ -21,7 +21,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmerkurio_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "merkurio")
 
-N_VARIANT_TUS = 12
+N_VARIANT_TUS = 15
 HOST_SOURCES = ["matcher.cpp", "host_patterns.cpp", "host_loops.cpp", "reduce.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
@@ -51,6 +51,7 @@ def _units():
     units.append(("order_hits_fallback.o", "order_hits_fallback.hip", []))
     units.append(("sets.o", "sets.hip", []))
     units.append(("build_tables.o", "build_tables.hip", []))
+    units.append(("ingest.o", "ingest.hip", []))
     units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     return units
 

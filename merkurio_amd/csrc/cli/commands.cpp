@@ -4,6 +4,9 @@
 // (mk_extract_single / mk_extract_paired / mk_tag_records): no text is searched on the host.
 #include "commands.hpp"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <future>
 
 #include <algorithm>
@@ -324,10 +327,21 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     const bool paired = (bool)a.in_fastq_2;
     const uint64_t window_bytes = (uint64_t)a.window_mb << 20;
     bool more1 = false, more2 = false;
+    // Device ingest: a single FASTQ input on one GPU is not parsed here at all -- the raw text of a
+    // window is copied into page-locked memory, uploaded and indexed on the device (mk_extract_fastq_text); the
+    // host reader below stays the fallback for everything the device refuses (and its byte-identical checker).
+    const bool device_ingest = !paired && devs.size() == 1 && !a.host_ingest;
+    const char *raw_text = nullptr;
+    uint64_t raw_n = 0, raw_resume = 0;
+    bool raw_more = false, raw_refused = false;
+    // (windows of 128 MB: the copy into pinned memory of window k + 1 overlaps upload + scan of window k; page-locking
+    // a buffer costs ~0.1 ms per MB, so the two staging buffers stay small)
+    const uint64_t raw_window = std::min<uint64_t>(window_bytes, 128ull << 20);
     try {
         s1.open(a.in_fastx);
         if (paired) s2.open(*a.in_fastq_2);
-        more1 = s1.fill(window_bytes);
+        if (device_ingest) raw_more = s1.raw_fill(raw_window, &raw_text, &raw_n, &raw_resume);
+        if (!raw_more) more1 = s1.fill(window_bytes);
         if (paired) more2 = s2.fill(window_bytes);
     } catch (...) {
         fm.get();  // a matcher error comes first, as in the serial order of the reference
@@ -452,6 +466,136 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             cur ^= 1;
         }
     };
+    // ---- device ingest loop: raw text windows -> mk_extract_fastq_text -> rows + kept records --------------------
+    if (raw_more) {
+        struct Pinned {  // (not released at the end of the run: unpinning 2 x 150 MB costs more than the process has left to live)
+            void *p = nullptr;
+            uint64_t cap = 0;
+            void need(uint64_t n) {
+                if (n <= cap) return;
+                mk_host_free(p);
+                p = nullptr;
+                cap = 0;
+                mk_check(mk_host_alloc((size_t)(n + n / 8 + 4096), &p), "Error allocating page-locked memory");
+                cap = n + n / 8 + 4096;
+            }
+        } pin[2];
+        // the window's bytes into pinned memory, on all host threads (page-cache pages cannot be DMA sources).  A plain
+        // file is read with pread() -- the kernel copies from the page cache without a page fault per 4 KiB of a
+        // mapping --, inflated text is copied from the reader's buffer.  file_off: offset of the window in a plain file.
+        const int raw_fd = s1.raw_is_plain() ? open(a.in_fastx.c_str(), O_RDONLY) : -1;
+        auto stage = [&](Pinned &dst, const char *src, uint64_t n, uint64_t file_off) {
+            dst.need(n);
+            const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (size_t)(n >> 22) + 1));
+            run_threads(T, [&](size_t t) {
+                const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
+                uint64_t done = lo;
+                while (raw_fd >= 0 && done < hi) {
+                    const ssize_t got = pread(raw_fd, (char *)dst.p + done, (size_t)(hi - done), (off_t)(file_off + done));
+                    if (got <= 0) break;
+                    done += (uint64_t)got;
+                }
+                if (done < hi) memcpy((char *)dst.p + done, src + done, (size_t)(hi - done));  // (no descriptor, or a short read)
+            });
+        };
+        std::vector<uint64_t> rec_start;
+        std::vector<uint8_t> keep;
+        std::vector<mk_row> rows(4096);
+        int cur = 0;
+        stage(pin[0], raw_text, raw_n, raw_resume - raw_n);
+        tm.mark("first window into pinned memory");
+        while (raw_more) {
+            const char *text = raw_text;  // (kept records and row ids are read from the host's own copy)
+            const uint64_t n_text = raw_n;
+            s1.raw_consume();
+            // the next window: inflate / find its end, copy into the other pinned buffer -- beside the device work
+            const char *nx_text = nullptr;
+            uint64_t nx_n = 0, nx_resume = 0;
+            std::future<bool> next = std::async(std::launch::async, [&] {
+                const bool more = s1.raw_fill(raw_window, &nx_text, &nx_n, &nx_resume);
+                if (more) stage(pin[cur ^ 1], nx_text, nx_n, nx_resume - nx_n);
+                return more;
+            });
+            uint64_t n_rec = 0, n_rows = 0;
+            uint32_t status = 0;
+            mk_counters cb;
+            std::vector<uint32_t> cnt_b(counts.size(), 0);
+            bool fell_back = false;
+            try {
+                uint64_t rec_cap = std::max<uint64_t>(rec_start.size() ? rec_start.size() - 1 : 0, n_text / 64 + 16);
+                for (;;) {
+                    if (rec_start.size() < rec_cap + 1) rec_start.resize(rec_cap + 1);
+                    if (keep.size() < rec_cap) keep.resize(rec_cap);
+                    memset(&cb, 0, sizeof(cb));
+                    std::fill(cnt_b.begin(), cnt_b.end(), 0);
+                    int rc = mk_extract_fastq_text(m, (const uint8_t *)pin[cur].p, n_text, lg.active, a.invert_match, rec_cap, &n_rec, rec_start.data(),
+                                                   keep.data(), rows.data(), rows.size(), &n_rows, &cb, cnt_b.data(), &status);
+                    if (rc == MK_E_CAPACITY && n_rec > rec_cap) {
+                        rec_cap = n_rec;
+                        continue;
+                    }
+                    if (rc == MK_E_CAPACITY && n_rows > rows.size()) {
+                        rows.resize(n_rows);
+                        continue;
+                    }
+                    mk_check(rc, "Error during matching");
+                    break;
+                }
+                if (status != 0) {
+                    fell_back = true;  // not plain 4-line FASTQ: the host reader takes over from this window on
+                } else {
+                    c.nb_records_tot += cb.nb_records_tot; c.nb_bases += cb.nb_bases;
+                    c.nb_hits_tot[0] += cb.nb_hits_tot[0]; c.nb_records_hit[0] += cb.nb_records_hit[0];
+                    c.nb_records_extracted += cb.nb_records_extracted;
+                    for (size_t k = 0; k < counts.size(); ++k) counts[k] += cnt_b[k];
+                    tm.mark("window: H2D + index + scan + D2H");
+                    // id of a record: its header line without '@' and line end
+                    auto id_of = [&](uint64_t r) {
+                        const uint64_t b = rec_start[r] + 1;
+                        const char *nl = (const char *)memchr(text + b, '\n', (size_t)(rec_start[r + 1] - b));
+                        uint64_t e = nl ? (uint64_t)(nl - text) : rec_start[r + 1];
+                        if (e > b && text[e - 1] == '\r') --e;
+                        return std::pair<const char *, size_t>(text + b, (size_t)(e - b));
+                    };
+                    emit_log_rows(lg, pats, rows.data(), lg.active ? n_rows : 0, [&](const mk_row &r) { return id_of(r.rec); },
+                                  [&](const mk_row &) -> const std::string & { return name1; });
+                    if (!a.suppress_output) {
+                        // kept records are written by the host reader's own code from the record's four lines
+                        FastxFile one;
+                        one.fastq = true;
+                        one.data = text;
+                        one.data_n = n_text;
+                        for (uint64_t k = 0; k < n_rec; ++k)
+                            if (keep[k]) {
+                                one.recs.clear();
+                                one.parse_span(rec_start[k], rec_start[k + 1]);
+                                one.write(0, w1);
+                            }
+                    }
+                    tm.mark("window: rows + records out");
+                }
+            } catch (...) {
+                next.wait();
+                throw;
+            }
+            if (fell_back) {
+                next.get();  // (its window, if any, was not consumed: fill() hands that text out again)
+                raw_refused = true;
+                break;
+            }
+            raw_more = next.get();
+            raw_text = nx_text;
+            raw_n = nx_n;
+            raw_resume = nx_resume;
+            cur ^= 1;
+        }
+        if (raw_fd >= 0) close(raw_fd);
+        if (raw_refused) {
+            // the host reader parses the refused window (and words any parse error, as the reference would) ...
+            s1.adopt_raw(raw_text, raw_n);
+            more1 = !f1.recs.empty();
+        }
+    }
     // per-device counters of a --gpus N job (summed once, at the end, by RCCL)
     std::vector<mk_counters> dev_c(ms.size());
     std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
@@ -464,9 +608,14 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         // pairs are matched by ordinal: both windows advance by the same number of records
         const size_t n = paired ? std::min(f1.recs.size(), f2.recs.size()) : f1.recs.size();
         // the next window is inflated and indexed while this one is scanned
-        s1.consume(n);
-        if (paired) s2.consume(n);
+        const bool adopted = raw_refused;  // ... this window came from the raw path: the stream resumes behind it afterwards
+        raw_refused = false;
+        if (!adopted) {
+            s1.consume(n);
+            if (paired) s2.consume(n);
+        }
         std::future<void> next_window = std::async(std::launch::async, [&] {
+            if (adopted) return;
             s1.prefetch(window_bytes);
             if (paired) s2.prefetch(window_bytes);
         });
@@ -516,6 +665,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             throw;
         }
         next_window.get();  // a malformed record in the next window is reported now, after this one was written
+        if (adopted) s1.resume_at(raw_resume);
         more1 = s1.fill(window_bytes);
         if (paired) more2 = s2.fill(window_bytes);
         tm.mark("next window");

@@ -580,6 +580,94 @@ bool FastxStream::fill(uint64_t window_bytes) {
     return !view.recs.empty();
 }
 
+// ---- raw windows (device ingest) ------------------------------------------------------------------------------
+// the last record start of d[0, n) at or behind `from` (n if there is none)
+static uint64_t last_record_start(const char *d, uint64_t n, uint64_t from) {
+    uint64_t last = n;
+    for (uint64_t r = next_record_start(d, n, from, true); r < n; r = next_record_start(d, n, r + 1, true)) last = r;
+    return last;
+}
+
+void FastxFile::parse_span(uint64_t b, uint64_t e) { parse_fastx_range(data, data_n, b, e, fastq, recs); }
+
+void FastxStream::adopt_raw(const char *text, uint64_t n) {
+    parse_window(text, n, 0, n, false);
+    view.recs.swap(spare_recs);
+    spare_recs.clear();
+    view.data = text;
+    view.data_n = n;
+    view.fastq = fastq;
+    have_spare = false;
+}
+
+void FastxStream::resume_at(uint64_t resume) {
+    if (src.mapped()) cursor = resume;  // (compressed: the unconsumed text is already the current buffer)
+}
+
+bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n_out, uint64_t *resume) {
+    *resume = 0;
+    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
+    if (src.mapped()) {
+        const char *d = src.text();
+        const uint64_t n = src.text_size();
+        uint64_t p = cursor;
+        while (p < n && (d[p] == '\n' || d[p] == '\r')) ++p;
+        if (p >= n || d[p] != '@') return false;
+        uint64_t end = std::min(n, p + window_bytes);
+        if (end < n) {
+            const uint64_t a0 = p & ~(uint64_t)4095;
+            (void)madvise(const_cast<char *>(d) + a0, (size_t)(std::min(n, end + (1u << 20)) - a0), MADV_WILLNEED);
+            end = next_record_start(d, n, end, true);  // the first record start at or behind the target
+        }
+        cursor = p;
+        raw_next = end;
+        *resume = end;
+        *text = d + p;
+        *n_out = end - p;
+        return end > p;
+    }
+    // compressed: the unconsumed tail of the current buffer opens the other one (as prefetch() does), then inflate
+    std::vector<char> &nb = bufs[cur ^ 1];
+    uint64_t &nl = lens[cur ^ 1];
+    const uint64_t tail = lens[cur] > cursor ? lens[cur] - cursor : 0;
+    if (nb.size() < tail) nb.resize(tail);
+    if (tail) memcpy(nb.data(), bufs[cur].data() + cursor, tail);
+    nl = tail;
+    uint64_t want = window_bytes > nl ? window_bytes - nl : 0;
+    uint64_t cut = 0;
+    for (;;) {
+        if (want) src.more_into(nb, nl, want);
+        uint64_t p = 0;
+        while (p < nl && (nb[p] == '\n' || nb[p] == '\r')) ++p;
+        if (p >= nl && src.exhausted()) {
+            cur ^= 1;
+            cursor = nl;
+            return false;
+        }
+        if (p < nl && nb[p] != '@') {  // not FASTQ: leave everything to fill()
+            cur ^= 1;
+            cursor = 0;
+            return false;
+        }
+        if (src.exhausted()) {
+            cut = nl;
+            break;
+        }
+        // more text follows: hand out whole records only -- everything in front of the last record start
+        cut = last_record_start(nb.data(), nl, nl > (1u << 20) ? nl - (1u << 20) : 0);
+        if (cut < nl && cut > p) break;
+        want = std::max<uint64_t>(window_bytes, nl);  // one record larger than the window: take more
+    }
+    cur ^= 1;
+    cursor = 0;  // (until raw_consume: a refused window is parsed again by fill())
+    raw_next = cut;
+    *text = nb.data();
+    *n_out = cut;
+    return cut > 0;
+}
+
+void FastxStream::raw_consume() { cursor = raw_next; }
+
 void FastxStream::consume(size_t n) { cursor = n < view.recs.size() ? view.recs[n].id_b - 1 : cur_end; }
 
 // ---- SAM / BAM ------------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ struct FastxFile {
     uint64_t raw_len(size_t i) const { return recs[i].raw_e - recs[i].raw_b; }
     // record.write(writer, None): FASTA keeps the original wrapping, FASTQ is 4 lines
     void write(size_t i, Sink &w) const;
+    // appends the records of data[b, e) (b at a record start) to recs
+    void parse_span(uint64_t b, uint64_t e);
 };
 
 // An input file as a sequence of (decompressed) bytes that is looked at through a sliding window, so that
@@ -96,6 +98,7 @@ struct FastxFile {
 struct WindowSource {
     void open(const std::string &path);
     bool mapped() const { return kind == PLAIN; }  // text()/text_size() is the complete text
+    bool is_file_mapping() const { return kind == PLAIN && src.map != nullptr; }  // (not an inflated bzip2 / xz / zstd copy)
     const char *text() const { return src.p; }
     uint64_t text_size() const { return src.n; }
     // compressed kinds: appends up to ~want more inflated bytes to dst[0,len) (some progress unless the
@@ -136,6 +139,20 @@ struct FastxStream {
     // Parses the window behind the consumed records into a spare index (and, for compressed input, a second
     // buffer); may run on another thread while `view` is being used.  Call after consume().
     void prefetch(uint64_t window_bytes);
+    // RAW windows (extract's device path: the window's text goes to the GPU as it is and is indexed there,
+    // mk_extract_fastq_text): the next ~window_bytes of text, from a record start to a record start, NOT parsed.
+    // false: no text is left, or the input is not FASTQ (nothing consumed: fill() then takes over).  The text stays
+    // valid until the raw_fill() after next; raw_consume() accepts the window, without it the next fill() /
+    // raw_fill() starts at the same place (a window the device refused is parsed by fill()).  Use before any fill().
+    bool raw_fill(uint64_t window_bytes, const char **text, uint64_t *n, uint64_t *resume);
+    void raw_consume();
+    // A raw window the device refused (the caller has already asked for the NEXT one with raw_fill(), as its prefetch
+    // thread does, but not consumed it): parsed here into `view`, as fill() would have; the caller then calls
+    // resume_at(the refused window's resume) and goes on with fill(), which continues right behind that window.
+    void adopt_raw(const char *text, uint64_t n);
+    // the raw windows are slices of a plain (memory-mapped) file: window = file[resume - n, resume)
+    bool raw_is_plain() const { return src.mapped() && src.is_file_mapping(); }
+    void resume_at(uint64_t resume);
 
    private:
     WindowSource src;
@@ -148,6 +165,7 @@ struct FastxStream {
     std::vector<FastxFile::Rec> spare_recs;
     const char *spare_data = nullptr;
     uint64_t spare_n = 0, spare_end = 0, cur_end = 0;  // *_end: where the records of a window end
+    uint64_t raw_next = 0;  // raw windows: where the window handed out last ends
     void parse_window(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool partial_ok);
 };
 

@@ -19,7 +19,8 @@ struct Spec {
 const Spec kCommon[] = {{'s', "kmer-seq", 2},      {'f', "kmer-file", 1},    {'r', "reverse-complement", 0}, {'c', "canonical", 0},
                         {'l', "out-log", 3},       {'j', "json-log", 3},     {'S', "suppress-output", 0},    {'v', "invert-match", 0},
                         {'I', "case-insensitive", 0}, {'L', "lowercase", 0}, {'U', "uppercase", 0},          {'q', "q-size", 1},
-                        {'a', "aho-corasick", 0},  {0, "device", 1},         {0, "batch-mb", 1},           {0, "gpus", 1},                 {0, "window-mb", 1}};
+                        {'a', "aho-corasick", 0},  {0, "device", 1},         {0, "batch-mb", 1},           {0, "gpus", 1},                 {0, "window-mb", 1},
+                        {0, "host-ingest", 0}};
 const Spec kExtract[] = {{'i', "in-fastx", 1}, {'1', "in-fastx", 1}, {'2', "in-fastq-2", 1}, {'o', "out-fastx", 1}};
 const Spec kTag[] = {{'i', "in-file", 1}, {'o', "out-file", 1}, {'t', "tag", 1}, {'p', "threads", 1}, {'m', "filter-matching", 0}};
 
@@ -46,7 +47,8 @@ void print_help(const char *sub) {
              "  -a, --aho-corasick           force Aho-Corasick\n      --device <N>             HIP device ordinal [0]\n"
              "      --gpus <N>               shard the records over N GPUs (device, device+1, ...) [1]\n"
              "      --batch-mb <MB>          sequence bytes per GPU batch [128]\n"
-             "      --window-mb <MB>         input text read and held per window [1024]");
+             "      --window-mb <MB>         input text read and held per window [1024]\n"
+             "      --host-ingest            parse FASTQ records on the host threads (default: a single FASTQ input is indexed on the GPU)");
     } else {
         puts("Usage: merkurio tag [OPTIONS] --in-file <IN_FILE> <--kmer-seq <KMER_SEQ>...|--kmer-file <KMER_FILE>>\n\n"
              "  -i, --in-file <PATH>         SAM/BAM input\n  -o, --out-file <PATH>        SAM output (stdout if absent)\n"
@@ -172,6 +174,7 @@ void fill_common(const Parsed &p, CommonArgs &c, bool has_out) {
     if (auto v = p.get("gpus")) c.gpus = (int)std::max<size_t>(1, to_num((*v)[0], "--gpus"));
     if (auto v = p.get("window-mb")) c.window_mb = (int)std::max<size_t>(1, to_num((*v)[0], "--window-mb"));
     if (auto v = p.get("batch-mb")) c.batch_mb = (int)std::max<size_t>(1, to_num((*v)[0], "--batch-mb"));
+    if (p.get("host-ingest")) c.host_ingest = true;
     // clap ArgGroups (src/cmd_extract.rs:33-62, src/cmd_tag.rs:29-66)
     if (c.kmer_seq.empty() == !c.kmer_file) {
         if (c.kmer_file)

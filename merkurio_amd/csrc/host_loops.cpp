@@ -111,6 +111,17 @@ struct DeviceLoop {
         mark(1);
         return MK_OK;
     }
+    // the batch is already in m->d_seq / m->d_off (ingest.hip put it there): scan + flags
+    int scan_resident(uint64_t n_seq_bytes, uint64_t n_rec, uint32_t mode, uint32_t batch_len, uint8_t *flags, uint64_t *flagged) {
+        n_bytes = n_seq_bytes;
+        const uint64_t cap0 = std::max<uint64_t>(std::max<uint64_t>(4096, n_rec / 8), m->d_hits_cap / sizeof(mk_hit));
+        int rc = batch_scan(m, n_bytes, n_rec, mode, batch_len, cap0, ~0ull, &found);
+        if (rc) return rc;
+        mark(2);
+        if ((rc = batch_flags(m, n_rec, flags, flagged))) return rc;
+        mark(1);
+        return MK_OK;
+    }
     int order(bool ac_order) { return order_hits_on_device(m, m->d_hits, found, ac_order, st); }
 
     // mk_row per tuple (in their current order) -> rows[0, min(found, cap))
@@ -273,6 +284,138 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
     if (n_rows) *n_rows = dl.found;
     if (logging && rows && dl.found > rows_cap)
         return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)dl.found);
+    return MK_OK;
+    MK_ABI_END
+}
+
+// ---- FASTQ text in, records out: the window's raw bytes are uploaded as they are, indexed and
+// gathered on the device (ingest.hip), then the extract loop runs as in mk_extract_single
+}  // extern "C"
+
+namespace mk {
+void launch_ingest_count(const uint8_t *d_text, uint64_t n, uint32_t *d_block_cnt, uint32_t *d_total, hipStream_t st);
+void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start,
+                           uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status, hipStream_t st);
+void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st);
+void launch_ingest_gather(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off,
+                          uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st);
+uint32_t ingest_block_bytes();
+uint32_t ingest_scan_tile();
+}  // namespace mk
+
+extern "C" {
+
+int mk_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(MK_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    return MK_OK;
+}
+
+void mk_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out,
+                          uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts,
+                          uint32_t *status) {
+    if (!m || !n_rec_out || !status || !c || (logging && !counts) || (n_text && !text)) return fail(MK_E_INVALID_ARG, "null argument");
+    *n_rec_out = 0;
+    *status = 0;
+    if (n_rows) *n_rows = 0;
+    if (n_text == 0) return MK_OK;
+    if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
+    MK_ABI_BEGIN
+    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
+    DeviceLoop dl(m);
+    hipStream_t st = dl.st;
+    int rc;
+    // the text, and the (upper-bounded) scan buffer it is gathered into
+    if ((rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
+    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
+    const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
+    if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
+    uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;  // | total | status, min, max
+    if (hipMemcpyAsync(m->d_text, text, n_text, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
+    dl.mark(1);
+    launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);
+    uint32_t total_nl = 0;
+    if (hipMemcpyAsync(&total_nl, d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "newline count failed");
+    const uint64_t n_lines = (uint64_t)total_nl + (text[n_text - 1] != '\n' ? 1 : 0);
+    if (n_lines % 4 != 0) {  // not whole 4-line records: the caller's reader decides what this text is
+        *status = 1;
+        return MK_OK;
+    }
+    const uint64_t n_rec = n_lines / 4;
+    *n_rec_out = n_rec;
+    if (n_rec > rec_cap || !rec_start || !keep)
+        return fail(MK_E_CAPACITY, "%llu records in the window, room for %llu", (unsigned long long)n_rec, (unsigned long long)rec_cap);
+    // workspace: line starts | record starts | sequence starts | sequence lengths | tile sums
+    const size_t n_tiles = n_rec / ingest_scan_tile() + 2;
+    const size_t ws = ((size_t)total_nl + 2 + 3 * n_rec + 8) * 4 + n_tiles * 8 + 64;
+    if ((rc = ensure_device(&m->d_ing_b, &m->d_ing_b_cap, ws))) return rc;
+    uint32_t *d_line = (uint32_t *)m->d_ing_b;
+    uint32_t *d_rec_start = d_line + total_nl + 2 + ((total_nl & 1) ? 1 : 0);
+    uint32_t *d_seq_start = d_rec_start + n_rec, *d_seq_len = d_seq_start + n_rec;
+    unsigned long long *d_tile = (unsigned long long *)(((uintptr_t)(d_seq_len + n_rec) + 15) & ~(uintptr_t)15);
+    uint32_t *d_st = d_total + 1;
+    const uint32_t st_init[3] = {0u, 0xFFFFFFFFu, 0u};
+    if (hipMemcpyAsync(d_st, st_init, sizeof(st_init), hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
+    launch_ingest_records((const uint8_t *)m->d_text, n_text, d_block, d_total, d_line, n_rec, d_rec_start, d_seq_start, d_seq_len, d_st, st);
+    uint32_t st_host[3] = {0, 0, 0};
+    if (hipMemcpyAsync(st_host, d_st, sizeof(st_host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "record indexing failed");
+    if (st_host[0]) {  // some record is not '@' / sequence / '+' / quality of equal length
+        *status = 1;
+        *n_rec_out = 0;
+        return MK_OK;
+    }
+    const uint32_t fixed = (n_rec && st_host[1] == st_host[2] && st_host[1] > 0) ? st_host[1] : 0;
+    unsigned long long n_seq = (unsigned long long)n_rec * fixed;
+    if ((rc = ensure_device((void **)&m->d_flags, &m->d_flags_cap, n_rec + 8))) return rc;
+    if ((rc = ensure_device((void **)&m->d_off, &m->d_off_cap, (n_rec + 1) * sizeof(uint64_t)))) return rc;
+    if (!fixed) {
+        launch_ingest_offsets(d_seq_len, n_rec, d_tile, (unsigned long long *)m->d_off, st);
+        if (hipMemcpyAsync(&n_seq, m->d_off + n_rec, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "offset scan failed");
+    }
+    launch_ingest_gather((const uint8_t *)m->d_text, d_seq_start, d_seq_len, (const unsigned long long *)m->d_off, fixed, n_rec, m->d_seq, st);
+    if (hipGetLastError() != hipSuccess) return fail(MK_E_HIP, "ingest kernels failed to launch");
+    m->ragged = !fixed;
+    std::vector<uint8_t> flags(n_rec ? n_rec : 1);
+    uint64_t flagged = 0;
+    if (n_seq == 0) {  // every sequence is empty: nothing can match
+        std::fill(flags.begin(), flags.end(), 0);
+        dl.found = 0;
+    } else if ((rc = dl.scan_resident(n_seq, n_rec, logging ? MK_MODE_HITS : MK_MODE_ANY, fixed, flags.data(), &flagged))) {
+        return rc;
+    }
+    if (logging) {  // the loop body of mk_extract_single (src/cmd_extract.rs:321-406)
+        c->nb_records_tot += n_rec;
+        c->nb_bases += n_seq;
+        c->nb_hits_tot[0] += dl.found;
+        c->nb_records_hit[0] += flagged;
+        if ((rc = dl.order(m->algo == MK_ALGO_AC))) return rc;
+        if ((rc = dl.rows_to_host(0, rows, rows_cap))) return rc;
+        if ((rc = dl.pattern_counts(m->algo == MK_ALGO_AC, n_rec, counts))) return rc;
+    }
+    // record table -> host: where every record starts in the text, one more entry = the end of the text
+    std::vector<uint32_t> rs(n_rec ? n_rec : 1);
+    if (n_rec && hipMemcpy(rs.data(), d_rec_start, n_rec * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the record table failed");
+    dl.mark(1);
+    dl.host_begin();
+    for (uint64_t r = 0; r < n_rec; ++r) {
+        rec_start[r] = rs[r];
+        keep[r] = (uint8_t)((flags[r] != 0) != (invert != 0));
+        c->nb_records_extracted += keep[r];
+    }
+    rec_start[n_rec] = n_text;
+    dl.finish();
+    if (n_rows) *n_rows = dl.found;
+    if (logging && rows && dl.found > rows_cap) return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)dl.found);
     return MK_OK;
     MK_ABI_END
 }

@@ -1,0 +1,282 @@
+// ingest.hip -- FASTQ text -> record table + concatenated sequences, on the device (the step before
+// the hot path; the reference gets its records from needletail's parse_fastx_file, src/cmd_extract.rs:281-282,321-328).
+//
+// The host used to index every record (four memchr per record on all threads), gather the sequence lines -- 47 % of a
+// FASTQ's bytes -- into a batch buffer and upload that.  Here the RAW text of a window goes to the device as it is and
+// five small kernels do the rest at HBM speed (a 1 GiB window: < 2 ms):
+//   1. newlines per 16 KiB block            2. exclusive scan of the block counts
+//   3. line starts (u32, one per line)      4. one lane per record: its four lines validated, sequence length
+//   5. exclusive scan of the lengths (skipped when all reads have one length)
+//   6. sequence lines copied into the scan buffer
+// Only plain 4-line FASTQ is taken: '@' header, sequence, '+' line, quality of the sequence's length, '\n' or '\r\n'
+// line ends, no blank lines.  Anything else (FASTA, wrapped or truncated records, blank lines) raises a status word and
+// the caller parses that window with its own reader -- which also produces the reference's error messages -- so the
+// device never has to decide what a malformed record means.  '@' as the first quality character is not a problem
+// here: lines are counted, not guessed (the window starts at a record start).
+#include <algorithm>
+
+#include "scan_kernel.h"
+
+namespace mk {
+
+constexpr uint32_t kIngestThreads = 256;
+constexpr uint32_t kIngestBytesPerThread = 64;
+constexpr uint32_t kIngestBlockBytes = kIngestThreads * kIngestBytesPerThread;  // 16 KiB
+
+// 0x80 in every byte of v that equals '\n' (exact: no borrow between bytes)
+__device__ __forceinline__ uint32_t nl_mask(uint32_t v) {
+    const uint32_t x = v ^ 0x0A0A0A0Au;
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// the 64 bytes of a thread as 16 dwords (bytes at or beyond n read as 0)
+__device__ __forceinline__ void load64(const uint8_t *__restrict__ text, uint64_t pos, uint64_t n, uint32_t w[16]) {
+    if (pos + 64 <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(text + pos);  // text is 16-byte aligned, pos a multiple of 64
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 v = p[k];
+            w[4 * k] = v.x, w[4 * k + 1] = v.y, w[4 * k + 2] = v.z, w[4 * k + 3] = v.w;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    for (uint64_t i = pos; i < n; ++i) w[(i - pos) >> 2] |= (uint32_t)text[i] << (8 * ((i - pos) & 3));
+}
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *lds) {  // 256 threads; every thread gets the total
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t t = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(kIngestThreads) void mk_ingest_count_kernel(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ block_cnt) {
+    __shared__ uint32_t lds[4];
+    const uint64_t pos = (uint64_t)blockIdx.x * kIngestBlockBytes + threadIdx.x * kIngestBytesPerThread;
+    uint32_t c = 0;
+    if (pos < n) {
+        uint32_t w[16];
+        load64(text, pos, n, w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c += __popc(nl_mask(w[k]));
+    }
+    const uint32_t t = block_sum(c, lds);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = t;
+}
+
+// in place: cnt[b] -> newlines in front of block b; *total = all of them (one workgroup)
+__global__ __launch_bounds__(1024) void mk_ingest_scan_blocks_kernel(uint32_t *__restrict__ cnt, uint32_t n_blocks, uint32_t *__restrict__ total) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? cnt[i] : 0;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o);
+            if ((int)(threadIdx.x & 63) >= o) incl += u;
+        }
+        if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_sum[w];
+        if (i < n_blocks) cnt[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// line_start[k] = first byte of line k (line 0 starts at 0; a text that ends in '\n' has an empty last "line" at n);
+// one more entry behind the last: n + 1, the virtual newline that ends a text without a final '\n'
+__global__ __launch_bounds__(kIngestThreads) void mk_ingest_lines_kernel(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ block_off,
+                                                                         const uint32_t *__restrict__ total, uint32_t *__restrict__ line_start) {
+    __shared__ uint32_t wave_sum[4];
+    const uint64_t pos = (uint64_t)blockIdx.x * kIngestBlockBytes + threadIdx.x * kIngestBytesPerThread;
+    uint32_t w[16];
+    uint32_t c = 0;
+    if (pos < n) {
+        load64(text, pos, n, w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c += __popc(nl_mask(w[k]));
+    }
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += u;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t k = block_off[blockIdx.x] + incl - c + 1;  // index of the line that starts behind this thread's first newline
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) k += wave_sum[wv];
+    if (c) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            uint32_t mk_ = nl_mask(w[d]);
+            while (mk_) {
+                const uint32_t b = (uint32_t)__ffs(mk_) - 1u;  // bit 7 of the byte
+                mk_ &= mk_ - 1;
+                line_start[k++] = (uint32_t)(pos + 4 * d + (b >> 3) + 1);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        line_start[0] = 0;
+        line_start[*total + 1] = (uint32_t)(n + 1);
+    }
+}
+
+// st[0] status bits, st[1] smallest, st[2] largest sequence length
+__global__ __launch_bounds__(256) void mk_ingest_records_kernel(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ line_start,
+                                                               uint64_t n_rec, uint32_t *__restrict__ rec_start, uint32_t *__restrict__ seq_start,
+                                                               uint32_t *__restrict__ seq_len, uint32_t *__restrict__ st) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bad = 0, len = 0;
+    bool live = i < n_rec;
+    if (live) {
+        const uint32_t l0 = line_start[4 * i], l1 = line_start[4 * i + 1], l2 = line_start[4 * i + 2], l3 = line_start[4 * i + 3],
+                       l4 = line_start[4 * i + 4];
+        // line k is [l_k, l_{k+1} - 1) without its '\n'; a '\r' in front of the '\n' belongs to the line end
+        uint32_t e1 = l2 - 1, e3 = l4 - 1;
+        if (e1 > l1 && text[e1 - 1] == '\r') --e1;
+        if (e3 > l3 && e3 - 1 < n && text[e3 - 1] == '\r') --e3;
+        len = e1 - l1;
+        bad |= text[l0] != '@';
+        bad |= l1 - l0 < 2;  // "@\n": no id at all is left to the host reader
+        bad |= (l3 - l2 < 2) || text[l2] != '+';
+        bad |= (e3 - l3) != len;
+        rec_start[i] = l0;
+        seq_start[i] = l1;
+        seq_len[i] = len;
+    }
+    // per-wave reductions, one atomic each
+    uint32_t mn = live ? len : 0xFFFFFFFFu, mx = live ? len : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_down(mn, o));
+        mx = max(mx, (uint32_t)__shfl_down(mx, o));
+    }
+    if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&st[0], 1u);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&st[1], mn);
+        atomicMax(&st[2], mx);
+    }
+}
+
+// ---- exclusive scan of u32 lengths into u64 offsets (tiles of 4096) -----------------------------------------------
+constexpr uint32_t kScanTile = 4096;
+__global__ __launch_bounds__(256) void mk_ingest_tile_sums_kernel(const uint32_t *__restrict__ len, uint64_t n, unsigned long long *__restrict__ tile_sum) {
+    __shared__ unsigned long long part[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile;
+    unsigned long long s = 0;
+    for (uint32_t k = threadIdx.x; k < kScanTile; k += 256)
+        if (base + k < n) s += len[base + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(1024) void mk_ingest_scan_tiles_kernel(unsigned long long *__restrict__ tile_sum, uint32_t n_tiles) {
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_tiles ? tile_sum[i] : 0;
+        unsigned long long incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = __shfl_up(incl, o);
+            if ((int)(threadIdx.x & 63) >= o) incl += u;
+        }
+        if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_sum[w];
+        if (i < n_tiles) tile_sum[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+}
+// off[i] = sum of len[0, i) for i in [0, n]; one workgroup per tile, 16 elements per thread
+__global__ __launch_bounds__(256) void mk_ingest_offsets_kernel(const uint32_t *__restrict__ len, uint64_t n, const unsigned long long *__restrict__ tile_base,
+                                                               unsigned long long *__restrict__ off) {
+    __shared__ unsigned long long wave_sum[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + threadIdx.x * 16;
+    uint32_t v[16];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = base + k < n ? len[base + k] : 0;
+        s += v[k];
+    }
+    unsigned long long incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += u;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long run = tile_base[blockIdx.x] + incl - s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += wave_sum[w];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (base + k <= n) off[base + k] = run;  // (index n: the total)
+        run += v[k];
+    }
+}
+
+// sequence line of record i -> seq[dst, dst + len): 16 lanes per record, bytes
+__global__ __launch_bounds__(256) void mk_ingest_gather_kernel(const uint8_t *__restrict__ text, const uint32_t *__restrict__ seq_start,
+                                                              const uint32_t *__restrict__ seq_len, const unsigned long long *__restrict__ off,
+                                                              uint32_t fixed_len, uint64_t n_rec, uint8_t *__restrict__ seq) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t sub = threadIdx.x & 15u;
+    if (i >= n_rec) return;
+    const uint32_t len = seq_len[i];
+    const uint8_t *__restrict__ src = text + seq_start[i];
+    uint8_t *__restrict__ dst = seq + (fixed_len ? i * (uint64_t)fixed_len : off[i]);
+    for (uint32_t k = sub; k < len; k += 16) dst[k] = src[k];
+}
+
+void launch_ingest_count(const uint8_t *d_text, uint64_t n, uint32_t *d_block_cnt, uint32_t *d_total, hipStream_t st) {
+    const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
+    hipLaunchKernelGGL(mk_ingest_count_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_cnt);
+    hipLaunchKernelGGL(mk_ingest_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d_block_cnt, n_blocks, d_total);
+}
+
+void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start,
+                           uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status, hipStream_t st) {
+    const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
+    hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start);
+    if (n_rec)
+        hipLaunchKernelGGL(mk_ingest_records_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, d_text, n, d_line_start, n_rec, d_rec_start,
+                           d_seq_start, d_seq_len, d_status);
+}
+
+void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st) {
+    const uint32_t n_tiles = (uint32_t)(n_rec / kScanTile + 1);  // (covers index n_rec as well)
+    hipLaunchKernelGGL(mk_ingest_tile_sums_kernel, dim3(n_tiles), dim3(256), 0, st, d_seq_len, n_rec, d_tile);
+    hipLaunchKernelGGL(mk_ingest_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, d_tile, n_tiles);
+    hipLaunchKernelGGL(mk_ingest_offsets_kernel, dim3(n_tiles), dim3(256), 0, st, d_seq_len, n_rec, d_tile, d_off);
+}
+
+void launch_ingest_gather(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off,
+                          uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st) {
+    if (!n_rec) return;
+    hipLaunchKernelGGL(mk_ingest_gather_kernel, dim3((unsigned)((n_rec * 16 + 255) / 256)), dim3(256), 0, st, d_text, d_seq_start, d_seq_len, d_off,
+                       fixed_len, n_rec, d_seq);
+}
+
+uint32_t ingest_block_bytes() { return kIngestBlockBytes; }
+uint32_t ingest_scan_tile() { return kScanTile; }
+
+}  // namespace mk

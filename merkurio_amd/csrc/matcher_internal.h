@@ -73,6 +73,9 @@ struct mk_matcher {
     size_t d_aux_cap = 0;
     void *d_pair = nullptr;  // paired extract: mate 1's tuples while mate 2 is scanned
     size_t d_pair_cap = 0;
+    // mk_extract_fastq_text (ingest.hip): the window's raw text, block counts + status words, line / record tables
+    void *d_text = nullptr, *d_ing_a = nullptr, *d_ing_b = nullptr;
+    size_t d_text_cap = 0, d_ing_a_cap = 0, d_ing_b_cap = 0;
     // where the last driver-loop call (mk_extract_single / mk_tag_records) spent its time, milliseconds:
     // [0] upload (H2D), [1] device work (scan, ordering, sets, counts), [2] download (D2H), [3] host loops
     float batch_ms[4] = {0, 0, 0, 0};

@@ -73,7 +73,7 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
                         hipStream_t stream);
 
 // host-side launcher of one kernel variant; defined (explicitly instantiated) in scan_variants.hip
-template <int S, int QC, bool EMIT, bool GF, int FL, bool MC = false>
+template <int S, int QC, bool EMIT, bool GF, int FL, int MC = 0>
 void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream);
 
 // static LDS bytes of one scan workgroup (filter + candidate rings + pattern counters)

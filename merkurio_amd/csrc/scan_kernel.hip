@@ -162,7 +162,7 @@ void launch_add_u64(unsigned long long *dst, const unsigned long long *src, size
 
 // the kernel variants are instantiated in groups by scan_variants.hip (one translation unit per
 // group, compiled in parallel); launch_variant<...> is the host-side launcher of one of them
-template <int S, int QC, bool EMIT, bool GF, int FL = 1, bool MC = false>
+template <int S, int QC, bool EMIT, bool GF, int FL = 1, int MC = 0>
 static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, const char *name) {
     launch_variant<S, QC, EMIT, GF, FL, MC>(p, grid, st);
     return name;
@@ -176,18 +176,32 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
     return emit ? launch_one<S_, QC_, true, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,plain>") \
                 : launch_one<S_, QC_, false, false, 0>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,plain>")
 #define MK_VARIANT_MC(S_, QC_)                                                                                              \
-    return emit ? launch_one<S_, QC_, true, false, 1, true>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,2-class>") \
-                : launch_one<S_, QC_, false, false, 1, true>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,2-class>")
+    return emit ? launch_one<S_, QC_, true, false, 1, 1>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,2-class>") \
+                : launch_one<S_, QC_, false, false, 1, 1>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,2-class>")
+// the k-mer families with a byte-table short class of stride 2 / 4 / 8: that stride compiled in
+#define MK_VARIANT_MCS(S_, QC_)                                                                                                         \
+    do {                                                                                                                                \
+        if (p.short_bytes && p.s2 == 2)                                                                                                 \
+            return emit ? launch_one<S_, QC_, true, false, 1, 2>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,s2=2,2-class>") \
+                        : launch_one<S_, QC_, false, false, 1, 2>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,s2=2,2-class>"); \
+        if (p.short_bytes && p.s2 == 4)                                                                                                 \
+            return emit ? launch_one<S_, QC_, true, false, 1, 4>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,s2=4,2-class>") \
+                        : launch_one<S_, QC_, false, false, 1, 4>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,s2=4,2-class>"); \
+        if (p.short_bytes && p.s2 == 8)                                                                                                 \
+            return emit ? launch_one<S_, QC_, true, false, 1, 8>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,false,s2=8,2-class>") \
+                        : launch_one<S_, QC_, false, false, 1, 8>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,false,s2=8,2-class>"); \
+        MK_VARIANT_MC(S_, QC_);                                                                                                         \
+    } while (0)
 
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream) {
     const bool plain_loads = flavour == 0;
     if (p.s2) {  // two length classes (filter.hpp): main filter in LDS + the short class's bitmap; one load flavour
         if (global_filter) return nullptr;
-        if (S == 16 && p.q == 16) MK_VARIANT_MC(16, 16);
-        if (S == 8 && p.q == 24) MK_VARIANT_MC(8, 24);
-        if (S == 4 && p.q == 28) MK_VARIANT_MC(4, 28);
-        if (S == 4 && p.q == 18) MK_VARIANT_MC(4, 18);
+        if (S == 16 && p.q == 16) MK_VARIANT_MCS(16, 16);
+        if (S == 8 && p.q == 24) MK_VARIANT_MCS(8, 24);
+        if (S == 4 && p.q == 28) MK_VARIANT_MCS(4, 28);
+        if (S == 4 && p.q == 18) MK_VARIANT_MCS(4, 18);
         if (wide) switch (S) {
                 case 2: MK_VARIANT_MC(2, -1);
                 case 4: MK_VARIANT_MC(4, -1);
@@ -273,6 +287,7 @@ const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool g
 #undef MK_VARIANT
 #undef MK_VARIANT_PLAIN
 #undef MK_VARIANT_MC
+#undef MK_VARIANT_MCS
 
 // ---- synthetic reads (bench / full-size parity tests) ----------------------------------
 // byte0 = global position of seq[0] in the synthetic stream (a multiple of 32)

@@ -426,13 +426,13 @@ __device__ __forceinline__ void probe_chain(const ScanParams &P, bool active, ui
 // Geometry of one kernel variant.  QC > 0: q-gram length fixed at compile time (the k-mer
 // sizes that matter get their own kernels: no runtime masks, no unused halo words);
 // QC == 0: runtime q <= 16 (32-bit keys); QC == -1: runtime q in 17..32.
-template <int S, int QC, bool CTX, bool MC = false>
+template <int S, int QC, bool CTX, int MC = 0>
 struct Geo {
     static constexpr bool kFixed = QC > 0;
     static constexpr int kNS = 16 / S;                                     // samples per lane per chunk
     static constexpr int kSpan = kFixed ? (kNS - 1) * S + QC + (CTX ? 7 : 0) : 48;  // bases a lane looks at
     // (the short class of an MC kernel looks at up to 15 + 8 bases)
-    static constexpr bool kNeedW1 = kSpan > 16 || MC, kNeedW2 = kSpan > 32;      // halo words
+    static constexpr bool kNeedW1 = kSpan > 16 || MC != 0, kNeedW2 = kSpan > 32;      // halo words
 };
 
 // ---- second length class (MC kernels; matcher.cpp: plan_classes) ------------------------------------------------
@@ -513,9 +513,12 @@ __device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32
 }
 
 // ---- main kernel -----------------------------------------------------------------------
-template <int S, int QC, bool EMIT, bool GF, int FL, bool MC = false>
+// MC: 0 = one length class; 1 = two classes, the short class's stride and table kind read at run time (a switch per
+// chunk: ~0.17 ms per 15 GB, profiles/r04_mc_ablate.txt); 2 / 4 / 8 = two classes, byte table, THAT stride compiled in
+// (the k-mer families only: a k-mer set plus a few short motifs is the case that matters)
+template <int S, int QC, bool EMIT, bool GF, int FL, int MC = 0>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
-    static_assert(!(MC && GF), "two length classes: kernels with the main filter in LDS only");
+    static_assert(!(MC != 0 && GF), "two length classes: kernels with the main filter in LDS only");
     constexpr bool NTL = FL != 0;  // non-temporal stream loads
     // context kernels: global filter with a compile-time q (filter.hpp: gf_has_ctx); kPipe: their
     // filter probes run one chunk ahead of their use (two samples per lane keeps that in registers)
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     constexpr bool kWide = FL == 0;  // hit-dense flavour: flags stored directly (drain_hits)
     // MC kernels: the short class's table comes FIRST (its ds_read_u8 / ds_read_b32 then carry their base as the
     // instruction's 16-bit offset; behind the 128 KiB filter every probe paid a v_add for it), the filter behind it
-    constexpr uint32_t kShortWords = MC ? kShortBitmapWords : 0;
+    constexpr uint32_t kShortWords = MC != 0 ? kShortBitmapWords : 0;
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[kShortWords + kLdsBytes / 4];  // (short-class table +) filter + candidate rings
     uint32_t *const bloom = lds_all + kShortWords;
     uint32_t *lds_sums = bloom + kBloomWords;  // wave 0's candidate ring, once every wave is done with its own
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
         for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
-        if constexpr (MC) {
+        if constexpr (MC != 0) {
             const uint4 *src2 = reinterpret_cast<const uint4 *>(P.short_bitmap);
             uint4 *dst2 = reinterpret_cast<uint4 *>(lds_all);
             for (uint32_t i = threadIdx.x; i < kShortBitmapWords / 4; i += kBlockThreads) dst2[i] = src2[i];
@@ -619,14 +622,16 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
             if constexpr (GF) m &= blk.x >> (h >> 12);  // the global filter's fourth bit (d)
             cand |= (m & 1u) << j;
         }
-        if constexpr (MC) {  // the short class's samples: bits 16.. of the mask (wave-uniform stride)
+        if constexpr (MC != 0) {  // the short class's samples: bits 16.. of the mask (wave-uniform stride)
             uint32_t c2;
 #if defined(MK_MC_ABL) && MK_MC_ABL == 1  // profiling builds: the two-class kernel without its short-class samples
             c2 = 0;
 #elif defined(MK_MC_ABL) && MK_MC_ABL == 2  // ... with one compile-time geometry instead of the switch
             c2 = short_filter<4, true>(short_bm, w0, w1, P.key2_mask);
 #else
-            if (P.short_bytes) {
+            if constexpr (MC > 1) {
+                c2 = short_filter<MC, true>(short_bm, w0, w1, P.key2_mask);
+            } else if (P.short_bytes) {
                 switch (P.s2) {
                     case 1: c2 = short_filter<1, true>(short_bm, w0, w1, P.key2_mask); break;
                     case 2: c2 = short_filter<2, true>(short_bm, w0, w1, P.key2_mask); break;
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
     auto queue_candidates = [&](uint32_t pk_cur, uint32_t pk_nxt, uint32_t wm1, uint32_t cand, uint64_t cpos, uint32_t h0, uint32_t h1) __attribute__((always_inline)) {
         const uint32_t w0 = pk_cur;
         uint32_t w1 = 0, w2 = 0;
-        if constexpr (NS > 2 || kCtx || MC) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below / the context needs the halo
+        if constexpr (NS > 2 || kCtx || MC != 0) halo(pk_cur, pk_nxt, w1, w2);  // the hash is recomputed below / the context needs the halo
         newest_end = cpos + kChunkBytes;  // parked and queued positions are all below it
         const uint32_t t_base = (uint32_t)cpos + lane * 16;
         do {  // wave-uniform; one iteration unless a lane has several positives in this chunk
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
                     slot_c = (prev7 & 0x3FFFu) | ((next7 & 0x3FFFu) << 14);
                 }
                 slot_t = t_base + j * S;
-                if constexpr (MC) {
+                if constexpr (MC != 0) {
                     // bits 16.. of the mask are the short class's samples: fingerprint = its packed key (filter.hpp).
                     // Both forms are computed and one is selected: a branch here diverges (the lanes of a wave hold
                     // candidates of both classes) and would run both sides anyway.

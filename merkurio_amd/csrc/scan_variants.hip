@@ -5,27 +5,28 @@
 #include "scan_kernel_impl.hpp"
 
 #ifndef MK_TU
-#error "compile with -DMK_TU=0..11"
+#error "compile with -DMK_TU=0..14"
 #endif
 
 namespace mk {
 
-template <int S, int QC, bool EMIT, bool GF, int FL, bool MC>
+template <int S, int QC, bool EMIT, bool GF, int FL, int MC>
 void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream) {
     hipLaunchKernelGGL((mk_scan_kernel<S, QC, EMIT, GF, FL, MC>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, p);
 }
 
 #define MK_INST(S_, QC_, GF_)                                                                    \
-    template void launch_variant<S_, QC_, false, GF_, 1, false>(const ScanParams &, int, hipStream_t); \
-    template void launch_variant<S_, QC_, true, GF_, 1, false>(const ScanParams &, int, hipStream_t)
-// two length classes (filter.hpp): the variant with the short class's bitmap probed next to the main filter
-#define MK_INST_MC(S_, QC_)                                                                            \
-    template void launch_variant<S_, QC_, false, false, 1, true>(const ScanParams &, int, hipStream_t); \
-    template void launch_variant<S_, QC_, true, false, 1, true>(const ScanParams &, int, hipStream_t)
+    template void launch_variant<S_, QC_, false, GF_, 1, 0>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, GF_, 1, 0>(const ScanParams &, int, hipStream_t)
+// two length classes (filter.hpp): the variant with the short class's table probed next to the main filter;
+// MC_ = 1: stride / table kind of the short class at run time, 2 / 4 / 8: byte table with that stride compiled in
+#define MK_INST_MC(S_, QC_, MC_)                                                                       \
+    template void launch_variant<S_, QC_, false, false, 1, MC_>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, false, 1, MC_>(const ScanParams &, int, hipStream_t)
 // the same variant with plain (cacheable) stream loads, for hit-dense text
 #define MK_INST_PLAIN(S_, QC_, GF_)                                                               \
-    template void launch_variant<S_, QC_, false, GF_, 0, false>(const ScanParams &, int, hipStream_t); \
-    template void launch_variant<S_, QC_, true, GF_, 0, false>(const ScanParams &, int, hipStream_t)
+    template void launch_variant<S_, QC_, false, GF_, 0, 0>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, GF_, 0, 0>(const ScanParams &, int, hipStream_t)
 
 #if MK_TU == 0  // LDS filter, q fixed at compile time: the 31-mer and 21-mer families
 uint32_t scan_lds_bytes() { return kLdsBytes; }
@@ -78,21 +79,36 @@ MK_INST(2, -1, true);
 MK_INST(4, -1, true);
 MK_INST(8, -1, true);
 MK_INST(16, -1, true);
-#elif MK_TU == 9  // two length classes, main class with q fixed at compile time
-MK_INST_MC(16, 16);
-MK_INST_MC(8, 24);
-MK_INST_MC(4, 28);
-MK_INST_MC(4, 18);
+#elif MK_TU == 9  // two length classes, main class with q fixed at compile time, short class at run time
+MK_INST_MC(16, 16, 1);
+MK_INST_MC(8, 24, 1);
+MK_INST_MC(4, 28, 1);
+MK_INST_MC(4, 18, 1);
 #elif MK_TU == 10  // two length classes, main class runtime q <= 16 (a main class at stride 1 is never split: matcher.cpp)
-MK_INST_MC(2, 0);
-MK_INST_MC(4, 0);
-MK_INST_MC(8, 0);
-MK_INST_MC(16, 0);
+MK_INST_MC(2, 0, 1);
+MK_INST_MC(4, 0, 1);
+MK_INST_MC(8, 0, 1);
+MK_INST_MC(16, 0, 1);
 #elif MK_TU == 11  // two length classes, main class runtime q in 17..32
-MK_INST_MC(2, -1);
-MK_INST_MC(4, -1);
-MK_INST_MC(8, -1);
-MK_INST_MC(16, -1);
+MK_INST_MC(2, -1, 1);
+MK_INST_MC(4, -1, 1);
+MK_INST_MC(8, -1, 1);
+MK_INST_MC(16, -1, 1);
+#elif MK_TU == 12  // the k-mer families with the short class's stride compiled in (byte table): stride 2
+MK_INST_MC(16, 16, 2);
+MK_INST_MC(8, 24, 2);
+MK_INST_MC(4, 28, 2);
+MK_INST_MC(4, 18, 2);
+#elif MK_TU == 13  // ... stride 4
+MK_INST_MC(16, 16, 4);
+MK_INST_MC(8, 24, 4);
+MK_INST_MC(4, 28, 4);
+MK_INST_MC(4, 18, 4);
+#elif MK_TU == 14  // ... stride 8
+MK_INST_MC(16, 16, 8);
+MK_INST_MC(8, 24, 8);
+MK_INST_MC(4, 28, 8);
+MK_INST_MC(4, 18, 8);
 #else
 #error "unknown MK_TU"
 #endif

@@ -48,7 +48,7 @@ EXPORTS = [
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_plan_geometry", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_matcher_class_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
-    "mk_extract_single", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
+    "mk_extract_single", "mk_extract_fastq_text", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
 ]
@@ -183,6 +183,12 @@ def load(build_if_missing=True):
                                         C.POINTER(C.c_uint32)]
     L.mk_extract_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p]
+    L.mk_extract_fastq_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p,
+                                        C.POINTER(C.c_uint32)]
+    L.mk_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mk_host_free.argtypes = [C.c_void_p]
+    L.mk_host_free.restype = None
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(Counters), C.c_void_p]
@@ -467,6 +473,33 @@ class Matcher:
                                             C.byref(res["c"]), res["counts"].ctypes.data)
         rows = self._rows(call)
         return keep[:n].astype(bool).tolist(), rows, res["c"].as_dict(res["counts"])
+
+    def extract_fastq_text(self, text: bytes, logging=True, invert=False):
+        """mk_extract_fastq_text: raw 4-line FASTQ text -> (status, rec_start list (n + 1), keep, rows, counters);
+        status 1 = not plain FASTQ, the caller's own reader must take the window"""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        cap = max(1, text.count(b"\n") // 4 + 2)
+        n_rec, status = C.c_uint64(), C.c_uint32()
+        rec_start = np.zeros(cap + 1, dtype=np.uint64)
+        keep = np.zeros(cap, dtype=np.uint8)
+        cnt = Counters()
+        counts = np.zeros(len(self.patterns), dtype=np.uint32)
+        rows = np.zeros(4096, dtype=ROW_DTYPE)
+        n_rows = C.c_uint64()
+        while True:
+            c2, k2 = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+            rc = load().mk_extract_fastq_text(self._h, buf.ctypes.data if len(buf) else None, len(buf), int(logging), int(invert), cap,
+                                              C.byref(n_rec), rec_start.ctypes.data, keep.ctypes.data, rows.ctypes.data, len(rows),
+                                              C.byref(n_rows), C.byref(c2), k2.ctypes.data, C.byref(status))
+            if rc == MK_E_CAPACITY and n_rows.value > len(rows):
+                rows = np.zeros(n_rows.value, dtype=ROW_DTYPE)
+                continue
+            _check(rc)
+            cnt, counts = c2, k2
+            break
+        n = n_rec.value
+        out_rows = [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else []
+        return status.value, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows, cnt.as_dict(counts)
 
     def extract_paired(self, seqs1, seqs2, logging=True, invert=False):
         d1, o1 = pack_records(seqs1)

@@ -438,3 +438,61 @@ def test_extract_reads_its_input_in_windows(tmp_path):
     p = run(["extract", "-i", str(tmp_path / "short_1.fastq"), "-2", str(tmp_path / "a_2.fastq"), "-f", str(tmp_path / "k.txt"),
              "-o", str(tmp_path / "m2"), "--window-mb", "1"], check=False)
     assert p.returncode == 1 and b"different number of records" in p.stderr
+
+
+def test_device_ingest_equals_host_ingest(tmp_path):
+    """extract on a single FASTQ: the default path uploads the window's text and indexes it on the GPU
+    (mk_extract_fastq_text); --host-ingest parses on the host threads, the byte-identical checker of the device's index.
+    Same kept records, text log and JSON log for: plain / gzip / BGZF-less multi-window input, '@' and '+' opening
+    quality lines, '+id' third lines, CRLF, no final newline, trimmed reads; a file with a blank line in the middle
+    (the device refuses that window, the host reader takes over from there) and a malformed record (the reference's
+    parse error, after the good windows were written)."""
+    import gzip
+    import random
+    rnd = random.Random(12)
+    kmers = ["".join(rnd.choice("ACGT") for _ in range(31)) for _ in range(50)]
+    (tmp_path / "k.txt").write_text("\n".join(kmers) + "\n")
+
+    def reads(n, lens=(150,), eol="\n", plus_id=False):
+        out = []
+        for i in range(n):
+            L = rnd.choice(lens)
+            s = [rnd.choice("ACGT") for _ in range(L)]
+            if L >= 31 and i % 4 == 0:
+                k = rnd.choice(kmers)
+                o = rnd.randrange(0, L - 30)
+                s[o:o + 31] = k
+            q = "".join(rnd.choice("@+IJ#5A") for _ in range(L))
+            out.append(f"@r{i} d/{i}{eol}{''.join(s)}{eol}+{('r%d' % i) if plus_id and i % 2 else ''}{eol}{q}{eol}")
+        return out
+
+    plain = reads(6000)
+    files = {
+        "plain.fastq": "".join(plain),
+        "crlf.fastq": "".join(reads(3000, eol="\r\n", plus_id=True)),
+        "ragged_nonl.fastq": "".join(reads(4000, lens=(36, 75, 150, 151, 0)))[:-1],
+        "blank_line.fastq": "".join(plain[:2500]) + "\n" + "".join(plain[2500:]),
+    }
+    for name, text in files.items():
+        (tmp_path / name).write_bytes(text.encode())
+    (tmp_path / "plain.fastq.gz").write_bytes(gzip.compress(files["plain.fastq"].encode(), 1))
+    for name in list(files) + ["plain.fastq.gz"]:
+        res = {}
+        for mode in ("device", "host"):
+            d = tmp_path / f"{name}.{mode}"
+            d.mkdir()
+            extra = ["--host-ingest"] if mode == "host" else []
+            run(["extract", "-i", str(tmp_path / name), "-f", str(tmp_path / "k.txt"), "-o", str(d / "out"), "-l", str(d / "log.txt"), "-j",
+                 str(d / "log.json"), "--window-mb", "1"] + extra)
+            res[mode] = (open(d / "out.fastq", "rb").read(), log_body(d / "log.txt"), json_stable(d / "log.json")[:2])
+        assert res["device"] == res["host"], name
+        assert res["device"][0].count(b"\n@r") > 500
+    # a malformed record in the third window: both paths write the records before it and end with the reference's message
+    bad = "".join(plain[:5000]) + "@broken\nACGT\n+\nII\n" + "".join(plain[5000:])
+    (tmp_path / "bad.fastq").write_text(bad)
+    outs = []
+    for extra in ([], ["--host-ingest"]):
+        p = run(["extract", "-i", str(tmp_path / "bad.fastq"), "-f", str(tmp_path / "k.txt"), "--window-mb", "1"] + extra, check=False)
+        assert p.returncode != 0 and b"Error during FASTQ/A record parsing." in p.stderr
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and outs[0].count(b"\n@r") > 300
