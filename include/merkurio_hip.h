@@ -328,6 +328,11 @@ int mk_tag_records(mk_matcher *m, const uint8_t *seq, const uint64_t *off, uint6
 int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap,
                           uint64_t *n_rec, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
                           mk_counters *counters, uint32_t *pattern_hit_counts, uint32_t *status);
+/* Optional overlap for a host that walks a file window by window: starts the upload of the NEXT window (page-locked
+ * memory) on a stream of its own and returns; the mk_extract_fastq_text call that is then given the same pointer and
+ * size finds its text on the device already.  May be called from another host thread while a call on the handle is in
+ * progress, but must have returned before the call that consumes it starts; any other window simply uploads itself. */
+int mk_upload_text_ahead(mk_matcher *m, const uint8_t *text, uint64_t n_text);
 /* page-locked host memory for buffers that are uploaded (text windows, record batches): the DMA engines read it
  * directly, pageable memory is staged through a bounce buffer by one runtime thread.  Release with mk_host_free. */
 int mk_host_alloc(size_t bytes, void **out);

@@ -21,7 +21,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmerkurio_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "merkurio")
 
-N_VARIANT_TUS = 15
+N_VARIANT_TUS = 17
 HOST_SOURCES = ["matcher.cpp", "host_patterns.cpp", "host_loops.cpp", "reduce.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]

@@ -336,7 +336,8 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     bool raw_more = false, raw_refused = false;
     // (windows of 128 MB: the copy into pinned memory of window k + 1 overlaps upload + scan of window k; page-locking
     // a buffer costs ~0.1 ms per MB, so the two staging buffers stay small)
-    const uint64_t raw_window = std::min<uint64_t>(window_bytes, 128ull << 20);
+    // (with logs every window also pays the ordering / row / count round trips: fewer, larger windows)
+    const uint64_t raw_window = std::min<uint64_t>(window_bytes, (a.out_log || a.json_log) ? 256ull << 20 : 128ull << 20);
     try {
         s1.open(a.in_fastx);
         if (paired) s2.open(*a.in_fastq_2);
@@ -513,7 +514,11 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             uint64_t nx_n = 0, nx_resume = 0;
             std::future<bool> next = std::async(std::launch::async, [&] {
                 const bool more = s1.raw_fill(raw_window, &nx_text, &nx_n, &nx_resume);
-                if (more) stage(pin[cur ^ 1], nx_text, nx_n, nx_resume - nx_n);
+                if (more) {
+                    stage(pin[cur ^ 1], nx_text, nx_n, nx_resume - nx_n);
+                    // ... and on its way to the device while this window is still being scanned / written out
+                    mk_check(mk_upload_text_ahead(m, (const uint8_t *)pin[cur ^ 1].p, nx_n), "Error uploading the next window");
+                }
                 return more;
             });
             uint64_t n_rec = 0, n_rows = 0;

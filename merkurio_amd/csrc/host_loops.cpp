@@ -317,6 +317,30 @@ void mk_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+int mk_upload_text_ahead(mk_matcher *m, const uint8_t *text, uint64_t n_text) {
+    if (!m || (n_text && !text)) return fail(MK_E_INVALID_ARG, "null argument");
+    if (n_text == 0 || n_text >= 0xFFFFFFF0ull) return MK_OK;  // (nothing to do / the call itself will refuse it)
+    MK_ABI_BEGIN
+    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
+    std::lock_guard<std::mutex> lk(m->ahead_mu);
+    if (!m->stream_ahead && hipStreamCreateWithFlags(&m->stream_ahead, hipStreamNonBlocking) != hipSuccess)
+        return fail(MK_E_HIP, "hipStreamCreate failed");
+    mk_matcher::AheadSlot *slot = nullptr;
+    for (auto &a : m->ahead)
+        if (!a.text && !slot) slot = &a;
+    if (!slot) return MK_OK;  // two windows wait already: this one will upload itself
+    if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) return fail(MK_E_HIP, "hipEventCreate failed");
+    int rc = ensure_device(&slot->d, &slot->cap, n_text + 64);
+    if (rc) return rc;
+    if (hipMemcpyAsync(slot->d, text, n_text, hipMemcpyHostToDevice, m->stream_ahead) != hipSuccess ||
+        hipEventRecord(slot->ev, m->stream_ahead) != hipSuccess)
+        return fail(MK_E_HIP, "upload of the next text window failed");
+    slot->text = text;
+    slot->n = n_text;
+    return MK_OK;
+    MK_ABI_END
+}
+
 int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out,
                           uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts,
                           uint32_t *status) {
@@ -331,13 +355,32 @@ int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, i
     DeviceLoop dl(m);
     hipStream_t st = dl.st;
     int rc;
-    // the text, and the (upper-bounded) scan buffer it is gathered into
-    if ((rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
+    // the text, and the (upper-bounded) scan buffer it is gathered into.  A window that mk_upload_text_ahead has
+    // already sent (same pointer, same size) is taken from its buffer: the copy ran beside the previous window's work
+    bool ahead = false;
+    {
+        std::lock_guard<std::mutex> lk(m->ahead_mu);
+        for (auto &a : m->ahead) {
+            if (!a.text) continue;
+            if (a.text == text && a.n == n_text && !ahead) {
+                std::swap(m->d_text, a.d);
+                std::swap(m->d_text_cap, a.cap);
+                if (hipStreamWaitEvent(st, a.ev, 0) != hipSuccess) return fail(MK_E_HIP, "hipStreamWaitEvent failed");
+                ahead = true;
+            }
+            // (a slot that holds any other window is stale -- the host did not come back for it: its copy, if still
+            // running, reads page-locked memory the host may be refilling, so let it finish before the slot is reused)
+            else if (hipEventSynchronize(a.ev) != hipSuccess)
+                return fail(MK_E_HIP, "hipEventSynchronize failed");
+            a.text = nullptr;
+        }
+    }
+    if (!ahead && (rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
     if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
     const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
     if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
     uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;  // | total | status, min, max
-    if (hipMemcpyAsync(m->d_text, text, n_text, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
+    if (!ahead && hipMemcpyAsync(m->d_text, text, n_text, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
     dl.mark(1);
     launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);

@@ -131,8 +131,10 @@ static void choose_geometry(uint32_t lmin, uint64_t n_pat, const mk_matcher_opti
 // its own stride S2 and q-grams of q2 <= 8 bases looked up in a plain table in LDS (filter.hpp,
 // scan_kernel_impl.hpp: MC kernels), the others keep the hashed filter with the geometry THEIR
 // shortest pattern admits.  The split is chosen with a cost model fitted to the stride sweep of
-// the headline set (ms per 15 GB launch on an MI355X, same file): 1.13 + 0.42 per hashed sample
-// per 16 bases + 0.13 / 0.25 per byte- / bit-table sample + 0.0152 per million candidates.
+// the headline set and to the two-class kernel at several short-class geometries (ms per 15 GB
+// launch on an MI355X, profiles/r04_mixed_sets.txt): 1.13 + 0.42 per hashed sample per 16 bases
+// + 0.075 / 0.15 per byte- / bit-table sample; a million candidates cost 0.0152 in a one-class
+// kernel and 0.025 in a two-class kernel (its hand-off serves both classes).
 struct ClassPlan {
     uint32_t split = 0;  // 0 = one class; else patterns shorter than this are the short class
     uint32_t S2 = 0, q2 = 0;
@@ -144,15 +146,16 @@ static double bloom_fp(double entries) {  // blocked filter of filter.hpp: bit a
     const double lo = 1.0 - exp(-entries / (kBloomBlocks * 32.0)), hi = 1.0 - exp(-2.0 * entries / (kBloomBlocks * 32.0));
     return lo * hi * hi;
 }
-static double main_cost(uint32_t lmin, uint64_t n, const mk_matcher_options &opt) {
+constexpr double kMCandPerLaunch = 15000.0;  // million bases of the model's 15 GB launch
+static double main_cost(uint32_t lmin, uint64_t n, const mk_matcher_options &opt, bool two_class) {
     uint32_t q, S, gb;
     choose_geometry(lmin, n, opt, &q, &S, &gb);
     const double per_base = std::min(1.0 / S, (double)n / pow(4.0, (double)std::min(q, 30u))) + bloom_fp((double)n * S) / S;
-    return 0.42 * (16.0 / S) + 15000.0 * 0.0152 * per_base;
+    return 0.42 * (16.0 / S) + kMCandPerLaunch * (two_class ? 0.025 : 0.0152) * per_base;
 }
 static double short_cost(uint32_t S2, uint32_t q2, uint64_t n) {
     const double per_sample = std::min(1.0, (double)n * S2 / pow(4.0, (double)q2));
-    return (q2 <= kShortByteMaxQ ? 0.13 : 0.25) * (16.0 / S2) + 15000.0 * 0.0152 * per_sample / S2;
+    return (q2 <= kShortByteMaxQ ? 0.075 : 0.15) * (16.0 / S2) + kMCandPerLaunch * 0.025 * per_sample / S2;
 }
 // lens: pattern lengths (any order).  Only sets whose main class fits the LDS filter are split.
 static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_options &opt) {
@@ -161,11 +164,53 @@ static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_optio
     const auto mm = std::minmax_element(lens.begin(), lens.end());
     best.n_main = n;
     best.lmin_main = *mm.first;
-    // (k-mer lists -- one length -- and sets beyond the LDS filter leave here without sorting half a million lengths)
-    if (opt.length_classes == 1 || opt.force_global_filter || n > kMaxLdsEntries || *mm.first == *mm.second) return best;
+    // (k-mer lists -- one length -- leave here without sorting half a million lengths)
+    if (opt.length_classes == 1 || *mm.first == *mm.second) return best;
+    if (opt.force_global_filter || n > kMaxLdsEntries) {
+        // Main filter in global memory (hundreds of thousands of patterns): its kernels need 14-base q-grams at a stride
+        // of 2 or more, i.e. patterns of 15 bases; ONE shorter pattern sends the whole set to S = 1 with its own length
+        // as q.  Patterns below 15 bases therefore form the short class whenever the rest can keep a real stride.
+        constexpr uint32_t kGfMinLen = 15;
+        if (*mm.first >= kGfMinLen || *mm.second < kGfMinLen || (opt.force_stride && opt.length_classes != 2 && !opt.force_split_len)) return best;
+        uint32_t split = 0xFFFFFFFFu;
+        uint64_t n_short = 0;
+        for (uint32_t l : lens) {
+            if (l < kGfMinLen)
+                ++n_short;
+            else
+                split = std::min(split, l);
+        }
+        if (opt.force_split_len) {
+            split = opt.force_split_len;
+            n_short = 0;
+            for (uint32_t l : lens) n_short += l < split;
+            if (n_short == 0 || n_short == n) return best;
+        }
+        uint32_t q, S, gb;
+        choose_geometry(split, n - n_short, opt, &q, &S, &gb);
+        if (S < 2) return best;
+        for (uint32_t s2 : {8u, 4u, 2u, 1u}) {
+            if (s2 > *mm.first || (opt.force_stride2 && s2 != opt.force_stride2)) continue;
+            const uint32_t qmax = std::min<uint32_t>(kShortMaxQ, *mm.first - s2 + 1);
+            for (uint32_t q2 : {qmax, std::min(qmax, kShortByteMaxQ)}) {
+                if (opt.force_q2 && q2 != std::min<uint32_t>(opt.force_q2, qmax)) continue;
+                const double c = short_cost(s2, q2, n_short);
+                if (best.split == 0 || c < best.cost) {
+                    best.split = split;
+                    best.S2 = s2;
+                    best.q2 = q2;
+                    best.lmin_main = split;
+                    best.n_main = n - n_short;
+                    best.n_short = n_short;
+                    best.cost = c;
+                }
+            }
+        }
+        return best;
+    }
     std::sort(lens.begin(), lens.end());
     if (opt.force_stride && opt.length_classes != 2 && !opt.force_split_len) return best;  // a forced stride means the whole set
-    best.cost = main_cost(lens[0], n, opt);
+    best.cost = main_cost(lens[0], n, opt, false);
     const double single = best.cost;
     for (uint64_t i = 1; i < n; ++i) {  // short class = lens[0 .. i), split at every distinct length
         if (lens[i] == lens[i - 1]) continue;
@@ -177,7 +222,7 @@ static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_optio
             choose_geometry(split, n - i, opt, &q, &S, &gb);
             if (S < 2) continue;
         }
-        const double mc = main_cost(split, n - i, opt);
+        const double mc = main_cost(split, n - i, opt, true);
         for (uint32_t s2 : {8u, 4u, 2u, 1u}) {
             if (s2 > lens[0] || (opt.force_stride2 && s2 != opt.force_stride2)) continue;
             const uint32_t qmax = std::min<uint32_t>(kShortMaxQ, lens[0] - s2 + 1);
@@ -381,8 +426,9 @@ int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint
     if (slots > (1ull << 27))  // bucket index has 26 bits: at most 2^26 table entries (patterns x stride)
         return fail(MK_E_UNSUPPORTED, "pattern set too large (%llu table entries)", (unsigned long long)m->entries);
     m->table_slots = (uint32_t)slots;
-    const bool gf_ctx = m->gbloom_blocks != 0 && gf_has_ctx(S, q_f);
     const bool two = plan.split != 0;
+    // (two classes next to a global filter run the runtime-q kernels, which carry no context fingerprints)
+    const bool gf_ctx = m->gbloom_blocks != 0 && gf_has_ctx(S, q_f) && !two;
     const size_t bloom_words = m->gbloom_blocks ? (size_t)m->gbloom_blocks * 2 : (size_t)kBloomWords;
     // (a failing MK_HIP returns; `owner` then releases whatever was allocated so far)
     MK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
@@ -460,12 +506,18 @@ void mk_matcher_destroy(mk_matcher *m) {
     (void)hipSetDevice(m->device);
     if (m->comm) (void)mk_comm_destroy(m);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->stream_ahead) {
+        (void)hipStreamSynchronize(m->stream_ahead);
+        (void)hipStreamDestroy(m->stream_ahead);
+        for (auto &a : m->ahead)
+            if (a.ev) (void)hipEventDestroy(a.ev);
+    }
     for (auto e : m->ev_start) (void)hipEventDestroy(e);
     for (auto e : m->ev_stop) (void)hipEventDestroy(e);
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
                     (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp,
-                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux, m->d_pair, (void *)m->d_short_table, m->d_text, m->d_ing_a, m->d_ing_b})
+                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux, m->d_pair, (void *)m->d_short_table, m->d_text, m->d_ing_a, m->d_ing_b, m->ahead[0].d, m->ahead[1].d})
         if (p) (void)hipFree(p);
     delete m;
 }

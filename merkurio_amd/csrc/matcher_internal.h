@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include "filter.hpp"
@@ -76,6 +77,18 @@ struct mk_matcher {
     // mk_extract_fastq_text (ingest.hip): the window's raw text, block counts + status words, line / record tables
     void *d_text = nullptr, *d_ing_a = nullptr, *d_ing_b = nullptr;
     size_t d_text_cap = 0, d_ing_a_cap = 0, d_ing_b_cap = 0;
+    // mk_upload_text_ahead: text windows copied on a stream of their own while the current window is processed.  Two
+    // slots, so that an upload that arrives before the previous one was consumed cannot overwrite it; the slot
+    // states are guarded by ahead_mu (the uploader may be another host thread than the one inside the extract call).
+    struct AheadSlot {
+        void *d = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        const uint8_t *text = nullptr;  // != nullptr: holds (or is receiving) text[0, n), not consumed yet
+        uint64_t n = 0;
+    } ahead[2];
+    hipStream_t stream_ahead = nullptr;
+    std::mutex ahead_mu;
     // where the last driver-loop call (mk_extract_single / mk_tag_records) spent its time, milliseconds:
     // [0] upload (H2D), [1] device work (scan, ordering, sets, counts), [2] download (D2H), [3] host loops
     float batch_ms[4] = {0, 0, 0, 0};

@@ -196,8 +196,27 @@ static const char *launch_one(const ScanParams &p, int grid, hipStream_t st, con
 const char *launch_scan(const ScanParams &p, int S, bool wide, bool emit, bool global_filter, int flavour, int grid_blocks,
                         hipStream_t stream) {
     const bool plain_loads = flavour == 0;
-    if (p.s2) {  // two length classes (filter.hpp): main filter in LDS + the short class's bitmap; one load flavour
-        if (global_filter) return nullptr;
+#define MK_VARIANT_MC_GF(S_, QC_)                                                                                          \
+    return emit ? launch_one<S_, QC_, true, true, 1, 1>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",true,true,2-class>") \
+                : launch_one<S_, QC_, false, true, 1, 1>(p, grid_blocks, stream, "mk_scan_kernel<" #S_ "," #QC_ ",false,true,2-class>")
+    if (p.s2 && global_filter) {  // two length classes, main filter in global memory: the runtime-q kernels (no context fingerprints)
+        if (wide) switch (S) {
+                case 2: MK_VARIANT_MC_GF(2, -1);
+                case 4: MK_VARIANT_MC_GF(4, -1);
+                case 8: MK_VARIANT_MC_GF(8, -1);
+                case 16: MK_VARIANT_MC_GF(16, -1);
+                default: return nullptr;
+            }
+        switch (S) {
+            case 2: MK_VARIANT_MC_GF(2, 0);
+            case 4: MK_VARIANT_MC_GF(4, 0);
+            case 8: MK_VARIANT_MC_GF(8, 0);
+            case 16: MK_VARIANT_MC_GF(16, 0);
+            default: return nullptr;
+        }
+    }
+#undef MK_VARIANT_MC_GF
+    if (p.s2) {  // two length classes (filter.hpp): main filter in LDS + the short class's table; one load flavour
         if (S == 16 && p.q == 16) MK_VARIANT_MCS(16, 16);
         if (S == 8 && p.q == 24) MK_VARIANT_MCS(8, 24);
         if (S == 4 && p.q == 28) MK_VARIANT_MCS(4, 28);

@@ -518,7 +518,8 @@ __device__ __forceinline__ uint32_t sample_hash(uint32_t w0, uint32_t w1, uint32
 // (the k-mer families only: a k-mer set plus a few short motifs is the case that matters)
 template <int S, int QC, bool EMIT, bool GF, int FL, int MC = 0>
 __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams P) {
-    static_assert(!(MC != 0 && GF), "two length classes: kernels with the main filter in LDS only");
+    static_assert(!(MC != 0 && GF && QC > 0), "two length classes with the main filter in global memory: the runtime-q kernels only "
+                                              "(the context fingerprints of the fixed-q ones cover the main class's geometry)");
     constexpr bool NTL = FL != 0;  // non-temporal stream loads
     // context kernels: global filter with a compile-time q (filter.hpp: gf_has_ctx); kPipe: their
     // filter probes run one chunk ahead of their use (two samples per lane keeps that in registers)
@@ -538,13 +539,13 @@ __global__ __launch_bounds__(kBlockThreads) void mk_scan_kernel(const ScanParams
         const uint4 *src = reinterpret_cast<const uint4 *>(P.bloom);
         uint4 *dst = reinterpret_cast<uint4 *>(bloom);
         for (uint32_t i = threadIdx.x; i < kBloomWords / 4; i += kBlockThreads) dst[i] = src[i];
-        if constexpr (MC != 0) {
-            const uint4 *src2 = reinterpret_cast<const uint4 *>(P.short_bitmap);
-            uint4 *dst2 = reinterpret_cast<uint4 *>(lds_all);
-            for (uint32_t i = threadIdx.x; i < kShortBitmapWords / 4; i += kBlockThreads) dst2[i] = src2[i];
-        }
-        __syncthreads();
     }
+    if constexpr (MC != 0) {  // ... and the short class's table (also next to a main filter in global memory)
+        const uint4 *src2 = reinterpret_cast<const uint4 *>(P.short_bitmap);
+        uint4 *dst2 = reinterpret_cast<uint4 *>(lds_all);
+        for (uint32_t i = threadIdx.x; i < kShortBitmapWords / 4; i += kBlockThreads) dst2[i] = src2[i];
+    }
+    if constexpr (!GF || MC != 0) __syncthreads();
     const uint2 *__restrict__ gbloom = reinterpret_cast<const uint2 *>(P.bloom);  // GF: filter blocks in global memory
     const uint32_t gmask = P.gbloom_blocks;  // number of 64-bit filter blocks in global memory
 

@@ -5,7 +5,7 @@
 #include "scan_kernel_impl.hpp"
 
 #ifndef MK_TU
-#error "compile with -DMK_TU=0..14"
+#error "compile with -DMK_TU=0..16"
 #endif
 
 namespace mk {
@@ -23,6 +23,10 @@ void launch_variant(const ScanParams &p, int grid_blocks, hipStream_t stream) {
 #define MK_INST_MC(S_, QC_, MC_)                                                                       \
     template void launch_variant<S_, QC_, false, false, 1, MC_>(const ScanParams &, int, hipStream_t); \
     template void launch_variant<S_, QC_, true, false, 1, MC_>(const ScanParams &, int, hipStream_t)
+// two length classes next to a main filter in global memory (runtime-q kernels)
+#define MK_INST_MC_GF(S_, QC_)                                                                       \
+    template void launch_variant<S_, QC_, false, true, 1, 1>(const ScanParams &, int, hipStream_t); \
+    template void launch_variant<S_, QC_, true, true, 1, 1>(const ScanParams &, int, hipStream_t)
 // the same variant with plain (cacheable) stream loads, for hit-dense text
 #define MK_INST_PLAIN(S_, QC_, GF_)                                                               \
     template void launch_variant<S_, QC_, false, GF_, 0, 0>(const ScanParams &, int, hipStream_t); \
@@ -109,6 +113,16 @@ MK_INST_MC(16, 16, 8);
 MK_INST_MC(8, 24, 8);
 MK_INST_MC(4, 28, 8);
 MK_INST_MC(4, 18, 8);
+#elif MK_TU == 15  // two length classes, main filter in global memory, runtime q <= 16
+MK_INST_MC_GF(2, 0);
+MK_INST_MC_GF(4, 0);
+MK_INST_MC_GF(8, 0);
+MK_INST_MC_GF(16, 0);
+#elif MK_TU == 16  // ... runtime q in 17..32
+MK_INST_MC_GF(2, -1);
+MK_INST_MC_GF(4, -1);
+MK_INST_MC_GF(8, -1);
+MK_INST_MC_GF(16, -1);
 #else
 #error "unknown MK_TU"
 #endif

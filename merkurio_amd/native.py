@@ -48,7 +48,7 @@ EXPORTS = [
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_plan_geometry", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
     "mk_matcher_filter_info", "mk_matcher_class_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
-    "mk_extract_single", "mk_extract_fastq_text", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
+    "mk_extract_single", "mk_extract_fastq_text", "mk_upload_text_ahead", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
 ]
@@ -186,6 +186,7 @@ def load(build_if_missing=True):
     L.mk_extract_fastq_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p,
                                         C.POINTER(C.c_uint32)]
+    L.mk_upload_text_ahead.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.mk_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.mk_host_free.argtypes = [C.c_void_p]
     L.mk_host_free.restype = None

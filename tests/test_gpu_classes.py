@@ -58,10 +58,10 @@ def _records(rnd, raw, n_rec, alpha=b"ACGT", lens=(60, 150, 300, 700)):
     return recs
 
 
-def _family(info):
+def _family(info, global_filter=False):
     """the kernel family a main-class geometry runs with (scan_kernel.hip: launch_scan)"""
     S, q = info["stride"], info["q_gram"]
-    qc = q if (S, q) in ((16, 16), (8, 24), (4, 28), (4, 18)) else (0 if q <= 16 else -1)
+    qc = q if (S, q) in ((16, 16), (8, 24), (4, 28), (4, 18)) and not global_filter else (0 if q <= 16 else -1)
     return f"<{S},{qc},"
 
 
@@ -80,6 +80,10 @@ SPLITS = [
     ([40, 48, 65, 100], 20, [10, 11], 2, dict(length_classes=2, force_stride=8), "<8,-1,"),  # main class runtime q in 17..32
     ([40, 48, 65, 100], 20, [4], 3, dict(length_classes=2, force_stride=2), "<2,-1,"),
     ([34, 64], 20, [12], 2, dict(length_classes=2), "<16,-1,"),
+    # main filter in GLOBAL memory (what a set of hundreds of thousands of patterns gets): runtime-q kernels
+    ([31], 400, [9, 12], 2, dict(force_global_filter=True), "<16,0,"),
+    ([21], 300, [8], 1, dict(force_global_filter=True, force_stride=8), "<8,0,"),
+    ([40, 65], 100, [5, 14], 2, dict(force_global_filter=True, force_stride=4, length_classes=2), "<4,-1,"),
 ]
 
 
@@ -99,7 +103,9 @@ def test_length_classes_match_oracle(mk, case):
     assert ci["split_len"] == min(main_lens) and ci["n_short"] == len({p for p in raw_short}), ci
     for mode in (mk.MK_MODE_HITS, mk.MK_MODE_ANY):
         flags, hits = m.scan(recs, mode, hits_cap=len(exp) + 16)
-        assert family == _family(m.filter_info()) and family in m.kernel_name and m.kernel_name.endswith("2-class>"), m.kernel_name
+        gf = bool(options and options.get("force_global_filter"))
+        assert m.filter_mode()["in_lds"] is (not gf)
+        assert family == _family(m.filter_info(), gf) and family in m.kernel_name and m.kernel_name.endswith("2-class>"), m.kernel_name
         assert flags.tolist() == [bool(f) for f in found_exp], mode
         if mode == mk.MK_MODE_HITS:
             assert _tuples(hits) == exp

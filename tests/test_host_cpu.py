@@ -158,8 +158,11 @@ def test_geometry_plan_and_length_classes():
     # q-gram floor: less than one true q-gram match per 1024 random bases -> q >= 12 for 10 k patterns
     mixed = mk.plan_geometry([rnd.randrange(15, 32) for _ in range(10_000)])
     assert (mixed["stride"], mixed["q_gram"], mixed["split_len"]) == (4, 12, 0)
+    # main filter in global memory: patterns below 15 bases (no 14-base q-gram at a stride of 2) form the short class
     big = mk.plan_geometry([21] * 500_000 + [8])
-    assert big["in_lds"] == 0 and big["split_len"] == 0
+    assert (big["in_lds"], big["q_gram"], big["stride"]) == (0, 14, 8) and (big["split_len"], big["n_short"], big["stride2"]) == (21, 1, 4)
+    assert mk.plan_geometry([21] * 500_000 + [8], dict(length_classes=1))["stride"] == 1  # (the round-3 geometry)
+    assert mk.plan_geometry([21] * 500_000 + [17])["split_len"] == 0  # 17 bases still admit q = 14 at stride 4
     many = mk.plan_geometry([31] * 10_000 + [10] * 100)
     assert many["split_len"] == 31 and many["n_short"] == 100 and many["q_gram2"] >= 7
     # a short class never samples past its shortest pattern: stride + q - 1 <= length
