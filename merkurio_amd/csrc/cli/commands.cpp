@@ -232,7 +232,8 @@ static mk_matcher *make_matcher(const CommonArgs &a, const Patterns &p, bool *us
 // --gpus N: the N handles live on devices (--device + d) mod the number of visible GPUs, so that the
 // multi-device path can be rehearsed on a box with fewer GPUs (several handles then share a device)
 static std::vector<int> device_list(const CommonArgs &a) {
-    const int avail = std::max(1, mk_device_count());
+    // (one GPU: no device query here -- the first HIP call starts the runtime, 0.2 s, and belongs on the matcher thread)
+    const int avail = a.gpus > 1 ? std::max(1, mk_device_count()) : 1;
     std::vector<int> devs;
     for (int d = 0; d < std::max(1, a.gpus); ++d) devs.push_back(a.gpus > 1 ? (a.device + d) % avail : a.device);
     return devs;
@@ -341,7 +342,9 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     try {
         s1.open(a.in_fastx);
         if (paired) s2.open(*a.in_fastq_2);
-        if (device_ingest) raw_more = s1.raw_fill(raw_window, &raw_text, &raw_n, &raw_resume);
+        // (the first window is small and goes up from where it lies: page-locked buffers need the HIP runtime, which
+        // is still starting on the matcher thread; the staging of window 2 then overlaps window 1)
+        if (device_ingest) raw_more = s1.raw_fill(std::min<uint64_t>(raw_window, 32ull << 20), &raw_text, &raw_n, &raw_resume);
         if (!raw_more) more1 = s1.fill(window_bytes);
         if (paired) more2 = s2.fill(window_bytes);
     } catch (...) {
@@ -503,10 +506,12 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         std::vector<uint8_t> keep;
         std::vector<mk_row> rows(4096);
         int cur = 0;
-        stage(pin[0], raw_text, raw_n, raw_resume - raw_n);
-        tm.mark("first window into pinned memory");
+        bool first = true;
         while (raw_more) {
-            const char *text = raw_text;  // (kept records and row ids are read from the host's own copy)
+            // kept records and row ids are read from the pinned copy: the file's own mapping has not been touched by
+            // this path (pread), and every first touch of one of its pages is a fault -- 8 ms per window with logs.
+            // (The first window was never staged: it is uploaded from the reader's memory.)
+            const char *text = first ? raw_text : (const char *)pin[cur].p;
             const uint64_t n_text = raw_n;
             s1.raw_consume();
             // the next window: inflate / find its end, copy into the other pinned buffer -- beside the device work
@@ -533,7 +538,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                     if (keep.size() < rec_cap) keep.resize(rec_cap);
                     memset(&cb, 0, sizeof(cb));
                     std::fill(cnt_b.begin(), cnt_b.end(), 0);
-                    int rc = mk_extract_fastq_text(m, (const uint8_t *)pin[cur].p, n_text, lg.active, a.invert_match, rec_cap, &n_rec, rec_start.data(),
+                    int rc = mk_extract_fastq_text(m, (const uint8_t *)text, n_text, lg.active, a.invert_match, rec_cap, &n_rec, rec_start.data(),
                                                    keep.data(), rows.data(), rows.size(), &n_rows, &cb, cnt_b.data(), &status);
                     if (rc == MK_E_CAPACITY && n_rec > rec_cap) {
                         rec_cap = n_rec;
@@ -574,7 +579,16 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                             if (keep[k]) {
                                 one.recs.clear();
                                 one.parse_span(rec_start[k], rec_start[k + 1]);
-                                one.write(0, w1);
+                                // record.write(_, None) re-emits the four lines with a bare '+': a record that is
+                                // stored that way already (and ends in its line end) is written as one piece
+                                const FastxFile::Rec &r = one.recs[0];
+                                const uint64_t b = rec_start[k], e = rec_start[k + 1];
+                                const bool crlf = r.id_e < n_text && text[r.id_e] == '\r';
+                                const uint64_t nl = crlf ? 2 : 1;
+                                if (r.qual_b == r.raw_e + 2 * nl + 1 && r.qual_e + nl == e && text[e - 1] == '\n')
+                                    w1.write(text + b, (size_t)(e - b));
+                                else
+                                    one.write(0, w1);
                             }
                     }
                     tm.mark("window: rows + records out");
@@ -593,6 +607,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             raw_n = nx_n;
             raw_resume = nx_resume;
             cur ^= 1;
+            first = false;
         }
         if (raw_fd >= 0) close(raw_fd);
         if (raw_refused) {

@@ -82,7 +82,7 @@ SPLITS = [
     ([34, 64], 20, [12], 2, dict(length_classes=2), "<16,-1,"),
     # main filter in GLOBAL memory (what a set of hundreds of thousands of patterns gets): runtime-q kernels
     ([31], 400, [9, 12], 2, dict(force_global_filter=True), "<16,0,"),
-    ([21], 300, [8], 1, dict(force_global_filter=True, force_stride=8), "<8,0,"),
+    ([21], 300, [8], 1, dict(force_global_filter=True, force_stride=8, length_classes=2), "<8,0,"),
     ([40, 65], 100, [5, 14], 2, dict(force_global_filter=True, force_stride=4, length_classes=2), "<4,-1,"),
 ]
 
