@@ -105,6 +105,15 @@ def main():
         names += list(variants)
     if args.only:
         names = [n for n in names if n in args.only.split(",")]
+    if args.only and "c5" in args.only:
+        # config 5's pattern set (500 k 21-mers, main filter in global memory) with and without one 8-mer; the
+        # one-class geometry of the latter (S = 1, q = 8: every text position is a candidate) on a tenth of the shard
+        c5 = mk.parse_pattern_list(kmer_seq=bench.make_patterns(500_000, 21, seed=13))[:500_000]
+        c5p = mk.parse_pattern_list(kmer_seq=c5 + [b"GATTACAG"])
+        for name, pats, n_rec, opts in (("c5", c5, 12_500_000, None), ("c5plus8", c5p, 12_500_000, None),
+                                        ("c5plus8_one_class", c5p, 1_250_000, {"force_single_class": True})):
+            if name in args.only.split(","):
+                print(name, json.dumps(measure(mk, lib, torch, pats, n_rec, 250, args.steps, options=opts)), flush=True)
     for name in names:
         opts = {}
         if name.startswith("s") and name[1:].isdigit():

@@ -42,7 +42,7 @@ for f in find("kt/**/*kernel_trace.csv") + find("kt*kernel_trace.csv"):
             scan_name, scan_avg_us = k, sum(v) / len(v) / 1e3
     for key in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"):
         if scan_row and key in scan_row:
-            print("  scan kernel launch {}={}".format(key, scan_row[key]))
+            print("  scan kernel launch {}={}  (as the trace reports it; the compiler's own figures: profiles/r04_isa_resources.txt)".format(key, scan_row[key]))
 
 print("== PMC (per-launch average over launches of kernels matching 'mk_scan')")
 pmc = {}
@@ -61,10 +61,16 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and scan_name:
     import bench
     a = bench.parse_args(bench_args.split())
     short = re.sub(r"^void mk::", "", scan_name).split("(")[0].replace(" ", "")
-    # bench.py's kernel names leave the stream-load flavour (5th template argument) out / call it "plain"
-    m5 = re.match(r"(mk_scan_kernel<[^>]*),(true|false|0|1)>$", short)
-    if m5:
-        short = m5.group(1) + (">" if m5.group(2) in ("true", "1") else ",plain>")
+    # bench.py's kernel names (scan_kernel.hip: launch_scan) from the template arguments <S, QC, EMIT, GF, FL, MC>
+    targs = re.match(r"mk_scan_kernel<(.*)>$", short)
+    if targs:
+        t = targs.group(1).split(",")
+        fl = t[4] if len(t) > 4 else "1"
+        mc = t[5] if len(t) > 5 else "0"
+        short = "mk_scan_kernel<" + ",".join(t[:4]) + (",plain" if fl in ("0", "false") and mc in ("0", "false") else "")
+        if mc not in ("0", "false"):
+            short += (",s2=%s" % mc if mc not in ("1", "true") else "") + ",2-class"
+        short += ">"
     fetch_kb, write_kb = pmc["FETCH_SIZE"], pmc["WRITE_SIZE"]
     # gfx950 tallies a wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md, HBM): that correction
     # applies to the kernel's TEXT STREAM only (16 B per lane, every byte once + one halo chunk per 31-chunk tile),
