@@ -1,7 +1,9 @@
 """Randomised differential test: many small random pattern sets / record batches through the
 GPU path vs the oracle, covering the generic (runtime-q) kernel variants, every stride the
 geometry rule can pick, odd pattern lengths, mixed alphabets, -I, -r/-c pattern lists, forced
-BNDMq / Aho-Corasick emission orders and the global-filter mode."""
+BNDMq / Aho-Corasick emission orders, the global-filter mode, length classes (a few much shorter
+patterns next to the set: split by the rule or forced, every short-class stride / table kind, r04)
+and the FASTQ-text entry point (mk_extract_fastq_text == mk_extract_single on the same reads, r04)."""
 import os
 import random
 
@@ -33,6 +35,9 @@ def _case(rnd):
     for _ in range(n_pat):
         L = max(1, base_len + (rnd.randrange(0, 9) if mixed else 0))
         raw.append(bytes(rnd.choice(alpha) for _ in range(L)))
+    if base_len >= 15 and rnd.random() < 0.35:  # length classes: a few much shorter patterns next to the set
+        for _ in range(rnd.choice([1, 1, 2, 5])):
+            raw.append(bytes(rnd.choice(alpha) for _ in range(rnd.choice([1, 2, 3, 5, 8, 8, 9, 12, 14]))))
     recs = []
     for _ in range(rnd.choice([1, 20, 200])):
         n = rnd.choice([0, 1, base_len - 1 if base_len > 1 else 1, base_len, base_len + 1, 100, 151, 700])
@@ -66,7 +71,16 @@ def test_fuzz_vs_oracle(mk, seed):
         elif choice < 0.4 and max_len <= 64 and not ci:
             algo, q = mk.MK_ALGO_BNDMQ, rnd.choice([0, 1])
         options = dict(force_global_filter=True) if rnd.random() < 0.15 else None
-        m = mk.Matcher(patterns, algo=algo, q=q, case_insensitive=ci, options=options)
+        if rnd.random() < 0.3:  # length-class options; a set they cannot split is created by the rule instead
+            options = dict(options or {}, length_classes=rnd.choice([1, 2, 2]), force_stride2=rnd.choice([0, 0, 1, 2, 4, 8]),
+                           force_q2=rnd.choice([0, 0, 3, 6, 7, 8]))
+        try:
+            m = mk.Matcher(patterns, algo=algo, q=q, case_insensitive=ci, options=options)
+        except mk.MerkurioError as e:
+            if e.code != mk.MK_E_INVALID_ARG or not options or "length_classes" not in options:
+                raise
+            options = {k: v for k, v in options.items() if k == "force_global_filter"} or None
+            m = mk.Matcher(patterns, algo=algo, q=q, case_insensitive=ci, options=options)
         use_ac = m.use_ac
         assert use_ac == (True if (ci or algo == mk.MK_ALGO_AC) else False if algo == mk.MK_ALGO_BNDMQ
                           else ob.select_aho_corasick(ci, False, False, patterns))
@@ -76,6 +90,11 @@ def test_fuzz_vs_oracle(mk, seed):
         got = m.extract_single(recs, logging=logging, invert=invert)
         exp = ob.extract_single(om, recs, logging=logging, invert=invert)
         assert got == exp, (seed, it, patterns[:3], len(recs))
+        if it % 3 == 0 and not any(b"\n" in r or b"\r" in r for r in recs):
+            # the same reads as FASTQ text through the device's record index (ingest.hip)
+            text = b"".join(b"@r%d x\n%s\n+\n%s\n" % (i, r, b"@" * len(r)) for i, r in enumerate(recs))
+            status, rec_start, keep_t, rows_t, c_t = m.extract_fastq_text(text, logging=logging, invert=invert)
+            assert status == 0 and (keep_t, rows_t, c_t) == exp and len(rec_start) == len(recs) + 1, (seed, it)
         if len(recs) >= 2:
             h = len(recs) // 2
             assert m.extract_paired(recs[:h], recs[h:2 * h], logging=True) == ob.extract_paired(om, recs[:h], recs[h:2 * h], logging=True)
