@@ -170,6 +170,9 @@ def test_comm_single_rank_c_abi():
     assert lib.mk_comm_reduce_counters(m.handle, t.data_ptr(), 48, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert t.cpu().tolist() == list(range(48))
+    import ctypes
+    seen = ctypes.c_int(0)  # what RCCL itself says (ncclCommCount): the figure bench.py prints as "RCCL saw N ranks"
+    assert lib.mk_comm_size(m.handle, ctypes.byref(seen)) == 0 and seen.value == 1, lib.mk_last_error()
     assert lib.mk_comm_init(m.handle, idb.ctypes.data, 0, 1) == mk.MK_E_INVALID_ARG  # already initialised
     assert lib.mk_comm_destroy(m.handle) == 0
 
