@@ -40,6 +40,15 @@ struct PhaseTimer {
     }
 };
 
+// The handles of a finished command.  The program that is about to end (main.cpp: every output is flushed and closed when
+// run_extract / run_tag return, then the process leaves through _exit) does not free device memory, streams and
+// communicators one by one first: with the HIP runtime's own exit handlers that teardown was 0.15 s of a 0.6 s run.
+bool g_process_is_ending = false;
+static void release_matchers(const std::vector<mk_matcher *> &ms) {
+    if (g_process_is_ending) return;
+    for (mk_matcher *x : ms) mk_matcher_destroy(x);
+}
+
 static void mk_check(int rc, const char *what) {
     if (rc != MK_OK) bail(std::string(what) + ": " + mk_last_error());
 }
@@ -735,7 +744,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         pe.set("number_of_extracted_records", Json::integer((long long)c.nb_records_extracted));
         lg.json.finalize(meta, cj, sum, &pe);
     }
-    for (mk_matcher *x : ms) mk_matcher_destroy(x);
+    release_matchers(ms);
     return 0;
 }
 
@@ -989,7 +998,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         sum.set("number_of_distinct_records_with_a_hit", Json::integer((long long)c.nb_records_hit[0]));
         lg.json.finalize(meta, cj, sum, nullptr);
     }
-    for (mk_matcher *x : ms) mk_matcher_destroy(x);
+    release_matchers(ms);
     return 0;
 }
 

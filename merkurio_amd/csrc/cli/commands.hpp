@@ -31,6 +31,9 @@ struct CommonArgs {
     bool host_ingest = false;  // --host-ingest: extract parses FASTQ records on the host threads even where the device could index them
 };
 
+// set by main(): the process ends right after the command (handles are not destroyed one by one, commands.cpp)
+extern bool g_process_is_ending;
+
 struct ExtractArgs : CommonArgs {
     std::string in_fastx;                   // -i / -1
     std::optional<std::string> in_fastq_2;  // -2

@@ -6,6 +6,8 @@
 
 #include "commands.hpp"
 
+#include <unistd.h>
+
 using namespace cli;
 
 namespace {
@@ -192,6 +194,16 @@ void fill_common(const Parsed &p, CommonArgs &c, bool has_out) {
 
 }  // namespace
 
+// A finished command has flushed and closed every output (its Sinks and writers are locals of run_extract / run_tag):
+// the process leaves without running the HIP runtime's exit handlers and the destructors of a job that is over --
+// 0.15 s of a 0.6 s run on 20 M reads (profiles/r04_e2e_extract.txt).  Errors take the ordinary way out.
+static int leave(int rc) {
+    fflush(stdout);
+    fflush(stderr);
+    if (rc == 0) _exit(0);
+    return rc;
+}
+
 int main(int argc, char **argv) {
     std::vector<std::string> all(argv, argv + argc);
     if (argc < 2 || all[1] == "-h" || all[1] == "--help" || all[1] == "help") {
@@ -218,7 +230,8 @@ int main(int argc, char **argv) {
             if (auto v = p.get("in-fastq-2")) a.in_fastq_2 = (*v)[0];
             if (auto v = p.get("out-fastx")) a.out_fastx = (*v)[0];
             fill_common(p, a, (bool)a.out_fastx);
-            return run_extract(a, all);
+            g_process_is_ending = true;
+            return leave(run_extract(a, all));
         }
         if (sub == "tag") {
             if (rest.empty()) {
@@ -240,7 +253,8 @@ int main(int argc, char **argv) {
             fill_common(p, a, (bool)a.out_file);
             if (a.filter_matching && a.invert_match)
                 usage_error("the argument '--filter-matching' cannot be used with '--invert-match'");
-            return run_tag(a, all);
+            g_process_is_ending = true;
+            return leave(run_tag(a, all));
         }
         usage_error("unrecognized subcommand '" + sub + "'");
     } catch (const Error &e) {

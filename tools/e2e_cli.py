@@ -32,6 +32,13 @@ rec[:, -1] = ord("\n")
 rec.tofile(fq)
 open(km, "wb").write(b"\n".join(p.tobytes() for p in pats) + b"\n")
 print(f"generated {n} reads ({os.path.getsize(fq) / 1e6:.0f} MB FASTQ) in {time.time() - t0:.1f} s", flush=True)
+GZ = bool(os.environ.get("MERKURIO_E2E_GZ"))
+m_small = min(n, 4_000_000)
+raw_small = rec[:m_small].tobytes() if GZ else None
+# the timed runs are children of this process: drop its 12 GB of arrays first (a fork of a large parent is not free)
+del rec, bases, hdr
+import gc
+gc.collect()
 binp = os.path.join(ROOT, "merkurio_amd", "lib", "merkurio")
 LOGS = ["-l", os.path.join(tmp, "e2e.log"), "-j", os.path.join(tmp, "e2e.json")]
 
@@ -54,12 +61,11 @@ for rep in range(2):  # (the first process on a fresh box also pays the GPU's st
 run("extract -l -j, device ingest", fq, LOGS, n)
 run("extract -l -j, --host-ingest", fq, LOGS + ["--host-ingest"], n)
 
-if os.environ.get("MERKURIO_E2E_GZ"):
+if GZ:
     import zlib
     from concurrent.futures import ThreadPoolExecutor
-    m = min(n, 4_000_000)
-    rec_bytes = rec.shape[1]
-    raw = rec[:m].tobytes()
+    m = m_small
+    raw = raw_small
     small = os.path.join(tmp, "e2e_small.fastq")
     open(small, "wb").write(raw)
     t0 = time.time()
