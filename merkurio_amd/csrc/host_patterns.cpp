@@ -87,8 +87,13 @@ void parallel_for(unsigned T, uint64_t n, F f) {
             if (!err) err = std::current_exception();
         }
     };
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(run, n * t / T, n * (t + 1) / T);
+    unsigned started = 1;
+    try {
+        for (; started < T; ++started) th.emplace_back(run, n * started / T, n * (started + 1) / T);
+    } catch (...) {  // no more threads to be had: the caller's thread takes the slices that got none
+    }
     run(0, n / T);
+    for (unsigned t = started; t < T; ++t) run(n * t / T, n * (t + 1) / T);
     for (auto &x : th) x.join();
     if (err) std::rethrow_exception(err);
 }
@@ -256,6 +261,8 @@ int mk_parse_pattern_list(const uint8_t *in_bytes, const uint32_t *in_off, uint3
                           uint32_t *out_n) {
     if (!out_bytes || !out_off || !out_n || (n_in && (!in_off || !in_bytes)))
         return mk::fail(MK_E_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < n_in; ++i)
+        if (in_off[i + 1] < in_off[i]) return mk::fail(MK_E_INVALID_ARG, "pattern offsets not monotone");
     MK_ABI_BEGIN
     // One flat arena (the transformed inputs, then their reverse complements) and one 16-byte reference per pattern:
     // no allocation per pattern.  Every stage runs on all host threads for lists of 50 k patterns and more
