@@ -56,7 +56,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel, n_rec, read_len, n_pat):
+def measured_traffic(kernel, n_rec, read_len, n_pat, plant_every=100):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this
     exact workload AND this exact kernel source (profiles/traffic_rNN.json: rocprofv3
     FETCH_SIZE/WRITE_SIZE passes, gfx950 correction applied).  -> (bytes | None, source note)"""
@@ -68,8 +68,8 @@ def measured_traffic(kernel, n_rec, read_len, n_pat):
             j = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if (j.get("kernel"), j.get("records_per_gpu"), j.get("read_len"), j.get("patterns")) != \
-                (kernel, n_rec, read_len, n_pat):
+        if (j.get("kernel"), j.get("records_per_gpu"), j.get("read_len"), j.get("patterns"), j.get("plant_every", 100)) != \
+                (kernel, n_rec, read_len, n_pat, plant_every):
             continue
         if j.get("kernel_source_sha16") == cur:
             best = (j["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
@@ -421,7 +421,7 @@ def main():
         if rehearsal:
             out["rehearsal"] = True
             out["rehearsal_note"] = f"{world} ranks share {n_dev} GPU(s): functional check, not a scaling measurement"
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, len(patterns))
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, len(patterns), args.plant_every)
         if world == 1 and not args.no_cpu_baseline and not args.paired and not args.ragged:
             out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, mates[0][2],
                                                args.cpu_seconds)
@@ -495,7 +495,7 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
              "records_hit_per_launch": int(summ[mk.MK_SUM_RECORDS_HIT]) // steps, "hits_per_launch": int(summ[mk.MK_SUM_HITS]) // steps,
              "filter_candidates_per_launch": int(summ[mk.MK_SUM_CANDIDATES]) // steps}
         # counter traffic exists for workloads that were profiled under rocprofv3 with this kernel source (profiles/traffic_*.json)
-        r["traffic"], r["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, n_pat)
+        r["traffic"], r["traffic_source"] = measured_traffic(m.kernel_name, n_rec, L, n_pat, plant_every)
         if r["traffic"] is None and r["traffic_source"] is None:
             r["traffic_source"] = "no committed PMC profile of this workload (tools/profile_gpu.sh writes one per workload it is run on)"
         if emit:
@@ -582,7 +582,8 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
                 "kernel": m0.kernel_name, "steps": steps, "launches_per_step": 2, "ms_per_step": round(dt / steps * 1e3, 4),
                 "value_gbases_per_s": round(2 * n3 * L0 * steps / dt / 1e9, 1), "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes_per_launch": algo, "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "pairs_kept": int(d_keep[:n3].sum().item())})
+                "pairs_kept": int(d_keep[:n3].sum().item()), "traffic": None,
+                "traffic_source": "no committed PMC profile of this workload (tools/profile_gpu.sh writes one per workload it is run on)"})
     del pair, d_keep
 
     m, a, b, c, n_pat = fresh(10_000_000, 150, 1024, 31, True, 100, 11)

@@ -48,39 +48,54 @@ int hip_fail(hipError_t e, const char *what) {
 // Larger S = fewer probes per base (the scan is VALU-bound: ~17 vector ops per probe) but S x
 // more filter entries, i.e. more false positives to verify.  Measured on MI355X with 10 k
 // 31-mers (profiles/r01_stride_sweep.txt): S=8 (80 k entries, 0.2 % of bases become
-// candidates) beats S=4 by 14 % and S=16 by 60 %.  Rule: largest S with <= 96 k entries and
-// q-grams long enough that random text matches one of them less than once per 1024 bases
-// (n / 4^q: the true q-gram matches, which no filter removes): q >= 12 for 10 k patterns, 14 for
-// the largest sets an LDS filter holds.  (Until r04 the floor was 14 for every set: 10 000
-// patterns of 15..31 bases sampled at S=2, 4.15 ms per 15 GB, where S=4 / q=12 costs one sample
-// in two and 9 M more candidates; profiles/r04_mixed_sets.txt.)
+// candidates) beats S=4 by 14 % and S=16 by 60 %.  Rule (r04): among the strides with <= 96 k
+// entries, the one the cost model likes best -- samples against candidates, the latter being the
+// filter's false positives and the TRUE q-gram matches of random text (n / 4^q per base, which no
+// filter removes).  (Until r04: the largest S with q >= 14, for every set: 10 000 patterns of
+// 15..31 bases sampled at S=2, 4.15 ms per 15 GB, where S=4 / q=12 costs one sample in two and
+// 9 M more candidates; profiles/r04_mixed_sets.txt.)
 constexpr uint64_t kMaxLdsEntries = 98304;
-static uint32_t min_q_for(uint64_t n_pat) {
-    uint32_t q = 1;
-    while (q < 14 && (1ull << (2 * q)) < 1024 * n_pat) ++q;
-    return q;
+constexpr double kMCandPerLaunch = 15000.0;  // million bases of the cost model's 15 GB launch
+static double bloom_fp(double entries) {  // blocked filter of filter.hpp: bit a in the low word, b and c in the high word
+    const double lo = 1.0 - exp(-entries / (kBloomBlocks * 32.0)), hi = 1.0 - exp(-2.0 * entries / (kBloomBlocks * 32.0));
+    return lo * hi * hi;
+}
+// ms per 15 GB launch of a hashed class of n patterns at stride S, q-grams of q bases (fit: profiles/r04_mixed_sets.txt):
+// 0.42 per sample per 16 bases + the candidates -- true q-gram matches of random text (n / 4^q per base, at most one
+// per sample) and the filter's false positives -- at per_mcand ms per million
+static double hashed_cost(uint64_t n, uint32_t S, uint32_t q, double per_mcand) {
+    const double per_base = std::min(1.0 / S, (double)n / pow(4.0, (double)std::min(q, 30u))) + bloom_fp((double)n * S) / S;
+    return 0.42 * (16.0 / S) + kMCandPerLaunch * per_mcand * per_base;
 }
 static void choose_geometry(uint32_t lmin, uint64_t n_pat, const mk_matcher_options &opt, uint32_t *q, uint32_t *S,
                             uint32_t *gblocks) {
     const int forced = (int)opt.force_stride;  // tuning / test hooks: mk_matcher_create_ex only
     const bool force_global = opt.force_global_filter != 0;
     *gblocks = 0;
-    if (n_pat <= kMaxLdsEntries && !force_global) {  // LDS filter
-        const uint32_t q_floor = min_q_for(n_pat);
-        for (uint32_t s : {16u, 8u, 4u, 2u, 1u}) {
-            if (s > lmin) continue;
-            uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
-            if (forced) {
-                if ((int)s != forced) continue;
-            } else if (s > 1 && (qq < q_floor || n_pat * s > kMaxLdsEntries)) {
-                continue;
-            }
-            *q = qq;
-            *S = s;
-            return;
-        }
+    if (n_pat <= kMaxLdsEntries && !force_global) {  // LDS filter: the stride the cost model likes best
         *q = std::min<uint32_t>(32, lmin);
         *S = 1;
+        double best = 1e300;
+        for (uint32_t s : {16u, 8u, 4u, 2u, 1u}) {
+            if (s > lmin) continue;
+            const uint32_t qq = std::min<uint32_t>(32, lmin - s + 1);
+            if (forced) {
+                if ((int)s != forced) continue;
+                *q = qq;
+                *S = s;
+                return;
+            }
+            if (s > 1 && n_pat * s > kMaxLdsEntries) continue;
+            // (the model knows nothing of bucket chains: more than ~2 table entries per distinct q-gram -- thousands of
+            // patterns on a q-gram of a base or two -- and every candidate walks its key's whole chain)
+            if (s > 1 && qq < 16 && (double)n_pat * s > 2.0 * pow(4.0, (double)qq)) continue;
+            const double c = hashed_cost(n_pat, s, qq, 0.0152);
+            if (c < best) {
+                best = c;
+                *q = qq;
+                *S = s;
+            }
+        }
         return;
     }
     // Large set: the filter moves to global memory, where every sample costs a random 8-byte
@@ -142,16 +157,10 @@ struct ClassPlan {
     uint64_t n_main = 0, n_short = 0;
     double cost = 0;
 };
-static double bloom_fp(double entries) {  // blocked filter of filter.hpp: bit a in the low word, b and c in the high word
-    const double lo = 1.0 - exp(-entries / (kBloomBlocks * 32.0)), hi = 1.0 - exp(-2.0 * entries / (kBloomBlocks * 32.0));
-    return lo * hi * hi;
-}
-constexpr double kMCandPerLaunch = 15000.0;  // million bases of the model's 15 GB launch
 static double main_cost(uint32_t lmin, uint64_t n, const mk_matcher_options &opt, bool two_class) {
     uint32_t q, S, gb;
     choose_geometry(lmin, n, opt, &q, &S, &gb);
-    const double per_base = std::min(1.0 / S, (double)n / pow(4.0, (double)std::min(q, 30u))) + bloom_fp((double)n * S) / S;
-    return 0.42 * (16.0 / S) + kMCandPerLaunch * (two_class ? 0.025 : 0.0152) * per_base;
+    return hashed_cost(n, S, q, two_class ? 0.025 : 0.0152);
 }
 static double short_cost(uint32_t S2, uint32_t q2, uint64_t n) {
     const double per_sample = std::min(1.0, (double)n * S2 / pow(4.0, (double)q2));
@@ -228,6 +237,7 @@ static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_optio
             const uint32_t qmax = std::min<uint32_t>(kShortMaxQ, lens[0] - s2 + 1);
             for (uint32_t q2 : {qmax, std::min(qmax, kShortByteMaxQ)}) {
                 if (opt.force_q2 && q2 != std::min<uint32_t>(opt.force_q2, qmax)) continue;
+                if (!opt.force_stride2 && !opt.force_q2 && s2 > 1 && (double)i * s2 > 2.0 * pow(4.0, (double)q2)) continue;  // bucket chains
                 const double c = mc + short_cost(s2, q2, i);
                 const bool forced = opt.length_classes == 2 || opt.force_split_len;
                 // a split must pay for the second code path: 10 % below the single class

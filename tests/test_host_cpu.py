@@ -155,9 +155,13 @@ def test_geometry_plan_and_length_classes():
     assert mk.plan_geometry([31] * 10_000 + [8], dict(length_classes=1))["stride"] == 1
     assert mk.plan_geometry([31] * 10_000 + [8], dict(force_stride=1))["split_len"] == 0
     assert mk.plan_geometry([31] * 2048)["stride"] == 16 and mk.plan_geometry([21] * 10_000)["q_gram"] == 14
-    # q-gram floor: less than one true q-gram match per 1024 random bases -> q >= 12 for 10 k patterns
+    # the stride is the cost model's choice (samples against candidates: filter false positives + true q-gram matches)
     mixed = mk.plan_geometry([rnd.randrange(15, 32) for _ in range(10_000)])
     assert (mixed["stride"], mixed["q_gram"], mixed["split_len"]) == (4, 12, 0)
+    twelve, nine = mk.plan_geometry([12] * 10_000), mk.plan_geometry([9] * 5)
+    assert (twelve["stride"], twelve["q_gram"]) == (2, 11) and (nine["stride"], nine["q_gram"]) == (4, 6)
+    # never a stride that puts thousands of entries on one q-gram (10 001 patterns at S = 8 would share 4 one-base keys)
+    assert mk.plan_geometry([31] * 10_000 + [8], dict(length_classes=1))["q_gram"] == 8
     # main filter in global memory: patterns below 15 bases (no 14-base q-gram at a stride of 2) form the short class
     big = mk.plan_geometry([21] * 500_000 + [8])
     assert (big["in_lds"], big["q_gram"], big["stride"]) == (0, 14, 8) and (big["split_len"], big["n_short"], big["stride2"]) == (21, 1, 4)

@@ -114,6 +114,16 @@ def main():
                                         ("c5plus8_one_class", c5p, 1_250_000, {"force_single_class": True})):
             if name in args.only.split(","):
                 print(name, json.dumps(measure(mk, lib, torch, pats, n_rec, 250, args.steps, options=opts)), flush=True)
+    if args.only and "len12" in args.only:
+        # 10 000 12-mers at forced strides 1, 2, 4 (q = 12, 11, 9): where the cost model's stride crosses over
+        k12 = mk.parse_pattern_list(kmer_seq=bench.make_patterns(10_000, 12, seed=21))[:10_000]
+        for st in (0, 1, 2, 4):
+            print(f"len12_s{st}", json.dumps(measure(mk, lib, torch, k12, args.records, args.read_len, args.steps,
+                                                     options={"force_stride": st} if st else None)), flush=True)
+        k9 = mk.parse_pattern_list(kmer_seq=bench.make_patterns(5, 9, seed=22))[:5]
+        for st in (0, 2, 4):
+            print(f"five9_s{st}", json.dumps(measure(mk, lib, torch, k9, args.records, args.read_len, args.steps,
+                                                     options={"force_stride": st} if st else None)), flush=True)
     for name in names:
         opts = {}
         if name.startswith("s") and name[1:].isdigit():

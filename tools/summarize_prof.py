@@ -86,7 +86,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and scan_name:
         "command": "python3 bench.py " + bench_args,
         "kernel": short,
         "kernel_source_sha16": bench.kernel_source_hash(),
-        "records_per_gpu": a.records, "read_len": a.read_len, "patterns": a.patterns * (2 if a.rc else 1),
+        "records_per_gpu": a.records, "read_len": a.read_len, "patterns": a.patterns * (2 if a.rc else 1), "plant_every": a.plant_every,
         "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
         "correction": "gfx950 tallies 16 B/lane streaming reads at half size (MI355X_MICROARCH.md HBM section): the text stream "
                       "(records x read_len x 32/31 bytes, known) is counted twice, the random reads (the rest of FETCH_SIZE) once; WRITE_SIZE exact",
