@@ -162,7 +162,8 @@ typedef struct {
 int mk_matcher_create_ex(const uint8_t *pat_bytes, const uint32_t *pat_off, uint32_t n_pat, uint32_t algo, uint32_t q,
                          uint32_t flags, int32_t device, const mk_matcher_options *options, mk_matcher **out);
 /* The filter geometry mk_matcher_create_ex would choose for patterns of these lengths, without creating anything (host
- * only, no device needed): main-class q-gram length and stride, whether the level-1 filter fits LDS, and the length
+ * only, no device needed) -- this library's counterpart of what AhoCorasick::builder()...build() decides about its
+ * automaton from the pattern list (src/cmd_extract.rs:260-265), which scans any list at one speed: main-class q-gram length and stride, whether the level-1 filter fits LDS, and the length
  * classes (see mk_matcher_class_info).  Any output pointer may be NULL. */
 int mk_plan_geometry(const uint32_t *pat_len, uint32_t n_pat, const mk_matcher_options *options, uint32_t *q_gram, uint32_t *stride,
                      uint32_t *in_lds, uint32_t *split_len, uint32_t *n_short, uint32_t *q_gram2, uint32_t *stride2);
