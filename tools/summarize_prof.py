@@ -38,18 +38,20 @@ for f in find("kt/**/*kernel_trace.csv") + find("kt*kernel_trace.csv"):
     print("== kernel trace:", os.path.relpath(f, out))
     for k, v in d.items():
         print("  {:60.60s} n={} avg_us={:.1f} min_us={:.1f} max_us={:.1f}".format(k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
-        if "mk_scan_kernel" in k:
+        # the scan kernel of the run = the mk_scan_kernel variant launched most often (a hit-dense run launches the
+        # sparse flavour during its warm-up and the dense one afterwards)
+        if "mk_scan_kernel" in k and (scan_name is None or len(v) > len(d[scan_name])):
             scan_name, scan_avg_us = k, sum(v) / len(v) / 1e3
     for key in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"):
         if scan_row and key in scan_row:
             print("  scan kernel launch {}={}  (as the trace reports it; the compiler's own figures: profiles/r04_isa_resources.txt)".format(key, scan_row[key]))
 
-print("== PMC (per-launch average over launches of kernels matching 'mk_scan')")
+print("== PMC (per-launch average over the launches of %s)" % (scan_name or "kernels matching 'mk_scan'"))
 pmc = {}
 for f in find("pmc*/**/*counter_collection.csv"):
     acc = defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if "mk_scan" not in row["Kernel_Name"]:
+        if "mk_scan" not in row["Kernel_Name"] or (scan_name and row["Kernel_Name"] != scan_name):
             continue
         acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in sorted(acc.items()):
