@@ -851,6 +851,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
             while (b1 < r1 && (bytes < batch_bytes || b1 == b0)) bytes += sam.recs[b1++].l_seq;
             const size_t nb = b1 - b0;
             sam.gather(b0, b1, seq, off);
+            if (ms.size() == 1) tm.mark("  batch: gather");
             keep.assign(nb, 0);
             foff.assign(nb + 1, 0);
             uint64_t n_rows = 0;
@@ -872,6 +873,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
                 for (size_t k = 0; k < cnts.size(); ++k) cnts[k] += cnt_b[k];
                 break;
             }
+            if (ms.size() == 1) tm.mark("  batch: mk_tag_records");
             BatchOut out;
             if (lg.active) {
                 out.rows.assign(rows.begin(), rows.begin() + n_rows);
@@ -931,6 +933,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
                     }
                 });
             }
+            if (ms.size() == 1) tm.mark("  batch: tag values + encode");
             on_batch(std::move(out));
             b0 = b1;
         }
@@ -941,10 +944,11 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     for (auto &x : dev_c) memset(&x, 0, sizeof(x));
     while (sam.fill(window_bytes)) {
         const size_t n = sam.recs.size();
+        tm.mark("window: read (inflate) + index");
         if (ms.size() == 1) {
             scan_range(m, dev_bufs[0], 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
                 emit(o);
-                tm.mark("batch: gather + scan + tag + write");
+                tm.mark("  batch: rows + write");
             });
         } else {
             // --gpus N: contiguous record ranges of the window per device, one host thread each; batch results
