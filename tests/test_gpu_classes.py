@@ -109,6 +109,12 @@ def test_length_classes_match_oracle(mk, case):
         assert flags.tolist() == [bool(f) for f in found_exp], mode
         if mode == mk.MK_MODE_HITS:
             assert _tuples(hits) == exp
+    # records of ONE length: mk_scan_batch sees that from its offsets and the kernel computes the record of an occurrence
+    # instead of looking it up (the fixed-length path of the two-class kernels)
+    eq = [r[:60] for r in recs if len(r) >= 60]
+    exp_eq, _, found_eq = _oracle(patterns, True, eq)
+    flags_eq, hits_eq = m.scan(eq, mk.MK_MODE_HITS, hits_cap=len(exp_eq) + 16)
+    assert _tuples(hits_eq) == exp_eq and flags_eq.tolist() == [bool(f) for f in found_eq]
     # the same set as ONE class: same answer (what round 3 computed, at the stride the shortest pattern dictates)
     one = mk.Matcher(patterns, algo=mk.MK_ALGO_AC, options=dict(length_classes=1))
     assert one.class_info()["split_len"] == 0
