@@ -420,6 +420,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         std::vector<mk_row> rows = std::vector<mk_row>(4096);
     };
     std::vector<DevBuffers> dev_bufs(ms.size());
+    double call_ms[4] = {0, 0, 0, 0};  // MERKURIO_TIMING: phases inside mk_extract_single / _paired, summed (one device)
     auto scan_range = [&](mk_matcher *mm, DevBuffers &DB, size_t r0, size_t r1, mk_counters &cc, std::vector<uint32_t> &cnts, auto on_batch) {
         Batch(&bufs)[2] = DB.bufs;
         std::vector<uint8_t> &keep = DB.keep;
@@ -463,6 +464,11 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                         continue;
                     }
                     mk_check(rc, "Error during matching");
+                    if (tm.on && ms.size() == 1) {  // where the call itself spent its time: upload / device / download / host loop
+                        float ms4[4] = {0, 0, 0, 0};
+                        if (mk_matcher_batch_times(mm, ms4) == MK_OK)
+                            for (int k = 0; k < 4; ++k) call_ms[k] += ms4[k];
+                    }
                     cc.nb_records_tot += cb.nb_records_tot; cc.nb_bases += cb.nb_bases;
                     cc.nb_hits_tot[0] += cb.nb_hits_tot[0]; cc.nb_hits_tot[1] += cb.nb_hits_tot[1];
                     cc.nb_records_hit[0] += cb.nb_records_hit[0]; cc.nb_records_hit[1] += cb.nb_records_hit[1];
@@ -706,6 +712,9 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     w1.flush();
     w2.flush();
     tm.mark("log rows + write records");
+    if (tm.on && (call_ms[0] + call_ms[1] + call_ms[2] + call_ms[3]) > 0)
+        fprintf(stderr, "[timing] inside the batch calls: upload %.3f s, device %.3f s, download %.3f s, host loop %.3f s\n", call_ms[0] * 1e-3,
+                call_ms[1] * 1e-3, call_ms[2] * 1e-3, call_ms[3] * 1e-3);
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, paired);
