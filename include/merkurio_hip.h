@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 4
+#define MK_ABI_VERSION 5
 
 /* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
 #define MK_OK 0
@@ -47,6 +47,7 @@ extern "C" {
 #define MK_E_INVALID_ARG (-9)
 #define MK_E_UNSUPPORTED (-10)
 #define MK_E_RCCL (-11) /* RCCL missing or a collective failed (counter reduction only) */
+#define MK_E_CORRUPT (-12) /* a BGZF member that does not inflate to its ISIZE / CRC-32 (mk_bgzf_inflate) */
 
 /* algorithm selector: what the reference's `-a` / `-q` / auto rule decides
  * (src/cmd_extract.rs:166-171, src/helpers.rs:203-211).  The device scan is the same for
@@ -397,6 +398,49 @@ int mk_comm_reduce_counters(mk_matcher *m, void *d_counters, size_t len, void *s
 /* ranks of the handle's communicator as RCCL reports them (ncclCommCount) */
 int mk_comm_size(const mk_matcher *m, int *n_ranks);
 int mk_comm_destroy(mk_matcher *m);
+
+/* -------------------------------------------------------------------------------------
+ * BGZF codec on the device (v5) -- the (de)compression either side of the hot path for BAM and bgzip'ed FASTA/FASTQ.
+ * Replaces what the reference gets from `bam 0.1.4` / flate2 on `tag`'s reader and writer threads
+ * (src/cmd_tag.rs:254-271 writer, :503-615 reader + record loop) and from needletail's gzip reader
+ * (src/cmd_extract.rs:281): BGZF (SAM specification 4.1) is a series of independent gzip members of at most 64 KiB,
+ * so members map to waves (deflate) and lanes (inflate).  A handle owns a stream and its device buffers, is bound to
+ * one device and serialises its calls; independent of any mk_matcher.
+ *
+ * mk_bgzf_deflate: in[0, n) -> ceil(n / block_bytes) complete members back to back in out (block_bytes <= 65280;
+ * 0 = 65280, what htslib writes).  The members inflate to `in` exactly, with correct CRC-32 / ISIZE / BSIZE; their
+ * compressed bytes are this library's own parse (not zlib's).  No EOF marker is appended (mk_bgzf_eof gives its 28
+ * bytes).  out_cap >= mk_bgzf_deflate_bound(n, block_bytes), else MK_E_CAPACITY with *out_len = that bound.
+ *
+ * mk_bgzf_inflate: the n_members members the caller found in in[0, n_in) by walking the BSIZE chain -> their text at
+ * out + out_off.  Every member is checked: stream errors, ISIZE and CRC-32 (on the device).  A damaged member:
+ * MK_E_CORRUPT, *bad_member = the first one, its status word in mk_last_error().  The call overwrites the span of out
+ * its members cover (min out_off .. max out_off + isize: gaps between members included), nothing outside it.
+ * --------------------------------------------------------------------------------------- */
+typedef struct mk_codec mk_codec;
+typedef struct mk_bgzf_member {
+    uint64_t data_off; /* first byte of the raw DEFLATE stream (member start + 12 + XLEN) */
+    uint64_t out_off;  /* where the member's text goes */
+    uint32_t data_len; /* BSIZE + 1 - XLEN - 20 */
+    uint32_t isize;    /* the trailer's ISIZE (<= 65536) */
+    uint32_t crc;      /* the trailer's CRC-32 */
+    uint32_t reserved;
+} mk_bgzf_member;
+int mk_codec_create(int device, mk_codec **out);
+void mk_codec_destroy(mk_codec *c);
+uint64_t mk_bgzf_deflate_bound(uint64_t n, uint32_t block_bytes);
+int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_bytes, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf_member *members, uint64_t n_members, uint8_t *out,
+                    uint64_t out_cap, uint64_t *bad_member);
+/* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,
+ * *consumed = bytes of whole members, *text_bytes = sum of ISIZE.  MK_E_CORRUPT where a header is not BGZF; a trailing
+ * partial member is not an error (*consumed < n).  Host code, no device. */
+int mk_bgzf_members(const uint8_t *in, uint64_t n, mk_bgzf_member *members, uint64_t cap, uint64_t *n_members, uint64_t *consumed,
+                    uint64_t *text_bytes);
+/* the 28-byte empty member that ends a BGZF file */
+const uint8_t *mk_bgzf_eof(void);
+/* milliseconds of the handle's last call: [0] upload, [1] kernels, [2] download */
+int mk_codec_times(const mk_codec *c, float ms[3]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,39 @@
+// bgzf_inflate.hip -- BGZF members inflated on the device, ONE LANE per member.
+//
+// Replaces, behind mk_bgzf_inflate (include/merkurio_hip.h), the inflate the reference gets from flate2 inside
+// `bam 0.1.4`'s reader (src/cmd_tag.rs:503-506) and needletail's gzip reader for bgzip'ed FASTA/FASTQ
+// (src/cmd_extract.rs:281).  DEFLATE decoding is serial inside a stream -- every codeword's position depends on the
+// one before it -- but BGZF cuts a file into independent members of <= 64 KiB, thousands per window: the lanes of a
+// wave each decode their own member with the serial decoder of inflate_serial.hpp (the code the host harness checks
+// against zlib), their fast decode tables side by side in LDS (1 152 B per lane, 72 KiB per wave), the rest of the
+// per-stream state (canonical orders for the rare long codewords, the code lengths while a header is read) in
+// private memory.  Bound: latency of dependent LDS / L2 accesses under divergence, hidden only by the number of
+// members in flight (64 per wave, 2 waves per CU: 32 768 streams on the part) -- not HBM, not MFMA.
+// The CRC-32 of every member's text is checked by mk_bgzf_crc_check_kernel (bgzf_deflate.hip) afterwards.
+#include <hip/hip_runtime.h>
+
+#include "codec_kernels.h"
+#include "inflate_serial.hpp"
+
+namespace mkz {
+
+constexpr uint32_t kFastPerLane = kLlFastSize + kDFastSize;
+
+__global__ __launch_bounds__(64) void mk_bgzf_inflate_kernel(const uint8_t *__restrict__ in, uint64_t n_in, const Member *__restrict__ members,
+                                                             uint32_t n_members, uint8_t *__restrict__ out, int32_t *__restrict__ status) {
+    __shared__ uint16_t fast[64 * kFastPerLane];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_members) return;
+    const Member m = members[i];
+    InflateScratch s;
+    uint16_t *const ll = fast + threadIdx.x * kFastPerLane;
+    status[i] = inflate_stream(in + m.data_off, m.data_len, out + m.out_off, m.isize, ll, ll + kLlFastSize, s);
+}
+
+void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status,
+                    hipStream_t s) {
+    if (!n_members) return;
+    hipLaunchKernelGGL(mk_bgzf_inflate_kernel, dim3((n_members + 63) / 64), dim3(64), 0, s, in, n_in, members, n_members, out, status);
+}
+
+}  // namespace mkz

@@ -1,0 +1,260 @@
+// codec_host.cpp -- host side of the C ABI's BGZF codec (include/merkurio_hip.h, v5): the mk_codec handle, its device
+// buffers, chunking of a call into device-sized pieces, the BSIZE walk.  Kernels: bgzf_deflate.hip, bgzf_inflate.hip.
+// Reference interface replaced: the BGZF reader / writer of `bam 0.1.4` as `merkurio tag` drives it
+// (src/cmd_tag.rs:254-271 `BamWriter::build().write_header(..).from_path`, :503-506 `BamReader::from_path(.., threads)`)
+// and needletail's gzip reader on bgzip'ed inputs (src/cmd_extract.rs:281).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "../host_common.h"
+#include "codec_kernels.h"
+
+namespace mk {
+int hip_fail(hipError_t e, const char *what);
+int ensure_device(void **p, size_t *cap, size_t need);
+}  // namespace mk
+
+struct mk_codec {
+    int device = 0, num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu;
+    // deflate: input chunk, per-block CRCs / sizes / offsets, token scratch, member slots, packed members
+    // inflate: compressed chunk (d_in), member table (d_aux), text (d_out), status words (d_len)
+    void *d_in = nullptr, *d_crc = nullptr, *d_tokens = nullptr, *d_slots = nullptr, *d_len = nullptr, *d_off = nullptr, *d_out = nullptr,
+         *d_aux = nullptr;
+    size_t in_cap = 0, crc_cap = 0, tokens_cap = 0, slots_cap = 0, len_cap = 0, off_cap = 0, out_cap = 0, aux_cap = 0;
+    float ms[3] = {0, 0, 0};
+};
+
+namespace {
+
+constexpr uint64_t kDeflateChunkBlocks = 4096;     // members per device pass (255 MiB of text)
+constexpr uint64_t kInflateChunkText = 256u << 20;  // text bytes per device pass
+
+#define MKC_HIP(call, what)                                   \
+    do {                                                      \
+        const hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return mk::hip_fail(e_, what);  \
+    } while (0)
+
+float elapsed(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
+}
+
+const uint8_t kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+}  // namespace
+
+extern "C" {
+
+int mk_codec_create(int device, mk_codec **out) {
+    MK_ABI_BEGIN
+    if (!out) return mk::fail(MK_E_INVALID_ARG, "mk_codec_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return mk::fail(MK_E_HIP, "no HIP device (the BGZF codec has no CPU path)");
+    if (device < 0 || device >= n) return mk::fail(MK_E_INVALID_ARG, "mk_codec_create: device %d of %d", device, n);
+    MKC_HIP(hipSetDevice(device), "hipSetDevice");
+    mk_codec *c = new mk_codec;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+    if (e != hipSuccess) {
+        mk_codec_destroy(c);
+        return mk::hip_fail(e, "mk_codec_create");
+    }
+    *out = c;
+    return MK_OK;
+    MK_ABI_END
+}
+
+void mk_codec_destroy(mk_codec *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : {c->d_in, c->d_crc, c->d_tokens, c->d_slots, c->d_len, c->d_off, c->d_out, c->d_aux})
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+uint64_t mk_bgzf_deflate_bound(uint64_t n, uint32_t block_bytes) {
+    const uint64_t bb = block_bytes ? block_bytes : mkz::kMaxBlockBytes;
+    const uint64_t blocks = (n + bb - 1) / bb;
+    return n + blocks * 31;  // a stored member: 18 + 5 + text + 8
+}
+
+const uint8_t *mk_bgzf_eof(void) { return kEof; }
+
+int mk_codec_times(const mk_codec *c, float ms[3]) {
+    if (!c || !ms) return mk::fail(MK_E_INVALID_ARG, "mk_codec_times: NULL argument");
+    for (int k = 0; k < 3; ++k) ms[k] = c->ms[k];
+    return MK_OK;
+}
+
+int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_bytes, uint8_t *out, uint64_t out_cap, uint64_t *out_len) {
+    MK_ABI_BEGIN
+    if (!c || !out_len || (n && (!in || !out))) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: NULL argument");
+    const uint32_t bb = block_bytes ? block_bytes : mkz::kMaxBlockBytes;
+    if (bb > mkz::kMaxBlockBytes) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: block_bytes %u > %u", bb, mkz::kMaxBlockBytes);
+    const uint64_t bound = mk_bgzf_deflate_bound(n, bb);
+    *out_len = 0;
+    if (out_cap < bound) {
+        *out_len = bound;
+        return mk::fail(MK_E_CAPACITY, "mk_bgzf_deflate: out_cap %llu < bound %llu", (unsigned long long)out_cap, (unsigned long long)bound);
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    MKC_HIP(hipSetDevice(c->device), "hipSetDevice");
+    c->ms[0] = c->ms[1] = c->ms[2] = 0;
+    const uint64_t chunk_bytes = kDeflateChunkBlocks * bb;
+    uint64_t written = 0;
+    for (uint64_t at = 0; at < n; at += chunk_bytes) {
+        const uint64_t cn = std::min<uint64_t>(chunk_bytes, n - at);
+        const uint32_t blocks = (uint32_t)((cn + bb - 1) / bb);
+        const uint32_t grid = mkz::deflate_grid(blocks, c->num_cus);
+        int rc;
+        if ((rc = mk::ensure_device(&c->d_in, &c->in_cap, cn + mkz::kPad)) || (rc = mk::ensure_device(&c->d_crc, &c->crc_cap, blocks * 4ull)) ||
+            (rc = mk::ensure_device(&c->d_tokens, &c->tokens_cap, (uint64_t)grid * mkz::kTokensPerWave * 4)) ||
+            (rc = mk::ensure_device(&c->d_slots, &c->slots_cap, (uint64_t)blocks * mkz::kSlotBytes)) ||
+            (rc = mk::ensure_device(&c->d_len, &c->len_cap, blocks * 4ull)) || (rc = mk::ensure_device(&c->d_off, &c->off_cap, (blocks + 1) * 8ull)) ||
+            (rc = mk::ensure_device(&c->d_out, &c->out_cap, mk_bgzf_deflate_bound(cn, bb))))
+            return rc;
+        uint64_t *d_total = (uint64_t *)c->d_off + blocks;
+        MKC_HIP(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
+        MKC_HIP(hipMemcpyAsync(c->d_in, in + at, cn, hipMemcpyHostToDevice, c->stream), "upload of the text");
+        MKC_HIP(hipMemsetAsync((uint8_t *)c->d_in + cn, 0, mkz::kPad, c->stream), "hipMemsetAsync");
+        MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
+        mkz::launch_crc((const uint8_t *)c->d_in, cn, bb, blocks, (uint32_t *)c->d_crc, c->stream);
+        mkz::launch_deflate((const uint8_t *)c->d_in, cn, bb, blocks, (const uint32_t *)c->d_crc, (uint32_t *)c->d_tokens, (uint8_t *)c->d_slots,
+                            (uint32_t *)c->d_len, grid, c->stream);
+        mkz::launch_pack((const uint8_t *)c->d_slots, (const uint32_t *)c->d_len, (uint64_t *)c->d_off, d_total, blocks, (uint8_t *)c->d_out, c->stream);
+        MKC_HIP(hipGetLastError(), "BGZF deflate kernels");
+        MKC_HIP(hipEventRecord(c->ev[2], c->stream), "hipEventRecord");
+        uint64_t total = 0;
+        MKC_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream), "download of the size");
+        MKC_HIP(hipStreamSynchronize(c->stream), "BGZF deflate");
+        if (total > out_cap - written) return mk::fail(MK_E_CAPACITY, "mk_bgzf_deflate: members exceed the bound (internal error)");
+        MKC_HIP(hipMemcpyAsync(out + written, c->d_out, total, hipMemcpyDeviceToHost, c->stream), "download of the members");
+        MKC_HIP(hipEventRecord(c->ev[3], c->stream), "hipEventRecord");
+        MKC_HIP(hipStreamSynchronize(c->stream), "BGZF deflate");
+        c->ms[0] += elapsed(c->ev[0], c->ev[1]), c->ms[1] += elapsed(c->ev[1], c->ev[2]), c->ms[2] += elapsed(c->ev[2], c->ev[3]);
+        written += total;
+    }
+    *out_len = written;
+    return MK_OK;
+    MK_ABI_END
+}
+
+int mk_bgzf_members(const uint8_t *in, uint64_t n, mk_bgzf_member *members, uint64_t cap, uint64_t *n_members, uint64_t *consumed,
+                    uint64_t *text_bytes) {
+    if (!n_members || (n && !in)) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_members: NULL argument");
+    uint64_t at = 0, k = 0, text = 0;
+    while (n - at >= 18) {
+        const uint8_t *h = in + at;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return mk::fail(MK_E_CORRUPT, "not a BGZF member at byte %llu", (unsigned long long)at);
+        const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+        if (n - at < 12 + (uint64_t)xlen) break;
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {  // the extra field's subfields: SI1 SI2 SLEN data
+            const uint8_t *f = h + 12 + x;
+            const uint32_t slen = f[2] | (uint32_t)f[3] << 8;
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = f[4] | (uint32_t)f[5] << 8, found = true;
+            x += 4 + slen;
+        }
+        if (!found) return mk::fail(MK_E_CORRUPT, "gzip member without a BC subfield at byte %llu", (unsigned long long)at);
+        const uint64_t size = (uint64_t)bsize + 1;
+        if (size < 12 + (uint64_t)xlen + 8) return mk::fail(MK_E_CORRUPT, "BGZF member with BSIZE %u at byte %llu", bsize, (unsigned long long)at);
+        if (n - at < size) break;
+        uint32_t crc, isize;
+        memcpy(&crc, h + size - 8, 4), memcpy(&isize, h + size - 4, 4);
+        if (isize > 65536) return mk::fail(MK_E_CORRUPT, "BGZF member with ISIZE %u at byte %llu", isize, (unsigned long long)at);
+        if (members && k < cap) members[k] = mk_bgzf_member{at + 12 + xlen, text, (uint32_t)(size - 12 - xlen - 8), isize, crc, 0};
+        ++k, text += isize, at += size;
+    }
+    *n_members = k;
+    if (consumed) *consumed = at;
+    if (text_bytes) *text_bytes = text;
+    return MK_OK;
+}
+
+int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf_member *members, uint64_t n_members, uint8_t *out,
+                    uint64_t out_cap, uint64_t *bad_member) {
+    MK_ABI_BEGIN
+    if (!c || (n_members && (!in || !members)) || (out_cap && !out)) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_inflate: NULL argument");
+    static_assert(sizeof(mk_bgzf_member) == sizeof(mkz::Member), "member layouts");
+    if (bad_member) *bad_member = 0;
+    for (uint64_t i = 0; i < n_members; ++i) {
+        const mk_bgzf_member &m = members[i];
+        if (m.data_off > n_in || m.data_len > n_in - m.data_off || m.isize > 65536 || m.out_off > out_cap || m.isize > out_cap - m.out_off) {
+            if (bad_member) *bad_member = i;
+            return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_inflate: member %llu lies outside its buffers", (unsigned long long)i);
+        }
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    MKC_HIP(hipSetDevice(c->device), "hipSetDevice");
+    c->ms[0] = c->ms[1] = c->ms[2] = 0;
+    std::vector<mkz::Member> part;
+    std::vector<int32_t> status;
+    for (uint64_t m0 = 0; m0 < n_members;) {
+        // a run of members whose compressed bytes and text are both contiguous enough to move in one piece each
+        uint64_t m1 = m0, text = 0, in_lo = members[m0].data_off, in_hi = in_lo, out_lo = members[m0].out_off, out_hi = out_lo;
+        while (m1 < n_members && (m1 == m0 || text + members[m1].isize <= kInflateChunkText)) {
+            const mk_bgzf_member &m = members[m1];
+            in_lo = std::min(in_lo, m.data_off), in_hi = std::max(in_hi, m.data_off + m.data_len);
+            out_lo = std::min(out_lo, m.out_off), out_hi = std::max(out_hi, m.out_off + m.isize);
+            text += m.isize, ++m1;
+        }
+        if (out_hi - out_lo > 2 * kInflateChunkText || in_hi - in_lo > 4 * kInflateChunkText)
+            return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_inflate: members %llu.. are scattered over more than a device pass holds",
+                            (unsigned long long)m0);
+        const uint32_t cnt = (uint32_t)(m1 - m0);
+        part.resize(cnt);
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const mk_bgzf_member &m = members[m0 + k];
+            part[k] = mkz::Member{m.data_off - in_lo, m.out_off - out_lo, m.data_len, m.isize, m.crc, 0};
+        }
+        const uint64_t cn = in_hi - in_lo, tn = out_hi - out_lo;
+        int rc;
+        if ((rc = mk::ensure_device(&c->d_in, &c->in_cap, cn + mkz::kPad)) || (rc = mk::ensure_device(&c->d_aux, &c->aux_cap, cnt * sizeof(mkz::Member))) ||
+            (rc = mk::ensure_device(&c->d_out, &c->out_cap, tn + 1)) || (rc = mk::ensure_device(&c->d_len, &c->len_cap, cnt * 4ull)))
+            return rc;
+        MKC_HIP(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
+        MKC_HIP(hipMemcpyAsync(c->d_in, in + in_lo, cn, hipMemcpyHostToDevice, c->stream), "upload of the members");
+        MKC_HIP(hipMemsetAsync((uint8_t *)c->d_in + cn, 0, mkz::kPad, c->stream), "hipMemsetAsync");
+        MKC_HIP(hipMemcpyAsync(c->d_aux, part.data(), cnt * sizeof(mkz::Member), hipMemcpyHostToDevice, c->stream), "upload of the member table");
+        MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
+        mkz::launch_inflate((const uint8_t *)c->d_in, cn, (const mkz::Member *)c->d_aux, cnt, (uint8_t *)c->d_out, (int32_t *)c->d_len, c->stream);
+        mkz::launch_crc_check((const uint8_t *)c->d_out, (const mkz::Member *)c->d_aux, cnt, (int32_t *)c->d_len, c->stream);
+        MKC_HIP(hipGetLastError(), "BGZF inflate kernels");
+        MKC_HIP(hipEventRecord(c->ev[2], c->stream), "hipEventRecord");
+        status.resize(cnt);
+        MKC_HIP(hipMemcpyAsync(status.data(), c->d_len, cnt * 4ull, hipMemcpyDeviceToHost, c->stream), "download of the status words");
+        if (tn) MKC_HIP(hipMemcpyAsync(out + out_lo, c->d_out, tn, hipMemcpyDeviceToHost, c->stream), "download of the text");
+        MKC_HIP(hipEventRecord(c->ev[3], c->stream), "hipEventRecord");
+        MKC_HIP(hipStreamSynchronize(c->stream), "BGZF inflate");
+        c->ms[0] += elapsed(c->ev[0], c->ev[1]), c->ms[1] += elapsed(c->ev[1], c->ev[2]), c->ms[2] += elapsed(c->ev[2], c->ev[3]);
+        for (uint32_t k = 0; k < cnt; ++k)
+            if (status[k]) {
+                if (bad_member) *bad_member = m0 + k;
+                if (status[k] > 0)  // the decoder was content (0), the checksum kernel raised its bit
+                    return mk::fail(MK_E_CORRUPT, "BGZF member %llu: CRC-32 of the inflated text differs from the trailer's", (unsigned long long)(m0 + k));
+                return mk::fail(MK_E_CORRUPT, "BGZF member %llu does not inflate to its ISIZE (decoder status %d)", (unsigned long long)(m0 + k), status[k]);
+            }
+        m0 = m1;
+    }
+    return MK_OK;
+    MK_ABI_END
+}
+
+}  // extern "C"

@@ -31,6 +31,7 @@ MK_E_CAPACITY = -8
 MK_E_INVALID_ARG = -9
 MK_E_UNSUPPORTED = -10
 MK_E_RCCL = -11
+MK_E_CORRUPT = -12
 MK_COMM_ID_BYTES = 128
 
 MK_ALGO_AUTO, MK_ALGO_AC, MK_ALGO_BNDMQ = 0, 1, 2
@@ -51,6 +52,8 @@ EXPORTS = [
     "mk_extract_single", "mk_extract_fastq_text", "mk_upload_text_ahead", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
+    "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
+    "mk_codec_times",
 ]
 
 
@@ -190,6 +193,17 @@ def load(build_if_missing=True):
     L.mk_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.mk_host_free.argtypes = [C.c_void_p]
     L.mk_host_free.restype = None
+    L.mk_codec_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mk_codec_destroy.argtypes = [C.c_void_p]
+    L.mk_codec_destroy.restype = None
+    L.mk_bgzf_deflate_bound.argtypes = [C.c_uint64, C.c_uint32]
+    L.mk_bgzf_deflate_bound.restype = C.c_uint64
+    L.mk_bgzf_deflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.mk_bgzf_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.mk_bgzf_members.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint64)]
+    L.mk_bgzf_eof.restype = C.POINTER(C.c_uint8 * 28)
+    L.mk_codec_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(Counters), C.c_void_p]
@@ -606,3 +620,64 @@ class AhoCorasick:
     def is_match(self, text: bytes) -> bool:
         flags, _ = self._m.scan([text], MK_MODE_ANY)
         return bool(flags[0])
+
+
+# ---- BGZF codec (include/merkurio_hip.h v5; the reference's `bam` reader / writer, src/cmd_tag.rs:254-271,503-506) ----
+MEMBER_DTYPE = np.dtype([("data_off", "<u8"), ("out_off", "<u8"), ("data_len", "<u4"), ("isize", "<u4"), ("crc", "<u4"), ("reserved", "<u4")])
+
+
+def bgzf_members(data):
+    """mk_bgzf_members: the member table of a BGZF byte string (host code) -> (members, consumed bytes, text bytes)"""
+    L = load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n, used, text = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _check(L.mk_bgzf_members(buf.ctypes.data if buf.size else None, buf.size, None, 0, C.byref(n), C.byref(used), C.byref(text)))
+    mem = np.zeros(n.value, dtype=MEMBER_DTYPE)
+    _check(L.mk_bgzf_members(buf.ctypes.data if buf.size else None, buf.size, mem.ctypes.data, mem.size, C.byref(n), C.byref(used), C.byref(text)))
+    return mem, used.value, text.value
+
+
+def bgzf_eof():
+    return bytes(load().mk_bgzf_eof().contents)
+
+
+class Codec:
+    """mk_codec: BGZF members deflated / inflated by the gfx950 kernels (no CPU path: without a device creation raises)"""
+
+    def __init__(self, device=0):
+        self._L = load()
+        h = C.c_void_p()
+        _check(self._L.mk_codec_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._L.mk_codec_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def deflate(self, data, block_bytes=0):
+        src = np.frombuffer(data, dtype=np.uint8)
+        out = np.empty(self._L.mk_bgzf_deflate_bound(src.size, block_bytes), dtype=np.uint8)
+        n = C.c_uint64(0)
+        _check(self._L.mk_bgzf_deflate(self._h, src.ctypes.data if src.size else None, src.size, block_bytes,
+                                       out.ctypes.data if out.size else None, out.size, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def inflate(self, data, members=None, text_bytes=None):
+        if members is None:
+            members, used, text_bytes = bgzf_members(data)
+            if used != len(data):
+                raise MerkurioError(MK_E_CORRUPT, "trailing bytes behind the last whole BGZF member")
+        src = np.frombuffer(data, dtype=np.uint8)
+        out = np.empty(text_bytes, dtype=np.uint8)
+        bad = C.c_uint64(0)
+        _check(self._L.mk_bgzf_inflate(self._h, src.ctypes.data if src.size else None, src.size, members.ctypes.data if members.size else None,
+                                       members.size, out.ctypes.data if out.size else None, out.size, C.byref(bad)))
+        return out.tobytes()
+
+    def times(self):
+        ms = (C.c_float * 3)()
+        _check(self._L.mk_codec_times(self._h, ms))
+        return tuple(ms)

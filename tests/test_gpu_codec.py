@@ -1,0 +1,182 @@
+"""The device BGZF codec through the C ABI (mk_codec_*, mk_bgzf_*; include/merkurio_hip.h v5) against zlib -- the checker
+for RFC 1951 / RFC 1952 here: the system's zlib is what the reference's flate2 implements and what every BAM reader
+links.  Replaces the BGZF reader / writer the reference gets from `bam 0.1.4` (src/cmd_tag.rs:254-271,503-506).
+
+deflate: every member the device writes is inflated by zlib and compared with the input byte for byte; its BSIZE, CRC-32
+and ISIZE are checked field by field (bit-exact text; the compressed bytes are the library's own parse).
+inflate: members written by zlib at every level / strategy, and by the device, come back byte for byte; damaged members
+are refused with MK_E_CORRUPT and the index of the first one."""
+import gzip
+import random
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from merkurio_amd import native as mk
+from test_codec_cpu import corpora, raw_deflate
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec():
+    c = mk.Codec()
+    yield c
+    c.close()
+
+
+def bam_like(n_rec, seed=5, const_qual=False):
+    """records shaped like `tag`'s BAM output: fixed fields, a counting name, nibble-packed random bases, qualities, a tag"""
+    rng = np.random.default_rng(seed)
+    L = 150
+    rec = np.zeros((n_rec, 36 + 12 + 4 + L // 2 + L + 14), dtype=np.uint8)
+    rec[:, 0:4] = np.frombuffer(struct.pack("<I", rec.shape[1] - 4), dtype=np.uint8)
+    pos = (np.arange(n_rec, dtype=np.uint32) * 37) % 2000000
+    rec[:, 8:12] = pos.view(np.uint8).reshape(n_rec, 4)
+    rec[:, 12] = 12
+    rec[:, 13] = 60
+    rec[:, 16] = 1
+    rec[:, 20:24] = np.frombuffer(struct.pack("<I", L), dtype=np.uint8)
+    rec[:, 24:28] = 255
+    names = np.array([b"r%010d\0" % i for i in range(n_rec)], dtype="S12")
+    rec[:, 36:48] = names.view(np.uint8).reshape(n_rec, 12)
+    rec[:, 48:52] = np.frombuffer(struct.pack("<I", L << 4), dtype=np.uint8)
+    nib = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, size=(n_rec, L))]
+    rec[:, 52:52 + L // 2] = nib[:, 0::2] << 4 | nib[:, 1::2]
+    q0 = 52 + L // 2
+    rec[:, q0:q0 + L] = 40 if const_qual else np.array([2, 12, 23, 37], dtype=np.uint8)[rng.choice(4, size=(n_rec, L), p=[0.02, 0.05, 0.13, 0.8])]
+    rec[:, q0 + L:] = np.frombuffer(b"NMC\0ASC\x96XSZabc\0", dtype=np.uint8)[:14]
+    return rec.tobytes()
+
+
+def check_members(data, blob, block_bytes):
+    """every member: header fields, zlib inflates its payload to the block it stands for, CRC-32 and ISIZE agree"""
+    bb = block_bytes or 65280
+    mem, used, text = mk.bgzf_members(blob)
+    assert used == len(blob) and text == len(data) and len(mem) == (len(data) + bb - 1) // bb
+    at = 0
+    for k, m in enumerate(mem):
+        start = int(m["data_off"]) - 18
+        assert blob[start:start + 16] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0])
+        bsize = struct.unpack_from("<H", blob, start + 16)[0]
+        assert bsize + 1 == 18 + int(m["data_len"]) + 8
+        block = data[k * bb:(k + 1) * bb]
+        d = zlib.decompressobj(-15)
+        got = d.decompress(blob[int(m["data_off"]):int(m["data_off"]) + int(m["data_len"])])
+        assert d.eof and d.unused_data == b"", k
+        assert got == block, k
+        assert int(m["crc"]) == zlib.crc32(block) and int(m["isize"]) == len(block)
+        at += bsize + 1
+    assert at == len(blob)
+
+
+@pytest.mark.parametrize("block_bytes", [0, 65280, 1000, 64, 7])
+def test_deflate_members_inflate_with_zlib(codec, block_bytes):
+    for name, data in corpora().items():
+        if block_bytes in (64, 7):
+            data = data[:3000]
+        blob = codec.deflate(data, block_bytes)
+        check_members(data, blob, block_bytes)
+        if data:
+            assert gzip.decompress(blob + mk.bgzf_eof()) == data, name  # the whole file, as a reader sees it
+
+
+def test_deflate_sizes_around_a_block_and_a_device_pass(codec):
+    rng = random.Random(3)
+    base = bam_like(1200)
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 65279, 65280, 65281, 2 * 65280, 2 * 65280 + 1):
+        data = (base * (n // len(base) + 1))[:n]
+        check_members(data, codec.deflate(data), 0)
+    # more members than one device pass takes (4096): 5 000 blocks of 4 KiB
+    data = bam_like(72000, seed=9)[:5000 * 4096 - 77]
+    blob = codec.deflate(data, 4096)
+    check_members(data, blob, 4096)
+    # text that cannot shrink is stored
+    noise = bytes(rng.getrandbits(8) for _ in range(150000))
+    blob = codec.deflate(noise)
+    check_members(noise, blob, 0)
+    assert len(blob) == len(noise) + 3 * 31
+
+
+def test_deflate_compresses_like_a_fast_zlib_level(codec):
+    """not a parity claim -- a guard against a parse that stops finding matches: within 25 % of zlib level 1 on BAM-like
+    records, FASTQ text and a run-heavy block"""
+    for name, data in (("bam", bam_like(40000)), ("bam const qual", bam_like(40000, const_qual=True)), ("fastq", corpora()["fastq"] * 8),
+                       ("zeros", bytes(300000))):
+        blob = codec.deflate(data)
+        z1 = sum(len(raw_deflate(data[i:i + 65280], level=1)) + 26 for i in range(0, len(data), 65280))
+        assert len(blob) <= 1.25 * z1, (name, len(blob), z1)
+
+
+def zlib_bgzf(data, block_bytes=65280, **kw):
+    out = b""
+    for i in range(0, len(data), block_bytes):
+        block = data[i:i + block_bytes]
+        z = raw_deflate(block, **kw)
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(z) + 25) + z
+        out += struct.pack("<II", zlib.crc32(block), len(block))
+    return out
+
+
+def test_inflate_members_written_by_zlib(codec):
+    for name, data in list(corpora().items()) + [("bam", bam_like(3000))]:
+        if not data:
+            continue
+        for kw in ({"level": 0}, {"level": 1}, {"level": 6}, {"level": 9}, {"strategy": zlib.Z_FIXED}, {"strategy": zlib.Z_HUFFMAN_ONLY},
+                   {"flush_every": 5000}):
+            for bb in (65280, 2000):
+                blob = zlib_bgzf(data[:200000], bb, **kw)
+                assert codec.inflate(blob) == data[:200000], (name, kw, bb)
+    assert codec.inflate(b"") == b""
+    assert codec.inflate(mk.bgzf_eof()) == b""
+
+
+def test_round_trip_on_the_device(codec):
+    data = bam_like(300000, seed=11)  # 82 MB, 1 260 members
+    blob = codec.deflate(data)
+    assert codec.inflate(blob) == data
+    assert gzip.decompress(blob) == data
+
+
+def test_inflate_refuses_damaged_members(codec):
+    data = bam_like(3000)
+    blob = bytearray(zlib_bgzf(data, level=6))
+    mem, _, _ = mk.bgzf_members(bytes(blob))
+    assert len(mem) >= 10
+    # a flipped bit in the payload of member 3: a stream error or a CRC mismatch, never a silent difference
+    bad = bytearray(blob)
+    bad[int(mem[3]["data_off"]) + int(mem[3]["data_len"]) // 2] ^= 0x10
+    with pytest.raises(mk.MerkurioError) as e:
+        codec.inflate(bytes(bad))
+    assert e.value.code == mk.MK_E_CORRUPT and "member 3" in str(e.value)
+    # a wrong CRC in the trailer of member 5
+    bad = bytearray(blob)
+    bad[int(mem[5]["data_off"]) + int(mem[5]["data_len"])] ^= 0xff
+    with pytest.raises(mk.MerkurioError) as e:
+        codec.inflate(bytes(bad))
+    assert e.value.code == mk.MK_E_CORRUPT and "member 5" in str(e.value) and "CRC" in str(e.value)
+    # a wrong ISIZE (one byte short) in member 0
+    m2 = mem.copy()
+    m2["isize"][0] -= 1
+    with pytest.raises(mk.MerkurioError) as e:
+        codec.inflate(bytes(blob), m2, int(mem["isize"].sum()))
+    assert e.value.code == mk.MK_E_CORRUPT and "member 0" in str(e.value)
+    # random damage: an error or the right text, and never a crash
+    rng = random.Random(17)
+    for _ in range(40):
+        bad = bytearray(blob)
+        k = rng.randrange(len(mem))
+        for _ in range(rng.randrange(1, 4)):
+            bad[int(mem[k]["data_off"]) + rng.randrange(int(mem[k]["data_len"]))] = rng.getrandbits(8)
+        try:
+            assert codec.inflate(bytes(bad)) == data
+        except mk.MerkurioError as e:
+            assert e.code == mk.MK_E_CORRUPT
+    # members outside their buffers are refused on the host
+    m2 = mem.copy()
+    m2["data_len"][2] = 1 << 30
+    with pytest.raises(mk.MerkurioError) as e:
+        codec.inflate(bytes(blob), m2, int(mem["isize"].sum()))
+    assert e.value.code == mk.MK_E_INVALID_ARG

@@ -16,12 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "merkurio_hip.h")).read()
     declared = set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"mk_matcher", "mk_hit", "mk_row", "mk_counters"}
+    declared -= {"mk_matcher", "mk_hit", "mk_row", "mk_counters", "mk_codec", "mk_bgzf_member"}
     assert declared == set(mk.EXPORTS), declared ^ set(mk.EXPORTS)
     L = mk.load()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.mk_abi_version() == 4
+    assert L.mk_abi_version() == 5
 
 
 def test_no_cpu_fallback_without_gpu():
