@@ -596,7 +596,59 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
     run("config 5, one GPU's shard: extract, 12.5 M x 250 bp, 500 k 21-mers (filter in global memory), any-hit flags", m, a, b, c,
         12_500_000, 250, n_pat, False, 100)
     del m, a, b, c
+    res += codec_configs(mk)
     return res
+
+
+def codec_configs(mk, megabytes=1024, reps=3):
+    """The BGZF codec either side of `tag` (include/merkurio_hip.h v5, merkurio_amd/csrc/codec/): 1 GiB of BAM-shaped
+    records (tests/textio.py: bam_like, 4-bin qualities) deflated into 65 280-byte members and inflated again through
+    the C ABI, host buffers in and out.  `kernel_ms` = the device part of a call (hipEvents around its kernels:
+    CRC + parse + codes + bit packing + pack, or inflate + CRC check), best of `reps`; `ms_per_call` the whole call with
+    its PCIe copies from / to pageable memory.  Neither kernel is bound by HBM or MFMA: both are latency-bound serial
+    decoders / parsers, one wave (deflate) or one lane (inflate) per member, so `frac` against the HBM peak is reported
+    for scale only.  The round trip is checked in the run."""
+    import numpy as np
+    from textio import bam_like
+    unit = bam_like(200000, seed=21)
+    data = unit * max(1, megabytes * (1 << 20) // len(unit))
+    codec = mk.Codec()
+    out = []
+    try:
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            blob = codec.deflate(data)
+            dt = time.perf_counter() - t0
+            up, dev_ms, down = codec.times()
+            if best is None or dev_ms < best[1]:
+                best = (dt, dev_ms, up, down)
+        out.append({"workload": f"BGZF deflate (tag's BAM output): {len(data) / 1e6:.0f} MB of BAM-shaped records -> {(len(data) + 65279) // 65280} members",
+                    "kernel": "mk_bgzf_crc_kernel + mk_bgzf_deflate_kernel + mk_bgzf_pack_kernel", "kernel_ms": round(best[1], 2),
+                    "ms_per_call": round(best[0] * 1e3, 1), "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1),
+                    "text_gb_per_s_kernels": round(len(data) / best[1] / 1e6, 1), "compression_ratio": round(len(data) / len(blob), 2),
+                    "bound": "latency (serial parse per member; not HBM, not MFMA)",
+                    "frac": round((len(data) + len(blob)) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            text = codec.inflate(blob)
+            dt = time.perf_counter() - t0
+            up, dev_ms, down = codec.times()
+            if best is None or dev_ms < best[1]:
+                best = (dt, dev_ms, up, down)
+        out.append({"workload": f"BGZF inflate (tag's BAM input): the {(len(data) + 65279) // 65280} members above -> {len(data) / 1e6:.0f} MB, CRC-32 checked",
+                    "kernel": "mk_bgzf_inflate_kernel + mk_bgzf_crc_check_kernel", "kernel_ms": round(best[1], 2), "ms_per_call": round(best[0] * 1e3, 1),
+                    "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1), "text_gb_per_s_kernels": round(len(data) / best[1] / 1e6, 1),
+                    "round_trip_equal": bool(text == data), "bound": "latency (one lane per member, 64 serial decoders per wave; not HBM, not MFMA)",
+                    "frac": round((len(data) + len(blob)) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
+        if text != data:
+            raise RuntimeError("BGZF round trip on the device does not reproduce its input")
+    finally:
+        codec.close()
+    return out
 
 
 def host_cores():

@@ -430,6 +430,10 @@ int mk_codec_create(int device, mk_codec **out);
 void mk_codec_destroy(mk_codec *c);
 uint64_t mk_bgzf_deflate_bound(uint64_t n, uint32_t block_bytes);
 int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_bytes, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+/* the same for text that lies in several pieces (a writer's per-thread record buffers): the members are those of the
+ * pieces' concatenation, which exists on the device only -- the host never copies the pieces together */
+int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint64_t *sizes, uint64_t n_pieces, uint32_t block_bytes,
+                           uint8_t *out, uint64_t out_cap, uint64_t *out_len);
 int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf_member *members, uint64_t n_members, uint8_t *out,
                     uint64_t out_cap, uint64_t *bad_member);
 /* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,

@@ -363,6 +363,8 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     tm.mark("open + first window");
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
+    // from here on (the HIP runtime is up) the members of a bgzip'ed input are inflated by the device codec (mk_bgzf_inflate)
+    if (!a.host_codec) set_bgzf_device(devs[0]);
     tm.mark("matcher create (HIP init), remainder");
     // writers: src/cmd_extract.rs:297-318, :420-460
     Sink w1, w2;
@@ -794,6 +796,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     tm.mark("open + header");
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
+    // from here on (the HIP runtime is up) the BGZF members of a BAM window are inflated by the device codec (mk_bgzf_inflate)
+    if (!a.host_codec) set_bgzf_device(devs[0]);
     tm.mark("matcher (HIP init), remainder");
     if (out_ext != "sam" && out_ext != "bam" && out_ext != "STDOUT") bail("Output file must be a BAM or SAM file.");
     Sink w;
@@ -802,6 +806,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     // header + @PG line (src/cmd_tag.rs:509-514)
     const std::string out_header =
         sam.header + "@PG\tID:" + kProgram + "\tPN:" + kProgram + "\tCL:" + join(argv) + "\tVN:" + kVersion + "\n";
+    if (to_bam && !a.host_codec) bw.use_device(devs[0]);  // members deflated by the device codec (mk_bgzf_deflate)
     if (to_bam) {  // BAM -> BAM passes raw records through: they keep the input's reference ids
         if (sam.is_bam)
             bw.open(with_extension(*a.out_file, out_ext), out_header, &sam.ref_names, &sam.ref_lens);
@@ -828,7 +833,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         std::vector<std::vector<uint8_t>> bin;  // BAM output: per-thread encoded records, in order
         std::vector<std::string> txt;           // SAM output
     };
-    auto emit = [&](const BatchOut &o) {
+    auto emit = [&](BatchOut &o) {  // (takes the batch's encoded records with it)
         if (lg.active)
             emit_log_rows(
                 lg, pats, o.rows.data(), o.rows.size(),
@@ -837,7 +842,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
                     return std::pair<const char *, size_t>(sam.data + rec.off + (sam.is_bam ? 36 : 0), rec.name_len);
                 },
                 [&](const mk_row &) -> const std::string & { return in_name; });
-        for (auto &b : o.bin) bw.put_encoded(b);
+        for (auto &b : o.bin) bw.put_encoded(std::move(b));  // moved, not copied: the pieces are joined on the device
         for (auto &t : o.txt) w.write(t);
     };
     // scan buffers of one device thread, reused by every batch of every window
@@ -981,6 +986,10 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     w.flush();
     bw.close();
     tm.mark("write");
+    if (to_bam && getenv("MERKURIO_TIMING"))
+        fprintf(stderr, "[timing] BGZF deflate on its own threads (%s): %.3f s\n", a.host_codec ? "zlib, host" : "device codec", bw.deflate_seconds);
+    if (getenv("MERKURIO_TIMING") && bgzf_device_seconds() > 0)
+        fprintf(stderr, "[timing] BGZF inflate calls of the device codec (inside the window reads): %.3f s\n", bgzf_device_seconds());
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, false);

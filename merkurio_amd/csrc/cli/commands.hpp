@@ -28,6 +28,7 @@ struct CommonArgs {
     int gpus = 1;         // --gpus N: records sharded over N devices, outputs in device order, counters reduced with RCCL
     int window_mb = 1024;  // --window-mb: text (decompressed) read, indexed and held per window of an extract input
     int batch_mb = 128;  // --batch-mb: sequence bytes per GPU batch (tools/batch_mb.sh: 128-256 MB is fastest end to end)
+    bool host_codec = false;   // --host-codec: BGZF members are deflated / inflated by zlib on the host threads instead of the device codec
     bool host_ingest = false;  // --host-ingest: extract parses FASTQ records on the host threads even where the device could index them
 };
 

@@ -7,9 +7,13 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "../../../include/merkurio_hip.h"
+
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <thread>
 
 namespace cli {
@@ -109,10 +113,45 @@ static bool bgzf_members(const uint8_t *d, size_t n, std::vector<BgzfMember> &me
     if (total_out) *total_out = total;
     return !mem.empty();
 }
-// inflates members [m0, m1) into out + (member.out_off - mem[m0].out_off) on the host threads
+// The device codec for BGZF input (set_bgzf_device; merkurio_amd/csrc/codec/): one handle per process, created by the
+// first window that is large enough to be worth a launch.  < 0: zlib on the host threads (--host-codec).
+static int g_bgzf_device = -1;
+static std::mutex g_bgzf_mu;
+static mk_codec *g_bgzf_codec = nullptr;
+static double g_bgzf_device_seconds = 0;
+void set_bgzf_device(int device) { g_bgzf_device = device; }
+double bgzf_device_seconds() { return g_bgzf_device_seconds; }
+// A launch of the inflate kernel takes 35-60 ms whether it holds 64 members or 49 152 (one lane per member, bound by
+// the latency of a lane's serial decode: profiles/r04_codec_kernels.txt); zlib on 16 host threads inflates ~4 GB/s.
+// Below ~0.5 GB of text per call the host threads are done first (extract's 128 MB raw windows: 0.63-0.70 s on the
+// host, 0.89-0.91 s through the device: profiles/r04_e2e_extract_bgzf.txt).
+constexpr size_t kDeviceInflateMinMembers = 8192;
+
+// inflates members [m0, m1) into out + (member.out_off - mem[m0].out_off): on the device (one lane per member,
+// mk_bgzf_inflate: stream errors, ISIZE and CRC-32 checked there) or on the host threads
 static void bgzf_inflate_range(const uint8_t *d, const std::vector<BgzfMember> &mem, size_t m0, size_t m1, char *out,
                                const std::string &path) {
     const size_t cnt = m1 - m0;
+    if (g_bgzf_device >= 0 && cnt >= kDeviceInflateMinMembers) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lock(g_bgzf_mu);
+        if (!g_bgzf_codec && mk_codec_create(g_bgzf_device, &g_bgzf_codec) != MK_OK) bail(std::string("Error while decompressing ") + path + ": " + mk_last_error());
+        const size_t base = mem[m0].out_off, in_lo = mem[m0].data_off;
+        std::vector<mk_bgzf_member> tab(cnt);
+        uint64_t text = 0, in_hi = in_lo;
+        for (size_t i = 0; i < cnt; ++i) {
+            const BgzfMember &b = mem[m0 + i];
+            tab[i] = mk_bgzf_member{b.data_off - in_lo, b.out_off - base, (uint32_t)b.data_len, b.isize, b.crc, 0};
+            text = std::max<uint64_t>(text, b.out_off - base + b.isize);
+            in_hi = std::max<uint64_t>(in_hi, b.data_off + b.data_len);
+        }
+        uint64_t bad = 0;
+        const int rc = mk_bgzf_inflate(g_bgzf_codec, d + in_lo, in_hi - in_lo, tab.data(), cnt, (uint8_t *)out, text, &bad);
+        if (rc == MK_E_CORRUPT) bail("Error while decompressing " + path);
+        if (rc != MK_OK) bail(std::string("Error while decompressing ") + path + ": " + mk_last_error());
+        g_bgzf_device_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return;
+    }
     const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), cnt / 16 + 1));
     const size_t base = mem[m0].out_off;
     run_threads(T, [&](size_t t) {
@@ -1120,26 +1159,34 @@ int SamFile::find_tag(size_t i, const std::string &tag, std::string *val) const 
 // ---- BAM output ---------------------------------------------------------------------------------
 BamWriter::~BamWriter() { close(); }
 
-void BamWriter::put(const void *p, size_t n) {
-    const uint8_t *b = (const uint8_t *)p;
-    while (n) {
-        size_t room = 0xff00 - block.size();
-        size_t k = std::min(room, n);
-        block.insert(block.end(), b, b + k);
-        b += k;
-        n -= k;
-        if (block.size() >= 0xff00) flush_block();
+constexpr size_t kBgzfBlock = 0xff00;
+constexpr size_t kFlushBytes = 1536 * kBgzfBlock;  // 100 MB of text per flush: two rounds of the deflate kernel's resident waves
+
+void BamWriter::put(const void *p, size_t n) {  // small writes (header, single records) share an open piece
+    if (pieces.empty() || pieces.back().size() + n > pieces.back().capacity()) {
+        pieces.emplace_back();
+        pieces.back().reserve(std::max<size_t>(n, 1u << 20));
     }
+    pieces.back().insert(pieces.back().end(), (const uint8_t *)p, (const uint8_t *)p + n);
+    pieces_bytes += n;
+    if (pieces_bytes >= kFlushBytes + kBgzfBlock) flush(false);
+}
+
+void BamWriter::put_encoded(std::vector<uint8_t> &&bytes) {
+    if (bytes.empty()) return;
+    pieces_bytes += bytes.size();
+    pieces.push_back(std::move(bytes));
+    if (pieces_bytes >= kFlushBytes + kBgzfBlock) flush(false);
 }
 
 // one BGZF member: gzip header with the BC extra field, raw deflate, crc32, isize
-static void bgzf_compress(const std::vector<uint8_t> &in, std::vector<uint8_t> &out) {
-    out.resize(in.size() + in.size() / 8 + 1024);
+static void bgzf_compress(const uint8_t *in, size_t n, std::vector<uint8_t> &out) {
+    out.resize(n + n / 8 + 1024);
     z_stream z;
     memset(&z, 0, sizeof(z));
     if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) bail("Error writing BAM file: zlib init failed");
-    z.next_in = const_cast<Bytef *>(in.data());
-    z.avail_in = (uInt)in.size();
+    z.next_in = const_cast<Bytef *>(in);
+    z.avail_in = (uInt)n;
     z.next_out = out.data() + 18;
     z.avail_out = (uInt)(out.size() - 26);
     if (deflate(&z, Z_FINISH) != Z_STREAM_END) bail("Error writing BAM file: deflate failed");
@@ -1149,32 +1196,84 @@ static void bgzf_compress(const std::vector<uint8_t> &in, std::vector<uint8_t> &
     memcpy(out.data(), hdr, 16);
     const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
     memcpy(out.data() + 16, &bsize, 2);
-    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), in.data(), (uInt)in.size());
-    const uint32_t isize = (uint32_t)in.size();
+    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), in, (uInt)n);
+    const uint32_t isize = (uint32_t)n;
     memcpy(out.data() + 18 + clen, &crc, 4);
     memcpy(out.data() + 22 + clen, &isize, 4);
     out.resize(clen + 26);
 }
 
-// full blocks are collected and compressed a batch at a time on every host thread (deflate is
-// the slow side of BAM output: ~50 MB/s per core); the members are written in order
-void BamWriter::flush_block() {
-    pending.emplace_back();
-    pending.back().swap(block);
-    block.reserve(0xff00);
-    if (pending.size() >= 8 * (size_t)io_threads()) flush_pending();
+void BamWriter::wait_flush() {
+    if (flushing_.valid()) flushing_.get();  // rethrows what the flush thread met
 }
 
-void BamWriter::flush_pending() {
-    if (pending.empty()) return;
-    std::vector<std::vector<uint8_t>> outs(pending.size());
-    const size_t T = std::min<size_t>(io_threads(), pending.size());
+// whole members of the stream so far (all of it at close) go to a flush thread; the bytes behind the last whole
+// member -- less than one member -- stay, as the first piece of what follows
+void BamWriter::flush(bool all) {
+    wait_flush();
+    const size_t take = all ? pieces_bytes : pieces_bytes / kBgzfBlock * kBgzfBlock;
+    if (!take) return;
+    run_.clear();
+    std::vector<uint8_t> rest;
+    size_t at = 0;
+    for (auto &p : pieces) {
+        if (at + p.size() <= take) {
+            at += p.size();
+            run_.push_back(std::move(p));
+        } else {
+            const size_t keep = at < take ? take - at : 0;  // bytes of this piece that belong to the run
+            rest.insert(rest.end(), p.begin() + keep, p.end());
+            at += p.size();
+            if (keep) {
+                p.resize(keep);
+                run_.push_back(std::move(p));
+            }
+        }
+    }
+    pieces.clear();
+    pieces_bytes = rest.size();
+    if (!rest.empty()) pieces.push_back(std::move(rest));
+    flushing_ = std::async(std::launch::async, [this] { compress_and_write(); });
+}
+
+void BamWriter::compress_and_write() {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t total = 0;
+    for (auto &p : run_) total += p.size();
+    if (device_ >= 0) {  // the device codec: every member of the run in one call, the pieces joined on the device
+        if (!codec_) {
+            mk_codec *c = nullptr;
+            if (mk_codec_create(device_, &c) != MK_OK) bail(std::string("Error writing BAM file: ") + mk_last_error());
+            codec_ = c;
+        }
+        std::vector<const uint8_t *> ptr(run_.size());
+        std::vector<uint64_t> len(run_.size());
+        for (size_t k = 0; k < run_.size(); ++k) ptr[k] = run_[k].data(), len[k] = run_[k].size();
+        z_.resize(mk_bgzf_deflate_bound(total, (uint32_t)kBgzfBlock));
+        uint64_t zn = 0;
+        if (mk_bgzf_deflate_pieces((mk_codec *)codec_, ptr.data(), len.data(), ptr.size(), (uint32_t)kBgzfBlock, z_.data(), z_.size(), &zn) != MK_OK)
+            bail(std::string("Error writing BAM file: ") + mk_last_error());
+        deflate_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (fwrite(z_.data(), 1, zn, f) != zn) bail("Error writing BAM file");
+        run_.clear();
+        return;
+    }
+    // zlib on every host thread (deflate is the slow side of BAM output: ~50 MB/s per core); members written in order
+    flat_.clear();
+    flat_.reserve(total);
+    for (auto &p : run_) flat_.insert(flat_.end(), p.begin(), p.end());
+    run_.clear();
+    const std::vector<uint8_t> &run = flat_;
+    const size_t blocks = (run.size() + kBgzfBlock - 1) / kBgzfBlock;
+    std::vector<std::vector<uint8_t>> outs(blocks);
+    const size_t T = std::min<size_t>(io_threads(), blocks);
     std::vector<std::string> errs(T);
     std::vector<std::thread> th;
     for (size_t t = 0; t < T; ++t)
         th.emplace_back([&, t] {
             try {
-                for (size_t i = t; i < pending.size(); i += T) bgzf_compress(pending[i], outs[i]);
+                for (size_t i = t; i < blocks; i += T)
+                    bgzf_compress(run.data() + i * kBgzfBlock, std::min(kBgzfBlock, run.size() - i * kBgzfBlock), outs[i]);
             } catch (const Error &e) {
                 errs[t] = e.what();
             }
@@ -1182,9 +1281,9 @@ void BamWriter::flush_pending() {
     for (auto &x : th) x.join();
     for (auto &e : errs)
         if (!e.empty()) bail(e);
+    deflate_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (auto &o : outs)
         if (fwrite(o.data(), 1, o.size(), f) != o.size()) bail("Error writing BAM file");
-    pending.clear();
 }
 
 void BamWriter::open(const std::string &path, const std::string &header_text, const std::vector<std::string> *names,
@@ -1374,12 +1473,12 @@ void BamWriter::encode_record(const std::string &line, std::vector<uint8_t> &dst
 
 void BamWriter::close() {
     if (!f) return;
-    if (!block.empty()) flush_block();
-    flush_pending();
-    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    fwrite(eof, 1, sizeof(eof), f);
+    flush(true);
+    wait_flush();
+    fwrite(mk_bgzf_eof(), 1, 28, f);
     fclose(f);
     f = nullptr;
+    if (codec_) mk_codec_destroy((mk_codec *)codec_), codec_ = nullptr;
 }
 
 void BamWriter::append_tagged_raw(const uint8_t *rec, uint32_t len, const std::string &tag, const char *val, size_t val_len,

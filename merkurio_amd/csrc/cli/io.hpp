@@ -4,6 +4,7 @@
 // bam 0.1.4 for SAM/BAM (src/cmd_tag.rs:470-497,503-615).
 #pragma once
 #include <cstdint>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
@@ -17,6 +18,10 @@ unsigned io_threads();
 // `tag -p N` given explicitly: at most N host threads for the codec work (the reference's meaning of -p:
 // BAM (de)compression threads, src/cmd_tag.rs:102-104,506); without it every core the process may use
 void set_io_threads_cap(unsigned n);
+// BGZF input (BAM, bgzip'ed FASTA/FASTQ) is inflated by the device codec on this HIP device from now on (windows of at
+// least a few hundred members; < 0: zlib on the host threads); seconds spent in those calls so far
+void set_bgzf_device(int device);
+double bgzf_device_seconds();
 
 // runs fn(t) for t in [0, T) on T host threads; the first cli::Error is re-raised on the caller
 template <class F>
@@ -218,16 +223,23 @@ struct SamFile {
 };
 // BAM writer (BGZF): encodes SAM text lines against the header's @SQ dictionary.  Used for
 // `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.
+// The uncompressed stream is kept as the pieces it arrives in (the per-thread record buffers of a batch are moved in,
+// not copied) and cut into 65 280-byte BGZF members when enough has gathered: on the device (use_device:
+// mk_bgzf_deflate_pieces uploads the pieces back to back, the codec of merkurio_amd/csrc/codec/ does the rest) or, with
+// --host-codec, by zlib on every host thread.  A flush runs on a thread of its own while the caller encodes the next
+// batch; members reach the file in order.
 struct BamWriter {
     FILE *f = nullptr;
-    std::vector<uint8_t> block;  // uncompressed bytes of the block being filled (< 64 KiB per BGZF block)
-    std::vector<std::vector<uint8_t>> pending;  // full blocks waiting for the next parallel deflate
+    std::vector<std::vector<uint8_t>> pieces;  // bytes not handed to a flush yet, in stream order
+    size_t pieces_bytes = 0;
     std::vector<std::string> ref_names;
     ~BamWriter();
     // reference dictionary from the @SQ lines of header_text, or (BAM -> BAM pass-through, where
     // records keep their reference ids) the input's own binary dictionary
     void open(const std::string &path, const std::string &header_text, const std::vector<std::string> *names = nullptr,
               const std::vector<uint32_t> *lens = nullptr);
+    // members are deflated on this HIP device from now on (the handle is created by the first flush)
+    void use_device(int device) { device_ = device; }
     // pass-through of a raw BAM record with one more Z tag appended (thread-safe, see encode_record)
     static void append_tagged_raw(const uint8_t *rec, uint32_t len, const std::string &tag, const char *val, size_t val_len,
                                   std::vector<uint8_t> &dst);
@@ -235,13 +247,20 @@ struct BamWriter {
     // block_size + record bytes of one SAM text line appended to dst (thread-safe: encoding is the
     // slow part of SAM -> BAM and runs on every host thread), then put_encoded() in record order
     void encode_record(const std::string &sam_line, std::vector<uint8_t> &dst) const;
-    void put_encoded(const std::vector<uint8_t> &bytes) { put(bytes.data(), bytes.size()); }
+    void put_encoded(std::vector<uint8_t> &&bytes);
     void close();
+    double deflate_seconds = 0;  // inside the flush threads (timing mode)
 
    private:
     void put(const void *p, size_t n);
-    void flush_block();
-    void flush_pending();
+    void flush(bool all);
+    void wait_flush();
+    void compress_and_write();
+    int device_ = -1;  // < 0: zlib on the host threads
+    void *codec_ = nullptr;
+    std::vector<std::vector<uint8_t>> run_;  // the flush in flight: its text ...
+    std::vector<uint8_t> z_, flat_;          // ... its members; the text in one piece (host codec only)
+    std::future<void> flushing_;
 };
 
 }  // namespace cli

@@ -5,10 +5,10 @@
 // (src/cmd_extract.rs:281).  DEFLATE decoding is serial inside a stream -- every codeword's position depends on the
 // one before it -- but BGZF cuts a file into independent members of <= 64 KiB, thousands per window: the lanes of a
 // wave each decode their own member with the serial decoder of inflate_serial.hpp (the code the host harness checks
-// against zlib), their fast decode tables side by side in LDS (1 152 B per lane, 72 KiB per wave), the rest of the
-// per-stream state (canonical orders for the rare long codewords, the code lengths while a header is read) in
-// private memory.  Bound: latency of dependent LDS / L2 accesses under divergence, hidden only by the number of
-// members in flight (64 per wave, 2 waves per CU: 32 768 streams on the part) -- not HBM, not MFMA.
+// against zlib; that header says what shapes it), each lane's decoder block -- canonical code descriptions, symbol
+// orders, a 64-byte window of its stream: 836 B -- side by side in LDS (52 KiB per wave, 3 waves per CU).  Bound:
+// latency of dependent LDS / L2 accesses under divergence, hidden only by the number of members in flight (64 per
+// wave: 49 152 streams on the part) -- not HBM, not MFMA.
 // The CRC-32 of every member's text is checked by mk_bgzf_crc_check_kernel (bgzf_deflate.hip) afterwards.
 #include <hip/hip_runtime.h>
 
@@ -17,17 +17,16 @@
 
 namespace mkz {
 
-constexpr uint32_t kFastPerLane = kLlFastSize + kDFastSize;
+static_assert(kPad >= kStreamPad, "input buffers carry the decoder's padding");
 
 __global__ __launch_bounds__(64) void mk_bgzf_inflate_kernel(const uint8_t *__restrict__ in, uint64_t n_in, const Member *__restrict__ members,
                                                              uint32_t n_members, uint8_t *__restrict__ out, int32_t *__restrict__ status) {
-    __shared__ uint16_t fast[64 * kFastPerLane];
+    __shared__ uint32_t lanes[64 * (kLaneTableU16 / 2)];
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_members) return;
     const Member m = members[i];
-    InflateScratch s;
-    uint16_t *const ll = fast + threadIdx.x * kFastPerLane;
-    status[i] = inflate_stream(in + m.data_off, m.data_len, out + m.out_off, m.isize, ll, ll + kLlFastSize, s);
+    uint16_t *const t = reinterpret_cast<uint16_t *>(lanes + threadIdx.x * (kLaneTableU16 / 2));
+    status[i] = inflate_stream(in + m.data_off, m.data_len, out + m.out_off, m.isize, t);
 }
 
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status,

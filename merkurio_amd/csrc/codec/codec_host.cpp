@@ -33,8 +33,12 @@ struct mk_codec {
 
 namespace {
 
-constexpr uint64_t kDeflateChunkBlocks = 4096;     // members per device pass (255 MiB of text)
-constexpr uint64_t kInflateChunkText = 256u << 20;  // text bytes per device pass
+// Members per device pass.  Deflate runs one wave per member on a resident grid of 3 waves per CU (768 on an MI355X):
+// 12 288 members = 16 full rounds, 765 MiB of text.  Inflate is bound by the latency of its longest lane, 35-60 ms per
+// launch whether it holds 64 waves or 768 (profiles/r04_codec_kernels.txt): a pass takes as many members as the part
+// holds streams (768 waves x 64 lanes), 3 GiB of text.
+constexpr uint64_t kDeflateChunkBlocks = 12288;
+constexpr uint64_t kInflateChunkText = 3ull << 30;
 
 #define MKC_HIP(call, what)                                   \
     do {                                                      \
@@ -102,9 +106,16 @@ int mk_codec_times(const mk_codec *c, float ms[3]) {
     return MK_OK;
 }
 
-int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_bytes, uint8_t *out, uint64_t out_cap, uint64_t *out_len) {
+int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint64_t *sizes, uint64_t n_pieces, uint32_t block_bytes,
+                           uint8_t *out, uint64_t out_cap, uint64_t *out_len) {
     MK_ABI_BEGIN
-    if (!c || !out_len || (n && (!in || !out))) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: NULL argument");
+    if (!c || !out_len || (n_pieces && (!pieces || !sizes))) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: NULL argument");
+    uint64_t n = 0;
+    for (uint64_t k = 0; k < n_pieces; ++k) {
+        if (sizes[k] && !pieces[k]) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: piece %llu is NULL", (unsigned long long)k);
+        n += sizes[k];
+    }
+    if (n && !out) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: NULL argument");
     const uint32_t bb = block_bytes ? block_bytes : mkz::kMaxBlockBytes;
     if (bb > mkz::kMaxBlockBytes) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: block_bytes %u > %u", bb, mkz::kMaxBlockBytes);
     const uint64_t bound = mk_bgzf_deflate_bound(n, bb);
@@ -118,6 +129,7 @@ int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_b
     c->ms[0] = c->ms[1] = c->ms[2] = 0;
     const uint64_t chunk_bytes = kDeflateChunkBlocks * bb;
     uint64_t written = 0;
+    uint64_t piece = 0, piece_at = 0;  // where the text of the next device pass starts
     for (uint64_t at = 0; at < n; at += chunk_bytes) {
         const uint64_t cn = std::min<uint64_t>(chunk_bytes, n - at);
         const uint32_t blocks = (uint32_t)((cn + bb - 1) / bb);
@@ -131,7 +143,12 @@ int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_b
             return rc;
         uint64_t *d_total = (uint64_t *)c->d_off + blocks;
         MKC_HIP(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
-        MKC_HIP(hipMemcpyAsync(c->d_in, in + at, cn, hipMemcpyHostToDevice, c->stream), "upload of the text");
+        for (uint64_t done = 0; done < cn;) {  // the pieces land back to back: the concatenation exists on the device only
+            while (piece_at == sizes[piece]) ++piece, piece_at = 0;
+            const uint64_t k = std::min<uint64_t>(cn - done, sizes[piece] - piece_at);
+            MKC_HIP(hipMemcpyAsync((uint8_t *)c->d_in + done, pieces[piece] + piece_at, k, hipMemcpyHostToDevice, c->stream), "upload of the text");
+            done += k, piece_at += k;
+        }
         MKC_HIP(hipMemsetAsync((uint8_t *)c->d_in + cn, 0, mkz::kPad, c->stream), "hipMemsetAsync");
         MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
         mkz::launch_crc((const uint8_t *)c->d_in, cn, bb, blocks, (uint32_t *)c->d_crc, c->stream);
@@ -153,6 +170,11 @@ int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_b
     *out_len = written;
     return MK_OK;
     MK_ABI_END
+}
+
+int mk_bgzf_deflate(mk_codec *c, const uint8_t *in, uint64_t n, uint32_t block_bytes, uint8_t *out, uint64_t out_cap, uint64_t *out_len) {
+    if (n && !in) return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_deflate: NULL argument");
+    return mk_bgzf_deflate_pieces(c, &in, &n, n ? 1 : 0, block_bytes, out, out_cap, out_len);
 }
 
 int mk_bgzf_members(const uint8_t *in, uint64_t n, mk_bgzf_member *members, uint64_t cap, uint64_t *n_members, uint64_t *consumed,
@@ -215,7 +237,7 @@ int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf
             out_lo = std::min(out_lo, m.out_off), out_hi = std::max(out_hi, m.out_off + m.isize);
             text += m.isize, ++m1;
         }
-        if (out_hi - out_lo > 2 * kInflateChunkText || in_hi - in_lo > 4 * kInflateChunkText)
+        if (out_hi - out_lo > 2 * kInflateChunkText || in_hi - in_lo > 2 * kInflateChunkText)
             return mk::fail(MK_E_INVALID_ARG, "mk_bgzf_inflate: members %llu.. are scattered over more than a device pass holds",
                             (unsigned long long)m0);
         const uint32_t cnt = (uint32_t)(m1 - m0);
@@ -227,7 +249,7 @@ int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf
         const uint64_t cn = in_hi - in_lo, tn = out_hi - out_lo;
         int rc;
         if ((rc = mk::ensure_device(&c->d_in, &c->in_cap, cn + mkz::kPad)) || (rc = mk::ensure_device(&c->d_aux, &c->aux_cap, cnt * sizeof(mkz::Member))) ||
-            (rc = mk::ensure_device(&c->d_out, &c->out_cap, tn + 1)) || (rc = mk::ensure_device(&c->d_len, &c->len_cap, cnt * 4ull)))
+            (rc = mk::ensure_device(&c->d_out, &c->out_cap, tn + 16)) || (rc = mk::ensure_device(&c->d_len, &c->len_cap, cnt * 4ull)))
             return rc;
         MKC_HIP(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
         MKC_HIP(hipMemcpyAsync(c->d_in, in + in_lo, cn, hipMemcpyHostToDevice, c->stream), "upload of the members");

@@ -15,7 +15,7 @@ namespace mkz {
 constexpr uint32_t kSlotBytes = 65536;       // a member never exceeds 64 KiB (BSIZE is 16 bits)
 constexpr uint32_t kMaxBlockBytes = 0xff00;  // input bytes per member (what htslib / the host writer use)
 constexpr uint32_t kTokensPerWave = 65536;   // token scratch of one resident deflate wave (u32 each)
-constexpr uint32_t kPad = 16;                // readable bytes every input buffer needs behind its last byte
+constexpr uint32_t kPad = 128;               // readable bytes every input buffer needs behind its last byte (inflate_serial.hpp: kStreamPad)
 
 // one member of an inflate call (the host walks the BSIZE chain and fills these)
 struct Member {

@@ -287,75 +287,6 @@ MKZ_HD void write_dynamic_header(BitSink &b, const HeaderScratch &h, bool final_
     }
 }
 
-// ---- decoder tables ----------------------------------------------------------------------------------
-// A code is decoded through a table indexed by the next `pbits` stream bits: entry = symbol << 4 | length for
-// codewords of at most pbits bits (replicated over the unused index bits), 0 for an index no short codeword
-// claims.  Longer codewords (rare: the tail of the code) are decoded bit by bit from the canonical description
-// count[len], sorted[]: the symbols in (length, symbol) order.
-struct DecodeCounts {
-    uint16_t count[kMaxBits + 1];
-};
-// count[] and sorted[] of lens[0..n); returns 0 if the lengths are a usable prefix code, 1 if they are
-// over-subscribed, 2 if incomplete.  An incomplete code is usable only as zlib's inflate_table accepts it: no
-// codeword at all, or (allow_single: literal / length and distance codes, not the code-length code) exactly one
-// codeword of length 1 -- the "one distance code" case of §3.2.7.
-MKZ_HD int canonical_decode_order(const uint8_t *lens, int n, DecodeCounts &c, uint16_t *sorted, bool allow_single = true) {
-    for (int l = 0; l <= kMaxBits; ++l) c.count[l] = 0;
-    for (int i = 0; i < n; ++i) c.count[lens[i]]++;
-    const int used = n - c.count[0];
-    c.count[0] = 0;
-    int left = 1;
-    for (int l = 1; l <= kMaxBits; ++l) {
-        left <<= 1;
-        left -= c.count[l];
-        if (left < 0) return 1;
-    }
-    uint16_t offs[kMaxBits + 2];
-    offs[1] = 0;
-    for (int l = 1; l <= kMaxBits; ++l) offs[l + 1] = (uint16_t)(offs[l] + c.count[l]);
-    for (int i = 0; i < n; ++i)
-        if (lens[i]) sorted[offs[lens[i]]++] = (uint16_t)i;
-    if (left > 0 && !(used == 0 || (allow_single && used == 1 && c.count[1] == 1))) return 2;
-    return 0;
-}
-// entries of the symbols first, first + stride, ... (a wave fills a table with stride 64); table zeroed by the caller
-MKZ_HD void fill_decode_table(const uint8_t *lens, int n, int pbits, uint16_t *table, int first, int stride) {
-    uint32_t count[kMaxBits + 1], next[kMaxBits + 2];
-    for (int l = 0; l <= kMaxBits; ++l) count[l] = 0;
-    for (int i = 0; i < n; ++i) count[lens[i]]++;
-    count[0] = 0;
-    uint32_t code = 0;
-    for (int l = 1; l <= kMaxBits; ++l) {
-        code = (code + count[l - 1]) << 1;
-        next[l] = code;
-    }
-    // the codeword of symbol i = next[len] + (symbols before i with the same length)
-    for (int i = first; i < n; i += stride) {
-        const uint32_t l = lens[i];
-        if (l == 0 || (int)l > pbits) continue;
-        uint32_t rank = 0;
-        for (int j = 0; j < i; ++j) rank += lens[j] == l;
-        const uint32_t r = reverse_bits(next[l] + rank, l);
-        for (uint32_t k = r; k < (1u << pbits); k += 1u << l) table[k] = (uint16_t)((uint32_t)i << 4 | l);
-    }
-}
-// bit-by-bit decode of a codeword from the stream bits `bits` (LSB first); returns symbol << 4 | length, or 0 if no
-// codeword matches within kMaxBits bits
-MKZ_HD uint32_t decode_slow(uint32_t bits, const DecodeCounts &c, const uint16_t *sorted) {
-    int code = 0, first = 0, index = 0;
-    for (int l = 1; l <= kMaxBits; ++l) {
-        code |= (int)(bits & 1u);
-        bits >>= 1;
-        const int cnt = c.count[l];
-        if (code - cnt < first) return (uint32_t)sorted[index + (code - first)] << 4 | (uint32_t)l;
-        index += cnt;
-        first += cnt;
-        first <<= 1;
-        code <<= 1;
-    }
-    return 0;
-}
-
 // the fixed code of §3.2.6
 MKZ_HD void fixed_code_lengths(uint8_t *ll_len /*288*/, uint8_t *d_len /*32*/) {
     for (int i = 0; i < 144; ++i) ll_len[i] = 8;

@@ -52,7 +52,7 @@ EXPORTS = [
     "mk_extract_single", "mk_extract_fastq_text", "mk_upload_text_ahead", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
-    "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
+    "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
     "mk_codec_times",
 ]
 
@@ -199,6 +199,7 @@ def load(build_if_missing=True):
     L.mk_bgzf_deflate_bound.argtypes = [C.c_uint64, C.c_uint32]
     L.mk_bgzf_deflate_bound.restype = C.c_uint64
     L.mk_bgzf_deflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.mk_bgzf_deflate_pieces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.mk_bgzf_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.mk_bgzf_members.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint64)]
@@ -663,6 +664,18 @@ class Codec:
         n = C.c_uint64(0)
         _check(self._L.mk_bgzf_deflate(self._h, src.ctypes.data if src.size else None, src.size, block_bytes,
                                        out.ctypes.data if out.size else None, out.size, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def deflate_pieces(self, pieces, block_bytes=0):
+        """mk_bgzf_deflate_pieces: the members of b"".join(pieces), which is never formed on the host"""
+        arrs = [np.frombuffer(p, dtype=np.uint8) for p in pieces]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data if a.size else None for a in arrs])
+        sizes = (C.c_uint64 * len(arrs))(*[a.size for a in arrs])
+        total = sum(a.size for a in arrs)
+        out = np.empty(self._L.mk_bgzf_deflate_bound(total, block_bytes), dtype=np.uint8)
+        n = C.c_uint64(0)
+        _check(self._L.mk_bgzf_deflate_pieces(self._h, ptrs, sizes, len(arrs), block_bytes, out.ctypes.data if out.size else None, out.size,
+                                              C.byref(n)))
         return out[:n.value].tobytes()
 
     def inflate(self, data, members=None, text_bytes=None):

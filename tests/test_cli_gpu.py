@@ -226,6 +226,12 @@ def test_bgzf_input_and_large_bam_round_trip(tmp_path):
     direct = [ln for ln in sam_without_own_pg(tmp_path / "direct.sam") if ln and not ln.startswith(b"@")]
     assert back == direct and len(direct) == 30000
     assert sum(1 for ln in direct if b"\tkm:Z:" in ln) >= 3000
+    # the members above were deflated on the device (mk_bgzf_deflate); --host-codec = zlib on the host threads, the
+    # checker: the two files must gunzip to the same BAM stream (their @PG lines name the two command lines)
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "h.bam"), "--host-codec"])
+    dev, host = gzip.decompress(raw), gzip.decompress(open(tmp_path / "h.bam", "rb").read())
+    cut = lambda b: b.split(b"\tVN:1.0.0\n", 1)[1]
+    assert cut(dev) == cut(host) and len(dev) > 5_000_000
 
 
 def test_cli_errors(golden, tmp_path):

@@ -16,6 +16,7 @@ import pytest
 
 from merkurio_amd import native as mk
 from test_codec_cpu import corpora, raw_deflate
+from textio import bam_like
 
 pytestmark = pytest.mark.gpu
 
@@ -25,30 +26,6 @@ def codec():
     c = mk.Codec()
     yield c
     c.close()
-
-
-def bam_like(n_rec, seed=5, const_qual=False):
-    """records shaped like `tag`'s BAM output: fixed fields, a counting name, nibble-packed random bases, qualities, a tag"""
-    rng = np.random.default_rng(seed)
-    L = 150
-    rec = np.zeros((n_rec, 36 + 12 + 4 + L // 2 + L + 14), dtype=np.uint8)
-    rec[:, 0:4] = np.frombuffer(struct.pack("<I", rec.shape[1] - 4), dtype=np.uint8)
-    pos = (np.arange(n_rec, dtype=np.uint32) * 37) % 2000000
-    rec[:, 8:12] = pos.view(np.uint8).reshape(n_rec, 4)
-    rec[:, 12] = 12
-    rec[:, 13] = 60
-    rec[:, 16] = 1
-    rec[:, 20:24] = np.frombuffer(struct.pack("<I", L), dtype=np.uint8)
-    rec[:, 24:28] = 255
-    names = np.array([b"r%010d\0" % i for i in range(n_rec)], dtype="S12")
-    rec[:, 36:48] = names.view(np.uint8).reshape(n_rec, 12)
-    rec[:, 48:52] = np.frombuffer(struct.pack("<I", L << 4), dtype=np.uint8)
-    nib = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, size=(n_rec, L))]
-    rec[:, 52:52 + L // 2] = nib[:, 0::2] << 4 | nib[:, 1::2]
-    q0 = 52 + L // 2
-    rec[:, q0:q0 + L] = 40 if const_qual else np.array([2, 12, 23, 37], dtype=np.uint8)[rng.choice(4, size=(n_rec, L), p=[0.02, 0.05, 0.13, 0.8])]
-    rec[:, q0 + L:] = np.frombuffer(b"NMC\0ASC\x96XSZabc\0", dtype=np.uint8)[:14]
-    return rec.tobytes()
 
 
 def check_members(data, blob, block_bytes):
@@ -98,6 +75,24 @@ def test_deflate_sizes_around_a_block_and_a_device_pass(codec):
     blob = codec.deflate(noise)
     check_members(noise, blob, 0)
     assert len(blob) == len(noise) + 3 * 31
+
+
+def test_deflate_of_pieces_equals_deflate_of_their_concatenation(codec):
+    """mk_bgzf_deflate_pieces (the BAM writer's per-thread record buffers): the pieces are joined on the device only"""
+    rng = random.Random(23)
+    data = bam_like(9000, seed=4)
+    cuts = sorted(rng.randrange(len(data)) for _ in range(40)) + [len(data)]
+    pieces, at = [], 0
+    for c in cuts:
+        pieces.append(data[at:c])
+        at = c
+    pieces[5:5] = [b"", b"x", b""]
+    joined = b"".join(pieces)
+    for bb in (0, 5000):
+        blob = codec.deflate_pieces(pieces, bb)
+        assert blob == codec.deflate(joined, bb)
+        check_members(joined, blob, bb)
+    assert codec.deflate_pieces([]) == b"" and codec.deflate_pieces([b"", b""]) == b""
 
 
 def test_deflate_compresses_like_a_fast_zlib_level(codec):

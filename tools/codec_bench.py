@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from merkurio_amd import native as mk
-from test_gpu_codec import bam_like, zlib_bgzf
+from textio import bam_like
+from test_gpu_codec import zlib_bgzf
 
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -87,5 +87,8 @@ if GZ:
     run(f"plain, {m} reads, --host-ingest", small, ["--host-ingest"], m)
     run(f"gzip (one member), {m} reads, device ingest", small + ".gz", [], m)
     run(f"gzip (one member), {m} reads, --host-ingest", small + ".gz", ["--host-ingest"], m)
-    run(f"BGZF, {m} reads, device ingest", bg, [], m)
-    run(f"BGZF, {m} reads, --host-ingest", bg, ["--host-ingest"], m)
+    for rep in range(2):
+        run(f"BGZF, {m} reads, device ingest, members inflated on the device", bg, [], m)
+        run(f"BGZF, {m} reads, device ingest, --host-codec (zlib on the host threads)", bg, ["--host-codec"], m)
+    run(f"BGZF, {m} reads, --host-ingest, members inflated on the device", bg, ["--host-ingest"], m)
+    run(f"BGZF, {m} reads, --host-ingest --host-codec", bg, ["--host-ingest", "--host-codec"], m)
