@@ -6,7 +6,8 @@
 // compressed form is this file's own parse (any RFC 1951 stream is a valid BGZF payload: the reference's readers,
 // htslib and zlib accept it; tests inflate every member with zlib).
 //
-// One WAVE per member (<= 65280 bytes of input), one wave per workgroup, a resident grid that loops over the members:
+// One WAVE per member (<= 65280 bytes of input), one wave per workgroup, a resident grid (16 waves per CU) whose waves
+// take the next member from a counter when they are done with one:
 //   1. parse, 64 positions (one per lane) at a time: 4-byte hash -> most recent earlier position (u16 table in LDS),
 //      match length by 8-byte compares, a distance-1 candidate for runs; a scalar walk over the window's lanes
 //      (ballot + readlane, one step per MATCH, literals in between are taken in one go; one-step lazy evaluation)
@@ -17,8 +18,9 @@
 //   3. the size is known before a bit is written (counts x code lengths): a member that would not shrink is stored.
 //   4. bit packing, 64 tokens at a time: wave scan of the code sizes, lanes OR their bits into an LDS staging
 //      area, whole words go out coalesced; the member's header and BSIZE lead the same word stream.
-// Bound: none of HBM / MFMA -- latency of dependent LDS and L2 accesses per window; what matters is resident waves
-// (LDS per wave: 43 KiB with a 14-bit table) and skipping work (covered windows, literal runs).
+// Bound: none of HBM / MFMA -- latency of dependent LDS and L2 accesses per window (59 % of the wave cycles are waits,
+// profiles/r04_codec_kernels.txt); what matters is resident waves (hence a 1 Ki-entry table: 9.8 KiB of LDS per wave,
+// see kHashBits) and skipping work (covered windows, literal runs).
 #include <hip/hip_runtime.h>
 
 #include "codec_kernels.h"
@@ -26,7 +28,13 @@
 
 namespace mkz {
 
-constexpr int kHashBits = 14;
+// The hash table's size is an occupancy decision, not a compression one: the kernel waits ~60 % of its cycles (dependent
+// L2 / LDS accesses per window), and only other resident waves can fill them.  On BAM-shaped records (2.1 GB, one MI355X;
+// profiles/r04_codec_hash_bits.txt): 14 bits = 3 waves per CU 14.5 GB/s, 13 = 6: 22, 12 = 9: 29.5, 11 = 12: 33,
+// 10 = 14: 38.5, 9 = 16: 42.5 GB/s -- with the ratio unchanged down to 10 bits (3.03; FASTQ text 2.97 -> 2.90, zlib level 1:
+// 2.88) because the table keeps the MOST RECENT position of a hash, which is where BAM / FASTQ repeats come from; at 9
+// bits FASTQ text falls below zlib level 1 (2.86).
+constexpr int kHashBits = 10;
 constexpr uint32_t kMinLen = 4;
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: literal / end-of-block symbol, or kTokMatch | (len-3) << 16 | (dist-1)
 
@@ -77,12 +85,17 @@ __device__ __forceinline__ uint32_t match_len(const uint8_t *a, const uint8_t *b
 struct DeflateLds {
     uint16_t head[1 << kHashBits];
     uint32_t freq_ll[288], freq_d[32];
-    uint32_t key_ll[288], key_d[32];    // (count << 9 | symbol) of the used symbols
-    uint32_t skey_ll[288], skey_d[32];  // ... in ascending order
+    uint32_t skey_ll[288], skey_d[32];  // (count << 9 | symbol) of the used symbols in ascending order
     BlockCodes codes;
-    HeaderScratch hdr;
+    union {  // the unsorted keys are dead once they are ranked, before the code builder's scratch comes to life
+        struct {
+            uint32_t key_ll[288], key_d[32];
+        } k;
+        HeaderScratch hdr;
+    };
     uint32_t words[192];  // the dynamic header's bits, then the staging area of 64 tokens
 };
+static_assert(sizeof(DeflateLds) <= 10240, "16 waves per CU (160 KiB of LDS)");
 
 // keys of the used symbols of freq[0, n), compacted by the wave; returns their number (>= 2, see symbol_keys)
 __device__ uint32_t wave_symbol_keys(const uint32_t *freq, uint32_t n, uint32_t *key, uint32_t lane) {
@@ -133,15 +146,20 @@ __device__ __forceinline__ void token_code(uint32_t t, const BlockCodes &c, uint
     bits |= (uint64_t)dxb << nb, nb += dnb;
 }
 
-__global__ __launch_bounds__(64) void mk_bgzf_deflate_kernel(const uint8_t *__restrict__ in, uint64_t n_bytes, uint32_t block_bytes,
+__global__ __launch_bounds__(64, 4) void mk_bgzf_deflate_kernel(const uint8_t *__restrict__ in, uint64_t n_bytes, uint32_t block_bytes,
                                                              uint32_t n_blocks, const uint32_t *__restrict__ crc,
                                                              uint32_t *__restrict__ tokens, uint8_t *__restrict__ slots,
-                                                             uint32_t *__restrict__ slot_len) {
+                                                             uint32_t *__restrict__ slot_len, uint32_t *__restrict__ next_block) {
     __shared__ DeflateLds L;
     const uint32_t lane = lane_id();
     uint32_t *const tok = tokens + (uint64_t)blockIdx.x * kTokensPerWave;
 
-    for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    // members are handed out one at a time (they take unequal time: a wave that is done asks for the next one)
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(next_block, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= n_blocks) break;
         const uint64_t at = (uint64_t)b * block_bytes;
         const uint8_t *const src = in + at;
         const uint32_t n = (uint32_t)(n_bytes - at < block_bytes ? n_bytes - at : block_bytes);
@@ -226,10 +244,10 @@ __global__ __launch_bounds__(64) void mk_bgzf_deflate_kernel(const uint8_t *__re
         __syncthreads();
 
         // ---- 2. the codes -------------------------------------------------------------------------------
-        const uint32_t m_ll = wave_symbol_keys(L.freq_ll, kLitLen, L.key_ll, lane);
-        const uint32_t m_d = wave_symbol_keys(L.freq_d, kDist, L.key_d, lane);
-        wave_rank_sort(L.key_ll, m_ll, L.skey_ll, lane);
-        wave_rank_sort(L.key_d, m_d, L.skey_d, lane);
+        const uint32_t m_ll = wave_symbol_keys(L.freq_ll, kLitLen, L.k.key_ll, lane);
+        const uint32_t m_d = wave_symbol_keys(L.freq_d, kDist, L.k.key_d, lane);
+        wave_rank_sort(L.k.key_ll, m_ll, L.skey_ll, lane);
+        wave_rank_sort(L.k.key_d, m_d, L.skey_d, lane);
         if (lane == 0) {
             block_codes_from_sorted(L.skey_ll, (int)m_ll, L.skey_d, (int)m_d, L.codes, L.hdr.huff);
             L.words[191] = plan_dynamic_header(L.codes.ll_len, L.codes.d_len, L.hdr);
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(256) void mk_bgzf_pack_kernel(const uint8_t *__rest
 
 // ---- launchers ----------------------------------------------------------------------------------------------------
 uint32_t deflate_grid(uint32_t n_blocks, int num_cus) {
-    const uint32_t resident = (uint32_t)num_cus * 3;  // 160 KiB of LDS per CU / 43 KiB per wave
+    const uint32_t resident = (uint32_t)num_cus * 16;  // 10 KiB of LDS and < 128 VGPRs per wave: 4 waves per SIMD
     return n_blocks < resident ? n_blocks : resident;
 }
 
@@ -425,9 +443,10 @@ void launch_crc_check(const uint8_t *out, const Member *members, uint32_t n_memb
     hipLaunchKernelGGL(mk_bgzf_crc_check_kernel, dim3((n_members + 3) / 4), dim3(256), 0, s, out, members, n_members, status);
 }
 void launch_deflate(const uint8_t *in, uint64_t n, uint32_t block_bytes, uint32_t n_blocks, const uint32_t *crc, uint32_t *tokens,
-                    uint8_t *slots, uint32_t *slot_len, uint32_t grid, hipStream_t s) {
+                    uint8_t *slots, uint32_t *slot_len, uint32_t *next_block, uint32_t grid, hipStream_t s) {
     if (!n_blocks) return;
-    hipLaunchKernelGGL(mk_bgzf_deflate_kernel, dim3(grid), dim3(64), 0, s, in, n, block_bytes, n_blocks, crc, tokens, slots, slot_len);
+    (void)hipMemsetAsync(next_block, 0, 4, s);
+    hipLaunchKernelGGL(mk_bgzf_deflate_kernel, dim3(grid), dim3(64), 0, s, in, n, block_bytes, n_blocks, crc, tokens, slots, slot_len, next_block);
 }
 void launch_pack(const uint8_t *slots, const uint32_t *slot_len, uint64_t *slot_off, uint64_t *total, uint32_t n_blocks, uint8_t *packed,
                  hipStream_t s) {

@@ -19,20 +19,33 @@ namespace mkz {
 
 static_assert(kPad >= kStreamPad, "input buffers carry the decoder's padding");
 
+// blockDim.x = the lanes of a wave that hold a member (8, 16, 32 or 64): LDS is sized for them at launch
 __global__ __launch_bounds__(64) void mk_bgzf_inflate_kernel(const uint8_t *__restrict__ in, uint64_t n_in, const Member *__restrict__ members,
                                                              uint32_t n_members, uint8_t *__restrict__ out, int32_t *__restrict__ status) {
-    __shared__ uint32_t lanes[64 * (kLaneTableU16 / 2)];
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ uint32_t lanes[];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_members) return;
     const Member m = members[i];
     uint16_t *const t = reinterpret_cast<uint16_t *>(lanes + threadIdx.x * (kLaneTableU16 / 2));
     status[i] = inflate_stream(in + m.data_off, m.data_len, out + m.out_off, m.isize, t);
 }
 
-void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status,
+// The lanes of a wave turn the decoder's loop together, so a wave is as slow as its slowest lane on every turn, and a launch
+// lasts as long as its slowest wave whatever it holds.  A call that does not fill the part's lanes is therefore spread over
+// MORE, NARROWER waves: the lockstep maximum is taken over fewer members and the waves of a SIMD fill each other's waits
+// (132 VGPRs: 3 waves per SIMD, 12 per CU).  Full waves only when there are members for all of them.
+uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
+    uint32_t lanes = 8;
+    while (lanes < 64 && (n_members + lanes - 1) / lanes > (uint32_t)num_cus * 12) lanes *= 2;
+    return lanes;
+}
+
+void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s) {
     if (!n_members) return;
-    hipLaunchKernelGGL(mk_bgzf_inflate_kernel, dim3((n_members + 63) / 64), dim3(64), 0, s, in, n_in, members, n_members, out, status);
+    const uint32_t lanes = inflate_lanes(n_members, num_cus);
+    hipLaunchKernelGGL(mk_bgzf_inflate_kernel, dim3((n_members + lanes - 1) / lanes), dim3(lanes), lanes * (kLaneTableU16 / 2) * 4, s, in, n_in, members,
+                       n_members, out, status);
 }
 
 }  // namespace mkz

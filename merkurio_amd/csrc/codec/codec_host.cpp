@@ -37,7 +37,7 @@ namespace {
 // 12 288 members = 16 full rounds, 765 MiB of text.  Inflate is bound by the latency of its longest lane, 35-60 ms per
 // launch whether it holds 64 waves or 768 (profiles/r04_codec_kernels.txt): a pass takes as many members as the part
 // holds streams (768 waves x 64 lanes), 3 GiB of text.
-constexpr uint64_t kDeflateChunkBlocks = 12288;
+constexpr uint64_t kDeflateChunkBlocks = 49152;
 constexpr uint64_t kInflateChunkText = 3ull << 30;
 
 #define MKC_HIP(call, what)                                   \
@@ -138,7 +138,7 @@ int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint
         if ((rc = mk::ensure_device(&c->d_in, &c->in_cap, cn + mkz::kPad)) || (rc = mk::ensure_device(&c->d_crc, &c->crc_cap, blocks * 4ull)) ||
             (rc = mk::ensure_device(&c->d_tokens, &c->tokens_cap, (uint64_t)grid * mkz::kTokensPerWave * 4)) ||
             (rc = mk::ensure_device(&c->d_slots, &c->slots_cap, (uint64_t)blocks * mkz::kSlotBytes)) ||
-            (rc = mk::ensure_device(&c->d_len, &c->len_cap, blocks * 4ull)) || (rc = mk::ensure_device(&c->d_off, &c->off_cap, (blocks + 1) * 8ull)) ||
+            (rc = mk::ensure_device(&c->d_len, &c->len_cap, blocks * 4ull)) || (rc = mk::ensure_device(&c->d_off, &c->off_cap, (blocks + 2) * 8ull)) ||
             (rc = mk::ensure_device(&c->d_out, &c->out_cap, mk_bgzf_deflate_bound(cn, bb))))
             return rc;
         uint64_t *d_total = (uint64_t *)c->d_off + blocks;
@@ -153,7 +153,7 @@ int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint
         MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
         mkz::launch_crc((const uint8_t *)c->d_in, cn, bb, blocks, (uint32_t *)c->d_crc, c->stream);
         mkz::launch_deflate((const uint8_t *)c->d_in, cn, bb, blocks, (const uint32_t *)c->d_crc, (uint32_t *)c->d_tokens, (uint8_t *)c->d_slots,
-                            (uint32_t *)c->d_len, grid, c->stream);
+                            (uint32_t *)c->d_len, (uint32_t *)(d_total + 1), grid, c->stream);
         mkz::launch_pack((const uint8_t *)c->d_slots, (const uint32_t *)c->d_len, (uint64_t *)c->d_off, d_total, blocks, (uint8_t *)c->d_out, c->stream);
         MKC_HIP(hipGetLastError(), "BGZF deflate kernels");
         MKC_HIP(hipEventRecord(c->ev[2], c->stream), "hipEventRecord");
@@ -256,7 +256,7 @@ int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf
         MKC_HIP(hipMemsetAsync((uint8_t *)c->d_in + cn, 0, mkz::kPad, c->stream), "hipMemsetAsync");
         MKC_HIP(hipMemcpyAsync(c->d_aux, part.data(), cnt * sizeof(mkz::Member), hipMemcpyHostToDevice, c->stream), "upload of the member table");
         MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
-        mkz::launch_inflate((const uint8_t *)c->d_in, cn, (const mkz::Member *)c->d_aux, cnt, (uint8_t *)c->d_out, (int32_t *)c->d_len, c->stream);
+        mkz::launch_inflate((const uint8_t *)c->d_in, cn, (const mkz::Member *)c->d_aux, cnt, (uint8_t *)c->d_out, (int32_t *)c->d_len, c->num_cus, c->stream);
         mkz::launch_crc_check((const uint8_t *)c->d_out, (const mkz::Member *)c->d_aux, cnt, (int32_t *)c->d_len, c->stream);
         MKC_HIP(hipGetLastError(), "BGZF inflate kernels");
         MKC_HIP(hipEventRecord(c->ev[2], c->stream), "hipEventRecord");

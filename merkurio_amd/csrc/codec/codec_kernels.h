@@ -33,15 +33,18 @@ void launch_crc_check(const uint8_t *out, const Member *members, uint32_t n_memb
 // Deflate: block b of in -> one complete BGZF member in slots[b * kSlotBytes ...], its size in slot_len[b].
 // tokens: kTokensPerWave u32 per launched wave (deflate_grid(n_blocks) waves); `in` readable up to in + n + kPad.
 uint32_t deflate_grid(uint32_t n_blocks, int num_cus);
+// next_block: one u32 of device memory (the kernel's work counter; zeroed by the launcher)
 void launch_deflate(const uint8_t *in, uint64_t n, uint32_t block_bytes, uint32_t n_blocks, const uint32_t *crc, uint32_t *tokens,
-                    uint8_t *slots, uint32_t *slot_len, uint32_t grid, hipStream_t s);
+                    uint8_t *slots, uint32_t *slot_len, uint32_t *next_block, uint32_t grid, hipStream_t s);
 // slot_len[0, n_blocks) -> slot_off (exclusive sums, u64) and *total; then the members back to back
 void launch_pack(const uint8_t *slots, const uint32_t *slot_len, uint64_t *slot_off, uint64_t *total, uint32_t n_blocks, uint8_t *packed,
                  hipStream_t s);
 
 // Inflate: member i of `in` -> out[out_off, out_off + isize); status[i] = 0 or an error code of inflate_serial.hpp.
 // `in` readable up to in + n_in + kPad.
-void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status,
+// (8 to 64 members per wave, by how many there are: inflate_lanes)
+uint32_t inflate_lanes(uint32_t n_members, int num_cus);
+void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s);
 
 }  // namespace mkz

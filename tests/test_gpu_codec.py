@@ -175,3 +175,52 @@ def test_inflate_refuses_damaged_members(codec):
     with pytest.raises(mk.MerkurioError) as e:
         codec.inflate(bytes(blob), m2, int(mem["isize"].sum()))
     assert e.value.code == mk.MK_E_INVALID_ARG
+
+
+def _fuzz_text(rng, n):
+    """text with the structures a parse can trip over: runs, short periods, long repeats, near-matches, noise"""
+    out = bytearray()
+    alphabet = bytes(rng.sample(range(256), rng.choice((1, 2, 4, 16, 64, 256))))
+    while len(out) < n:
+        kind = rng.randrange(7)
+        if kind == 0:
+            out += bytes(rng.choice(alphabet) for _ in range(rng.randrange(1, 400)))
+        elif kind == 1:
+            out += bytes([rng.choice(alphabet)]) * rng.randrange(1, 700)  # runs: distance 1, lengths across 258
+        elif kind == 2:
+            p = bytes(rng.choice(alphabet) for _ in range(rng.randrange(2, 9)))  # periods 2..8: the register-pattern copies
+            out += p * rng.randrange(1, 120)
+        elif kind == 3 and out:
+            b = rng.randrange(len(out))  # a repeat of earlier text, any distance (also > 32 KiB: must not become a match)
+            out += out[b:b + rng.randrange(3, 600)]
+        elif kind == 4 and out:
+            b = rng.randrange(len(out))  # a repeat with one byte changed
+            s = bytearray(out[b:b + rng.randrange(8, 300)])
+            s[rng.randrange(len(s))] ^= 1 + rng.randrange(255)
+            out += s
+        elif kind == 5:
+            out += bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 300)))
+        else:
+            out += b"@r%d\n" % rng.randrange(10 ** 9) + bytes(rng.choice(b"ACGT") for _ in range(100)) + b"\n+\n" + b"F" * 100 + b"\n"
+    return bytes(out[:n])
+
+
+def test_fuzz_both_directions(codec):
+    """seeded random texts and block sizes: device deflate -> zlib, zlib (random level / strategy / flush points) -> device
+    inflate, device -> device; every case byte for byte"""
+    import os
+    n_cases = int(os.environ.get("MERKURIO_FUZZ_CODEC", "60"))
+    for seed in range(n_cases):
+        rng = random.Random(1000 + seed)
+        n = rng.choice((rng.randrange(1, 300), rng.randrange(300, 70000), rng.randrange(70000, 400000)))
+        data = _fuzz_text(rng, n)
+        bb = rng.choice((0, 0, 65280, rng.randrange(1, 65281)))
+        blob = codec.deflate(data, bb)
+        assert gzip.decompress(blob) == data, (seed, "device deflate -> zlib")
+        mem, used, text = mk.bgzf_members(blob)
+        assert used == len(blob) and text == len(data) and all(int(m["crc"]) == zlib.crc32(data[int(m["out_off"]):int(m["out_off"]) + int(m["isize"])]) for m in mem)
+        assert codec.inflate(blob) == data, (seed, "device -> device")
+        kw = rng.choice(({"level": rng.randrange(0, 10)}, {"strategy": zlib.Z_FIXED}, {"strategy": zlib.Z_HUFFMAN_ONLY}, {"strategy": zlib.Z_RLE},
+                         {"level": rng.randrange(1, 10), "flush_every": rng.randrange(50, 20000)}))
+        zb = zlib_bgzf(data, rng.randrange(1, 65281) if rng.random() < 0.3 else 65280, **kw)
+        assert codec.inflate(zb) == data, (seed, "zlib -> device inflate", kw)
