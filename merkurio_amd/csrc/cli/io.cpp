@@ -9,6 +9,19 @@
 
 #include "../../../include/merkurio_hip.h"
 
+// The device codec is reached through weak references: the reader / writer harnesses of the CPU tests compile this file
+// without libmerkurio_hip.so (they never select a device: set_bgzf_device / BamWriter::use_device), the CLI links it.
+extern "C" {
+__attribute__((weak)) int mk_codec_create(int device, mk_codec **out);
+__attribute__((weak)) void mk_codec_destroy(mk_codec *c);
+__attribute__((weak)) uint64_t mk_bgzf_deflate_bound(uint64_t n, uint32_t block_bytes);
+__attribute__((weak)) int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint64_t *sizes, uint64_t n_pieces, uint32_t block_bytes,
+                                                 uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+__attribute__((weak)) int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf_member *members, uint64_t n_members, uint8_t *out,
+                                          uint64_t out_cap, uint64_t *bad_member);
+__attribute__((weak)) const char *mk_last_error(void);
+}
+
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -119,7 +132,7 @@ static int g_bgzf_device = -1;
 static std::mutex g_bgzf_mu;
 static mk_codec *g_bgzf_codec = nullptr;
 static double g_bgzf_device_seconds = 0;
-void set_bgzf_device(int device) { g_bgzf_device = device; }
+void set_bgzf_device(int device) { g_bgzf_device = mk_bgzf_inflate ? device : -1; }
 double bgzf_device_seconds() { return g_bgzf_device_seconds; }
 // A launch of the inflate kernel takes 35-60 ms whether it holds 64 members or 49 152 (one lane per member, bound by
 // the latency of a lane's serial decode: profiles/r04_codec_kernels.txt); zlib on 16 host threads inflates ~4 GB/s.
@@ -1157,7 +1170,14 @@ int SamFile::find_tag(size_t i, const std::string &tag, std::string *val) const 
 }
 
 // ---- BAM output ---------------------------------------------------------------------------------
-BamWriter::~BamWriter() { close(); }
+BamWriter::~BamWriter() {
+    try {
+        close();  // (the command closes the writer itself: an error surfaces there, not here)
+    } catch (...) {
+    }
+}
+
+void BamWriter::use_device(int device) { device_ = mk_bgzf_deflate_pieces ? device : -1; }
 
 constexpr size_t kBgzfBlock = 0xff00;
 constexpr size_t kFlushBytes = 1536 * kBgzfBlock;  // 100 MB of text per flush: two rounds of the deflate kernel's resident waves
@@ -1203,40 +1223,69 @@ static void bgzf_compress(const uint8_t *in, size_t n, std::vector<uint8_t> &out
     out.resize(clen + 26);
 }
 
-void BamWriter::wait_flush() {
-    if (flushing_.valid()) flushing_.get();  // rethrows what the flush thread met
+constexpr size_t kMaxQueuedRuns = 6;
+
+void BamWriter::writer_loop() {
+    for (;;) {
+        Run run;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return !queue_.empty() || closing_; });
+            if (queue_.empty()) return;
+            run = std::move(queue_.front());
+            queue_.pop_front();
+            busy_ = true;
+        }
+        cv_.notify_all();
+        try {
+            if (!failed_) compress_and_write(run);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!failed_) failed_ = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            busy_ = false;
+        }
+        cv_.notify_all();
+    }
 }
 
-// whole members of the stream so far (all of it at close) go to a flush thread; the bytes behind the last whole
+// whole members of the stream so far (all of it at close) go to the writer thread; the bytes behind the last whole
 // member -- less than one member -- stay, as the first piece of what follows
 void BamWriter::flush(bool all) {
-    wait_flush();
     const size_t take = all ? pieces_bytes : pieces_bytes / kBgzfBlock * kBgzfBlock;
     if (!take) return;
-    run_.clear();
+    Run run;
     std::vector<uint8_t> rest;
     size_t at = 0;
     for (auto &p : pieces) {
         if (at + p.size() <= take) {
             at += p.size();
-            run_.push_back(std::move(p));
+            run.push_back(std::move(p));
         } else {
             const size_t keep = at < take ? take - at : 0;  // bytes of this piece that belong to the run
             rest.insert(rest.end(), p.begin() + keep, p.end());
             at += p.size();
             if (keep) {
                 p.resize(keep);
-                run_.push_back(std::move(p));
+                run.push_back(std::move(p));
             }
         }
     }
     pieces.clear();
     pieces_bytes = rest.size();
     if (!rest.empty()) pieces.push_back(std::move(rest));
-    flushing_ = std::async(std::launch::async, [this] { compress_and_write(); });
+    std::unique_lock<std::mutex> lk(mu_);
+    if (failed_) std::rethrow_exception(failed_);
+    if (!writer_.joinable()) writer_ = std::thread([this] { writer_loop(); });
+    cv_.wait(lk, [&] { return queue_.size() < kMaxQueuedRuns; });
+    queue_.push_back(std::move(run));
+    lk.unlock();
+    cv_.notify_all();
 }
 
-void BamWriter::compress_and_write() {
+void BamWriter::compress_and_write(Run &run_) {
     const auto t0 = std::chrono::steady_clock::now();
     size_t total = 0;
     for (auto &p : run_) total += p.size();
@@ -1473,12 +1522,27 @@ void BamWriter::encode_record(const std::string &line, std::vector<uint8_t> &dst
 
 void BamWriter::close() {
     if (!f) return;
-    flush(true);
-    wait_flush();
-    fwrite(mk_bgzf_eof(), 1, 28, f);
+    std::exception_ptr err;
+    try {
+        flush(true);
+    } catch (...) {
+        err = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        closing_ = true;
+    }
+    cv_.notify_all();
+    if (writer_.joinable()) writer_.join();
+    if (!err && failed_) err = failed_;
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!err) fwrite(eof, 1, sizeof(eof), f);
     fclose(f);
     f = nullptr;
     if (codec_) mk_codec_destroy((mk_codec *)codec_), codec_ = nullptr;
+    closing_ = false;
+    failed_ = nullptr;
+    if (err) std::rethrow_exception(err);
 }
 
 void BamWriter::append_tagged_raw(const uint8_t *rec, uint32_t len, const std::string &tag, const char *val, size_t val_len,

@@ -4,7 +4,11 @@
 // bam 0.1.4 for SAM/BAM (src/cmd_tag.rs:470-497,503-615).
 #pragma once
 #include <cstdint>
+#include <condition_variable>
+#include <deque>
+#include <exception>
 #include <future>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -239,7 +243,7 @@ struct BamWriter {
     void open(const std::string &path, const std::string &header_text, const std::vector<std::string> *names = nullptr,
               const std::vector<uint32_t> *lens = nullptr);
     // members are deflated on this HIP device from now on (the handle is created by the first flush)
-    void use_device(int device) { device_ = device; }
+    void use_device(int device);
     // pass-through of a raw BAM record with one more Z tag appended (thread-safe, see encode_record)
     static void append_tagged_raw(const uint8_t *rec, uint32_t len, const std::string &tag, const char *val, size_t val_len,
                                   std::vector<uint8_t> &dst);
@@ -252,15 +256,22 @@ struct BamWriter {
     double deflate_seconds = 0;  // inside the flush threads (timing mode)
 
    private:
+    using Run = std::vector<std::vector<uint8_t>>;  // a run of whole members, as the pieces it arrived in
     void put(const void *p, size_t n);
     void flush(bool all);
-    void wait_flush();
-    void compress_and_write();
+    void writer_loop();
+    void compress_and_write(Run &run);
     int device_ = -1;  // < 0: zlib on the host threads
     void *codec_ = nullptr;
-    std::vector<std::vector<uint8_t>> run_;  // the flush in flight: its text ...
-    std::vector<uint8_t> z_, flat_;          // ... its members; the text in one piece (host codec only)
-    std::future<void> flushing_;
+    std::vector<uint8_t> z_, flat_;  // the run being written: its members; its text in one piece (host codec only)
+    // runs wait in a queue for the writer thread (a batch hands over several at once: with one flush in flight the
+    // caller stood behind its own previous run); at most kMaxQueuedRuns of them, then the caller waits
+    std::deque<Run> queue_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::thread writer_;
+    bool closing_ = false, busy_ = false;
+    std::exception_ptr failed_;
 };
 
 }  // namespace cli

@@ -346,12 +346,22 @@ __device__ __forceinline__ void build_crc_tables(uint32_t (*t)[256]) {
         __syncthreads();
     }
 }
-// the CRC-32 of d[0, n), computed by one wave
+// the CRC-32 of d[0, n), computed by one wave: a contiguous piece per lane, read 16 bytes at a time (a lane's loads walk
+// its own piece, so a wave-wide load touches 64 lines: with dword loads every line came up from L2 sixteen times)
 __device__ uint32_t wave_crc32(const uint8_t *d, uint32_t n, const uint32_t (*t)[256], uint32_t lane) {
-    const uint32_t piece = (((n + 63) >> 6) + 3) & ~3u;
+    const uint32_t piece = (((n + 63) >> 6) + 15) & ~15u;
     const uint32_t b0 = lane * piece < n ? lane * piece : n, e0 = b0 + piece < n ? b0 + piece : n;
     uint32_t r = lane == 0 ? 0xffffffffu : 0u;
     uint32_t i = b0;
+    for (; i + 16 <= e0; i += 16) {
+        uint32_t w[4];
+        __builtin_memcpy(w, d + i, 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r ^= w[k];
+            r = t[3][r & 255u] ^ t[2][(r >> 8) & 255u] ^ t[1][(r >> 16) & 255u] ^ t[0][r >> 24];
+        }
+    }
     for (; i + 4 <= e0; i += 4) {
         r ^= ld32(d + i);
         r = t[3][r & 255u] ^ t[2][(r >> 8) & 255u] ^ t[1][(r >> 16) & 255u] ^ t[0][r >> 24];

@@ -646,6 +646,7 @@ class Codec:
     """mk_codec: BGZF members deflated / inflated by the gfx950 kernels (no CPU path: without a device creation raises)"""
 
     def __init__(self, device=0):
+        self._h = None
         self._L = load()
         h = C.c_void_p()
         _check(self._L.mk_codec_create(device, C.byref(h)))

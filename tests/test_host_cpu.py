@@ -179,3 +179,41 @@ def test_geometry_plan_and_length_classes():
         mk.plan_geometry([31, 8], dict(length_classes=3))
     with pytest.raises(mk.MerkurioError):
         mk.plan_geometry([31, 8], dict(force_q2=9))
+
+
+def test_bgzf_member_walk_and_codec_without_gpu():
+    """mk_bgzf_members is host code (the BSIZE chain of SAM spec 4.1): members written by zlib, extra subfields in front of
+    BC, a trailing partial member, headers that are not BGZF.  The codec itself has no CPU path: no device, no handle."""
+    import struct
+    import zlib
+
+    def member(block, extra=b""):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        z = co.compress(block) + co.flush()
+        xtra = extra + b"BC" + struct.pack("<HH", 2, len(z) + 12 + len(extra) + 6 + 8 - 1)
+        return bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff]) + struct.pack("<H", len(xtra)) + xtra + z + struct.pack("<II", zlib.crc32(block), len(block))
+
+    rnd = random.Random(5)
+    blocks = [bytes(rnd.choice(b"ACGT") for _ in range(n)) for n in (1, 700, 65280, 0, 3000)]
+    blob = b"".join(member(b, b"XY\x03\x00abc" if k == 2 else b"") for k, b in enumerate(blocks)) + mk.bgzf_eof()
+    mem, used, text = mk.bgzf_members(blob)
+    assert used == len(blob) and text == sum(map(len, blocks)) and len(mem) == len(blocks) + 1
+    at = 0
+    for m, b in zip(mem, blocks + [b""]):
+        assert int(m["isize"]) == len(b) and int(m["out_off"]) == at and int(m["crc"]) == zlib.crc32(b)
+        d = zlib.decompressobj(-15)
+        assert d.decompress(blob[int(m["data_off"]):int(m["data_off"]) + int(m["data_len"])]) == b
+        at += len(b)
+    mem2, used2, _ = mk.bgzf_members(blob[:-40])  # the last members are cut: whole members only, no error
+    assert used2 < len(blob) - 40 and len(mem2) == len(mem) - 2
+    assert mk.bgzf_eof() == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    for bad in (b"\x1f\x8b\x08\x00" + bytes(30), b"PK\x03\x04" + bytes(30), blob[:3] + b"\x00" + blob[4:]):
+        with pytest.raises(mk.MerkurioError) as e:
+            mk.bgzf_members(bad)
+        assert e.value.code == mk.MK_E_CORRUPT
+    L = mk.load()
+    assert L.mk_bgzf_deflate_bound(0, 0) == 0 and L.mk_bgzf_deflate_bound(65280, 0) == 65280 + 31 and L.mk_bgzf_deflate_bound(65281, 0) == 65281 + 62
+    if mk.device_count() == 0:
+        with pytest.raises(mk.MerkurioError) as e:
+            mk.Codec()
+        assert e.value.code == mk.MK_E_HIP and "no CPU path" in str(e.value)
