@@ -956,9 +956,14 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     std::vector<mk_counters> dev_c(ms.size());
     std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
     for (auto &x : dev_c) memset(&x, 0, sizeof(x));
-    while (sam.fill(window_bytes)) {
+    bool more_windows = sam.fill(window_bytes);
+    while (more_windows) {
         const size_t n = sam.recs.size();
         tm.mark("window: read (inflate) + index");
+        // the next window of a compressed input is inflated (device codec: the host threads are free for the batches
+        // below) and indexed beside this one; an error in it is reported after this window was written
+        std::future<void> next_window = std::async(std::launch::async, [&] { sam.prefetch(window_bytes); });
+        try {
         if (ms.size() == 1) {
             scan_range(m, dev_bufs[0], 0, n, c, counts, io_threads(), [&](BatchOut &&o) {
                 emit(o);
@@ -977,7 +982,13 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
             for (auto &v : outs)
                 for (auto &o : v) emit(o);
         }
+        } catch (...) {
+            next_window.wait();  // it works on sam
+            throw;
+        }
         tm.mark("window done");
+        next_window.get();
+        more_windows = sam.fill(window_bytes);
     }
     if (ms.size() > 1) {
         reduce_device_counters(ms, devs, dev_c, dev_counts, c, counts);

@@ -1042,45 +1042,92 @@ void SamFile::drop_front(uint64_t k) {
     buf_len -= k;
 }
 
-bool SamFile::fill(uint64_t window_bytes) {
-    recs.clear();
-    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
-    if (!src.mapped()) {  // compressed: drop what became records, take more
-        drop_front(cursor);
-        cursor = 0;
-    }
+// The next records of a compressed input: b[0, bl) holds the text not yet turned into records (it starts at a record /
+// line start), more is inflated behind it until ~window_bytes are there, the records are parsed into rs; cur = the
+// bytes of b they cover.  false: no record is left.
+bool SamFile::next_window(std::vector<char> &b, uint64_t &bl, uint64_t &cur, std::vector<Rec> &rs, uint64_t window_bytes) {
+    rs.clear();
+    cur = 0;
     for (;;) {
-        if (!src.mapped() && buf_len < window_bytes) src.more_into(buf, buf_len, window_bytes - buf_len);
-        const char *d = bytes();
-        const uint64_t n = n_bytes();
-        data = d;
-        if (cursor >= n && src.exhausted()) return false;
+        if (bl < window_bytes) src.more_into(b, bl, window_bytes - bl);
+        const char *d = b.data();
+        const uint64_t n = bl;
+        if (cur >= n && src.exhausted()) return false;
+        SamFile part;  // (the parsers append to a SamFile's records)
+        part.is_bam = is_bam;
         if (is_bam) {
-            cursor = parse_bam_records(d, n, cursor, std::min<uint64_t>(n, cursor + window_bytes), !src.exhausted(), *this);
+            cur = parse_bam_records(d, n, cur, std::min<uint64_t>(n, cur + window_bytes), !src.exhausted(), part);
         } else {
-            uint64_t stop;
-            if (src.mapped()) {
-                stop = std::min(n, cursor + window_bytes);
-                if (stop < n) stop = std::min(line_end(d, n, stop > 0 ? stop - 1 : 0) + 1, n);  // first line start at or after
-            } else {
-                stop = std::min(n, cursor + window_bytes);
-                if (stop < n) stop = std::min(line_end(d, n, stop > 0 ? stop - 1 : 0) + 1, n);  // first line start at or after
-                if (stop >= n && !src.exhausted()) {  // the last line of the buffer may go on: complete lines only
-                    stop = n;
-                    while (stop > cursor && d[stop - 1] != '\n') --stop;
-                }
+            uint64_t stop = std::min(n, cur + window_bytes);
+            if (stop < n) stop = std::min(line_end(d, n, stop > 0 ? stop - 1 : 0) + 1, n);  // first line start at or after
+            if (stop >= n && !src.exhausted()) {  // the last line of the buffer may go on: complete lines only
+                stop = n;
+                while (stop > cur && d[stop - 1] != '\n') --stop;
             }
-            if (stop > cursor) parse_sam_text(d, n, cursor, stop, false, *this);
-            cursor = stop;
+            if (stop > cur) parse_sam_text(d, n, cur, stop, false, part);
+            cur = stop;
         }
-        if (!recs.empty()) return true;
-        if (src.exhausted() && cursor >= n) return false;
+        if (!part.recs.empty()) {
+            rs.swap(part.recs);
+            return true;
+        }
+        if (src.exhausted() && cur >= n) return false;
         if (src.exhausted()) {  // bytes are left that are no record
             if (is_bam) bail("Error during BAM record parsing: truncated file");
             return false;
         }
-        if (src.mapped()) continue;       // a window without records (blank lines): next one
-        src.more_into(buf, buf_len, std::max<uint64_t>(window_bytes, buf_len));  // one record larger than the window
+        src.more_into(b, bl, std::max<uint64_t>(window_bytes, bl));  // one record larger than the window
+    }
+}
+
+// (compressed input) the window after the current one, prepared beside it: the unconsumed tail of the current window
+// opens a second buffer, the inflate (device codec or host threads) and the record index run on the calling thread while
+// the current window's `data` / `recs` stay as they are; the next fill() swaps the result in
+void SamFile::prefetch(uint64_t window_bytes) {
+    if (src.mapped() || have_next) return;
+    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
+    const uint64_t tail = buf_len > cursor ? buf_len - cursor : 0;
+    if (nbuf.size() < tail) nbuf.resize(tail);
+    if (tail) memcpy(nbuf.data(), buf.data() + cursor, tail);
+    nbuf_len = tail;
+    next_more = next_window(nbuf, nbuf_len, ncursor, nrecs, window_bytes);
+    have_next = true;
+}
+
+bool SamFile::fill(uint64_t window_bytes) {
+    if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
+    if (!src.mapped()) {  // compressed: drop what became records, take more
+        if (have_next) {  // prefetch() has done that already
+            have_next = false;
+            buf.swap(nbuf);
+            buf_len = nbuf_len;
+            cursor = ncursor;
+            recs.swap(nrecs);
+            nrecs.clear();
+            data = buf.data();
+            return next_more;
+        }
+        drop_front(cursor);
+        const bool more = next_window(buf, buf_len, cursor, recs, window_bytes);
+        data = buf.data();
+        return more;
+    }
+    recs.clear();
+    for (;;) {
+        const char *d = src.text();
+        const uint64_t n = src.text_size();
+        data = d;
+        if (cursor >= n) return false;
+        if (is_bam) {
+            cursor = parse_bam_records(d, n, cursor, std::min<uint64_t>(n, cursor + window_bytes), false, *this);
+        } else {
+            uint64_t stop = std::min(n, cursor + window_bytes);
+            if (stop < n) stop = std::min(line_end(d, n, stop > 0 ? stop - 1 : 0) + 1, n);  // first line start at or after
+            if (stop > cursor) parse_sam_text(d, n, cursor, stop, false, *this);
+            cursor = stop;
+        }
+        if (!recs.empty()) return true;
+        // a window without records (blank lines): next one
     }
 }
 

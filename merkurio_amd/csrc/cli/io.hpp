@@ -204,6 +204,10 @@ struct SamFile {
     // then points at that window.
     void open(const std::string &path);
     bool fill(uint64_t window_bytes);
+    // (compressed input; a no-op otherwise) reads, inflates and indexes the window after the current one on the calling
+    // thread -- meant for a second thread, beside the work on the current window, whose `data` / `recs` stay valid; the
+    // next fill() hands the prepared window out.  An error of that window is thrown here.
+    void prefetch(uint64_t window_bytes);
     std::string name(size_t i) const { return std::string(data + recs[i].off + (is_bam ? 36 : 0), recs[i].name_len); }
     // SEQ of records [b0, b1) as the matcher sees it (upper-case ASCII), concatenated (+1 pad byte)
     void gather(size_t b0, size_t b1, std::vector<uint8_t> &seq, std::vector<uint64_t> &off) const;
@@ -224,6 +228,11 @@ struct SamFile {
     const char *bytes() const { return src.mapped() ? src.text() : buf.data(); }
     uint64_t n_bytes() const { return src.mapped() ? src.text_size() : buf_len; }
     void drop_front(uint64_t k);
+    bool next_window(std::vector<char> &b, uint64_t &bl, uint64_t &cur, std::vector<Rec> &rs, uint64_t window_bytes);
+    std::vector<char> nbuf;  // the prefetched window
+    uint64_t nbuf_len = 0, ncursor = 0;
+    std::vector<Rec> nrecs;
+    bool have_next = false, next_more = false;
 };
 // BAM writer (BGZF): encodes SAM text lines against the header's @SQ dictionary.  Used for
 // `tag -o out.bam` (src/cmd_tag.rs:254-271); output is checked by reading it back.

@@ -1,9 +1,12 @@
 // test harness: reads a SAM / BAM file through the CLI's windowed reader (SamFile::open / fill,
 // merkurio_amd/csrc/cli/io.cpp) and prints the header, then one line per record: name, the sequence as
 // the matcher sees it, the value of an existing km tag, the record as SAM text.
-// usage: harness <file> <window bytes>
+// usage: harness <file> <window bytes> [prefetch]   (prefetch: the next window is read by SamFile::prefetch on a second thread
+//        while the current one is printed, as `merkurio tag` does)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <future>
 
 #include "io.hpp"
 using namespace cli;
@@ -14,8 +17,12 @@ int main(int argc, char **argv) {
         const uint64_t w = strtoull(argv[2], nullptr, 10);
         fputs(f.header.c_str(), stdout);
         size_t windows = 0, total = 0;
-        while (f.fill(w)) {
+        const bool ahead = argc > 3 && !strcmp(argv[3], "prefetch");
+        bool more = f.fill(w);
+        while (more) {
             ++windows;
+            std::future<void> next;
+            if (ahead) next = std::async(std::launch::async, [&] { f.prefetch(w); });
             std::vector<uint8_t> seq;
             std::vector<uint64_t> off;
             f.gather(0, f.recs.size(), seq, off);
@@ -27,6 +34,8 @@ int main(int argc, char **argv) {
                        line.c_str());
             }
             total += f.recs.size();
+            if (ahead) next.get();
+            more = f.fill(w);
         }
         printf("#windows %zu records %zu\n", windows, total);
     } catch (const Error &e) {

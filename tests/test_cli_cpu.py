@@ -277,12 +277,14 @@ def test_windowed_sam_bam_reader(tmp_path, golden):
     (tmp_path / "u.bam").write_bytes(raw)
     (tmp_path / "trunc.bam").write_bytes(bgzf(raw[:-7]))
 
-    def run_h(name, w):
-        return subprocess.run([exe, str(tmp_path / name), str(w)], capture_output=True, text=True).stdout
+    def run_h(name, w, *extra):
+        return subprocess.run([exe, str(tmp_path / name), str(w), *extra], capture_output=True, text=True).stdout
 
     ref = {}
     for name in ("x.sam", "b.bam", "g.bam", "u.bam"):
         outs = [run_h(name, w) for w in (1 << 16, 1 << 19, 1 << 30)]
+        # the next window prepared on a second thread beside the current one (SamFile::prefetch): the same windows
+        assert [run_h(name, w, "prefetch") for w in (1 << 16, 1 << 19)] == outs[:2], name
         bodies = [o.rsplit("#windows", 1)[0] for o in outs]
         assert bodies[0] == bodies[1] == bodies[2], name
         assert outs[0].rsplit("#windows", 1)[1].split()[2] == str(n) and int(outs[0].rsplit("#windows", 1)[1].split()[0]) > 3, name
@@ -294,6 +296,7 @@ def test_windowed_sam_bam_reader(tmp_path, golden):
     want = [f"read{i}\t{s.upper()}\t" + ("1:OLD,VAL" if i % 97 == 0 else "0:") for i, s in enumerate(seqs)]
     assert ref["x.sam"] == want and ref["b.bam"] == want and ref["g.bam"] == want and ref["u.bam"] == want
     assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16)
+    assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16, "prefetch")
 
 
 def test_log_rows_are_formatted_like_serde_json(tmp_path):
