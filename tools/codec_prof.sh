@@ -22,7 +22,6 @@ python3 - <<PY > $OUT/summary.txt
 import csv, glob, re
 from collections import defaultdict
 print("# tools/codec_prof.sh $MB: rocprofv3 --kernel-trace --stats of tools/codec_bench.py $MB 3 (two corpora x 3 deflate calls + 3 + 3 inflate calls), then PMC passes of one call each")
-print(open("$OUT/kt.log").read().split("/opt/amdgpu")[0])
 for ln in open("$OUT/kt.log"):
     if ln.startswith(("BAM", "  deflate", "  inflate")): print(ln.rstrip())
 print()
