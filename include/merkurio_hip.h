@@ -436,6 +436,20 @@ int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint
                            uint8_t *out, uint64_t out_cap, uint64_t *out_len);
 int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf_member *members, uint64_t n_members, uint8_t *out,
                     uint64_t out_cap, uint64_t *bad_member);
+/* mk_extract_fastq_text for a window of a bgzip'ed FASTQ: the members are uploaded as they are (a fifth of the text) and
+ * inflated on the device STRAIGHT INTO the text buffer the ingest kernels read -- the text is never uploaded.  The window's
+ * text = head[0, n_head) (the unfinished record the previous window ended with) followed by the members' text
+ * (members[i].out_off = running sum of ISIZE from 0); it is copied to text[0, *n_text) for the caller (record ids, kept
+ * records, the next head).  [0, *n_used) of it are whole 4-line records and are what is indexed and scanned, exactly as
+ * mk_extract_fastq_text does (same outputs, same *status = 1 for text that is not plain FASTQ: the caller's own reader then
+ * takes the window); the rest, text[*n_used, *n_text), is the next call's head.  last != 0: no text follows, a final line
+ * without a line end counts, an unfinished record is a refusal (*status = 1).  A damaged member: MK_E_CORRUPT.
+ * text_cap < n_head + sum of ISIZE: MK_E_CAPACITY.  The codec handle lends its device buffers and must be on the matcher's
+ * device.  (The reference gets these records from needletail's gzip reader, src/cmd_extract.rs:281-282,321-328.) */
+int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, uint64_t n_head, const uint8_t *bgzf, uint64_t n_bgzf,
+                          const mk_bgzf_member *members, uint64_t n_members, int last, uint8_t *text, uint64_t text_cap, uint64_t *n_text,
+                          uint64_t *n_used, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec, uint64_t *rec_start, uint8_t *keep,
+                          mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *pattern_hit_counts, uint32_t *status);
 /* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,
  * *consumed = bytes of whole members, *text_bytes = sum of ISIZE.  MK_E_CORRUPT where a header is not BGZF; a trailing
  * partial member is not an error (*consumed < n).  Host code, no device. */
@@ -443,6 +457,9 @@ int mk_bgzf_members(const uint8_t *in, uint64_t n, mk_bgzf_member *members, uint
                     uint64_t *text_bytes);
 /* the 28-byte empty member that ends a BGZF file */
 const uint8_t *mk_bgzf_eof(void);
+/* Tuning / test hook: a call is cut into device passes of at most `deflate_members` members (default 49 152 = 3.2 GB of
+ * text) / `inflate_text_bytes` of text (default 3 GiB); 0 keeps the default.  Results do not depend on it. */
+int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inflate_text_bytes);
 /* milliseconds of the handle's last call: [0] upload, [1] kernels, [2] download */
 int mk_codec_times(const mk_codec *c, float ms[3]);
 

@@ -11,25 +11,13 @@
 #include <vector>
 
 #include "../host_common.h"
+#include "codec_internal.h"
 #include "codec_kernels.h"
 
 namespace mk {
 int hip_fail(hipError_t e, const char *what);
 int ensure_device(void **p, size_t *cap, size_t need);
 }  // namespace mk
-
-struct mk_codec {
-    int device = 0, num_cus = 256;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::mutex mu;
-    // deflate: input chunk, per-block CRCs / sizes / offsets, token scratch, member slots, packed members
-    // inflate: compressed chunk (d_in), member table (d_aux), text (d_out), status words (d_len)
-    void *d_in = nullptr, *d_crc = nullptr, *d_tokens = nullptr, *d_slots = nullptr, *d_len = nullptr, *d_off = nullptr, *d_out = nullptr,
-         *d_aux = nullptr;
-    size_t in_cap = 0, crc_cap = 0, tokens_cap = 0, slots_cap = 0, len_cap = 0, off_cap = 0, out_cap = 0, aux_cap = 0;
-    float ms[3] = {0, 0, 0};
-};
 
 namespace {
 
@@ -100,6 +88,14 @@ uint64_t mk_bgzf_deflate_bound(uint64_t n, uint32_t block_bytes) {
 
 const uint8_t *mk_bgzf_eof(void) { return kEof; }
 
+int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inflate_text_bytes) {
+    if (!c) return mk::fail(MK_E_INVALID_ARG, "mk_codec_set_pass_limits: NULL handle");
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->deflate_pass_blocks = deflate_members;
+    c->inflate_pass_text = inflate_text_bytes;
+    return MK_OK;
+}
+
 int mk_codec_times(const mk_codec *c, float ms[3]) {
     if (!c || !ms) return mk::fail(MK_E_INVALID_ARG, "mk_codec_times: NULL argument");
     for (int k = 0; k < 3; ++k) ms[k] = c->ms[k];
@@ -127,7 +123,7 @@ int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint
     std::lock_guard<std::mutex> lock(c->mu);
     MKC_HIP(hipSetDevice(c->device), "hipSetDevice");
     c->ms[0] = c->ms[1] = c->ms[2] = 0;
-    const uint64_t chunk_bytes = kDeflateChunkBlocks * bb;
+    const uint64_t chunk_bytes = (c->deflate_pass_blocks ? c->deflate_pass_blocks : kDeflateChunkBlocks) * bb;
     uint64_t written = 0;
     uint64_t piece = 0, piece_at = 0;  // where the text of the next device pass starts
     for (uint64_t at = 0; at < n; at += chunk_bytes) {
@@ -231,7 +227,8 @@ int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf
     for (uint64_t m0 = 0; m0 < n_members;) {
         // a run of members whose compressed bytes and text are both contiguous enough to move in one piece each
         uint64_t m1 = m0, text = 0, in_lo = members[m0].data_off, in_hi = in_lo, out_lo = members[m0].out_off, out_hi = out_lo;
-        while (m1 < n_members && (m1 == m0 || text + members[m1].isize <= kInflateChunkText)) {
+        const uint64_t pass_text = c->inflate_pass_text ? c->inflate_pass_text : kInflateChunkText;
+        while (m1 < n_members && (m1 == m0 || text + members[m1].isize <= pass_text)) {
             const mk_bgzf_member &m = members[m1];
             in_lo = std::min(in_lo, m.data_off), in_hi = std::max(in_hi, m.data_off + m.data_len);
             out_lo = std::min(out_lo, m.out_off), out_hi = std::max(out_hi, m.out_off + m.isize);

@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "matcher_internal.h"
+#include "codec/codec_internal.h"
+#include "codec/codec_kernels.h"
 
 using namespace mk;
 
@@ -341,53 +343,21 @@ int mk_upload_text_ahead(mk_matcher *m, const uint8_t *text, uint64_t n_text) {
     MK_ABI_END
 }
 
-int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out,
-                          uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts,
-                          uint32_t *status) {
-    if (!m || !n_rec_out || !status || !c || (logging && !counts) || (n_text && !text)) return fail(MK_E_INVALID_ARG, "null argument");
-    *n_rec_out = 0;
-    *status = 0;
-    if (n_rows) *n_rows = 0;
-    if (n_text == 0) return MK_OK;
-    if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
-    MK_ABI_BEGIN
-    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
-    DeviceLoop dl(m);
+// The window's text is in m->d_text[0, n_text) (uploaded, or inflated there): index, gather, scan, order, rows, counts,
+// record table -- everything of mk_extract_fastq_text behind the upload.  last_byte = text[n_text - 1].
+static int extract_text_resident(mk_matcher *m, DeviceLoop &dl, uint64_t n_text, uint8_t last_byte, int logging, int invert, uint64_t rec_cap,
+                                 uint64_t *n_rec_out, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
+                                 mk_counters *c, uint32_t *counts, uint32_t *status) {
     hipStream_t st = dl.st;
     int rc;
-    // the text, and the (upper-bounded) scan buffer it is gathered into.  A window that mk_upload_text_ahead has
-    // already sent (same pointer, same size) is taken from its buffer: the copy ran beside the previous window's work
-    bool ahead = false;
-    {
-        std::lock_guard<std::mutex> lk(m->ahead_mu);
-        for (auto &a : m->ahead) {
-            if (!a.text) continue;
-            if (a.text == text && a.n == n_text && !ahead) {
-                std::swap(m->d_text, a.d);
-                std::swap(m->d_text_cap, a.cap);
-                if (hipStreamWaitEvent(st, a.ev, 0) != hipSuccess) return fail(MK_E_HIP, "hipStreamWaitEvent failed");
-                ahead = true;
-            }
-            // (a slot that holds any other window is stale -- the host did not come back for it: its copy, if still
-            // running, reads page-locked memory the host may be refilling, so let it finish before the slot is reused)
-            else if (hipEventSynchronize(a.ev) != hipSuccess)
-                return fail(MK_E_HIP, "hipEventSynchronize failed");
-            a.text = nullptr;
-        }
-    }
-    if (!ahead && (rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
-    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
     const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
     if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
     uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;  // | total | status, min, max
-    if (!ahead && hipMemcpyAsync(m->d_text, text, n_text, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
-    dl.mark(1);
     launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);
     uint32_t total_nl = 0;
     if (hipMemcpyAsync(&total_nl, d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return fail(MK_E_HIP, "newline count failed");
-    const uint64_t n_lines = (uint64_t)total_nl + (text[n_text - 1] != '\n' ? 1 : 0);
+    const uint64_t n_lines = (uint64_t)total_nl + (last_byte != '\n' ? 1 : 0);
     if (n_lines % 4 != 0) {  // not whole 4-line records: the caller's reader decides what this text is
         *status = 1;
         return MK_OK;
@@ -460,6 +430,153 @@ int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, i
     if (n_rows) *n_rows = dl.found;
     if (logging && rows && dl.found > rows_cap) return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)dl.found);
     return MK_OK;
+}
+int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out,
+                          uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts,
+                          uint32_t *status) {
+    if (!m || !n_rec_out || !status || !c || (logging && !counts) || (n_text && !text)) return fail(MK_E_INVALID_ARG, "null argument");
+    *n_rec_out = 0;
+    *status = 0;
+    if (n_rows) *n_rows = 0;
+    if (n_text == 0) return MK_OK;
+    if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
+    MK_ABI_BEGIN
+    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
+    DeviceLoop dl(m);
+    hipStream_t st = dl.st;
+    int rc;
+    // the text, and the (upper-bounded) scan buffer it is gathered into.  A window that mk_upload_text_ahead has
+    // already sent (same pointer, same size) is taken from its buffer: the copy ran beside the previous window's work
+    bool ahead = false;
+    {
+        std::lock_guard<std::mutex> lk(m->ahead_mu);
+        for (auto &a : m->ahead) {
+            if (!a.text) continue;
+            if (a.text == text && a.n == n_text && !ahead) {
+                std::swap(m->d_text, a.d);
+                std::swap(m->d_text_cap, a.cap);
+                if (hipStreamWaitEvent(st, a.ev, 0) != hipSuccess) return fail(MK_E_HIP, "hipStreamWaitEvent failed");
+                ahead = true;
+            }
+            // (a slot that holds any other window is stale -- the host did not come back for it: its copy, if still
+            // running, reads page-locked memory the host may be refilling, so let it finish before the slot is reused)
+            else if (hipEventSynchronize(a.ev) != hipSuccess)
+                return fail(MK_E_HIP, "hipEventSynchronize failed");
+            a.text = nullptr;
+        }
+    }
+    if (!ahead && (rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
+    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
+    if (!ahead && hipMemcpyAsync(m->d_text, text, n_text, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
+    dl.mark(1);
+    return extract_text_resident(m, dl, n_text, text[n_text - 1], logging, invert, rec_cap, n_rec_out, rec_start, keep, rows, rows_cap, n_rows, c, counts,
+                                 status);
+    MK_ABI_END
+}
+
+int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, uint64_t n_head, const uint8_t *bgzf, uint64_t n_bgzf,
+                          const mk_bgzf_member *members, uint64_t n_members, int last, uint8_t *text, uint64_t text_cap, uint64_t *n_text_out,
+                          uint64_t *n_used_out, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out, uint64_t *rec_start, uint8_t *keep,
+                          mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts, uint32_t *status) {
+    if (!m || !codec || !n_text_out || !n_used_out || !n_rec_out || !status || !c || (logging && !counts) || (n_head && !head) ||
+        (n_members && (!bgzf || !members)))
+        return fail(MK_E_INVALID_ARG, "null argument");
+    *n_text_out = *n_used_out = *n_rec_out = 0;
+    *status = 0;
+    if (n_rows) *n_rows = 0;
+    uint64_t n_text = n_head;
+    for (uint64_t i = 0; i < n_members; ++i) {
+        const mk_bgzf_member &b = members[i];
+        if (b.data_off > n_bgzf || b.data_len > n_bgzf - b.data_off || b.isize > 65536 || b.out_off != n_text - n_head)
+            return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: member %llu lies outside its buffer or its text is not in sequence", (unsigned long long)i);
+        n_text += b.isize;
+    }
+    *n_text_out = n_text;
+    if (n_text == 0) return MK_OK;
+    if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
+    if (!text || text_cap < n_text) return fail(MK_E_CAPACITY, "mk_extract_fastq_bgzf: the window's text takes %llu bytes", (unsigned long long)n_text);
+    MK_ABI_BEGIN
+    if (codec->device != m->device) return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: the codec and the matcher are on different devices");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
+    DeviceLoop dl(m);
+    hipStream_t st = dl.st;
+    int rc;
+    if ((rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
+    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
+    uint32_t total_nl = 0;
+    {
+        // the members' bytes and their table go up (a fifth of the text), the text is inflated behind the head in place
+        std::lock_guard<std::mutex> lock(codec->mu);
+        uint64_t in_lo = n_members ? members[0].data_off : 0, in_hi = in_lo;
+        std::vector<mkz::Member> part(n_members);
+        for (uint64_t i = 0; i < n_members; ++i) {
+            in_lo = std::min<uint64_t>(in_lo, members[i].data_off);
+            in_hi = std::max<uint64_t>(in_hi, members[i].data_off + members[i].data_len);
+        }
+        for (uint64_t i = 0; i < n_members; ++i)
+            part[i] = mkz::Member{members[i].data_off - in_lo, n_head + members[i].out_off, members[i].data_len, members[i].isize, members[i].crc, 0};
+        const uint64_t cn = in_hi - in_lo;
+        if ((rc = ensure_device(&codec->d_in, &codec->in_cap, cn + mkz::kPad)) ||
+            (rc = ensure_device(&codec->d_aux, &codec->aux_cap, (n_members + 1) * sizeof(mkz::Member))) ||
+            (rc = ensure_device(&codec->d_len, &codec->len_cap, (n_members + 1) * 4ull)))
+            return rc;
+        if (n_head && hipMemcpyAsync(m->d_text, head, n_head, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the head failed");
+        if (n_members) {
+            if (hipMemcpyAsync(codec->d_in, bgzf + in_lo, cn, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemsetAsync((uint8_t *)codec->d_in + cn, 0, mkz::kPad, st) != hipSuccess ||
+                hipMemcpyAsync(codec->d_aux, part.data(), n_members * sizeof(mkz::Member), hipMemcpyHostToDevice, st) != hipSuccess)
+                return fail(MK_E_HIP, "upload of the members failed");
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the members failed");
+            dl.mark(1);
+            mkz::launch_inflate((const uint8_t *)codec->d_in, cn, (const mkz::Member *)codec->d_aux, (uint32_t)n_members, (uint8_t *)m->d_text,
+                                (int32_t *)codec->d_len, codec->num_cus, st);
+            mkz::launch_crc_check((const uint8_t *)m->d_text, (const mkz::Member *)codec->d_aux, (uint32_t)n_members, (int32_t *)codec->d_len, st);
+            std::vector<int32_t> st_words(n_members);
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(st_words.data(), codec->d_len, n_members * 4ull, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return fail(MK_E_HIP, "BGZF inflate failed");
+            for (uint64_t i = 0; i < n_members; ++i)
+                if (st_words[i])
+                    return fail(MK_E_CORRUPT, st_words[i] > 0 ? "BGZF member %llu: CRC-32 of the inflated text differs from the trailer's (status %d)"
+                                                               : "BGZF member %llu does not inflate to its ISIZE (decoder status %d)",
+                                (unsigned long long)i, st_words[i]);
+        } else if (hipStreamSynchronize(st) != hipSuccess) {
+            return fail(MK_E_HIP, "upload of the head failed");
+        }
+    }
+    // the text goes to the host as well: record ids, kept records and the unfinished record at its end are read there
+    const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
+    if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
+    uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;
+    launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);
+    if (hipMemcpyAsync(&total_nl, d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(text, m->d_text, n_text, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "download of the text failed");
+    dl.mark(1);
+    // whole records only: the window starts at a record start, a record is four lines
+    uint64_t n_used = n_text;
+    if (last) {
+        const uint64_t lines = (uint64_t)total_nl + (text[n_text - 1] != '\n' ? 1 : 0);
+        if (lines % 4 != 0) {  // an unfinished record at the end of the input: the caller's reader words that error
+            *status = 1;
+            return MK_OK;
+        }
+    } else {
+        while (n_used > 0 && text[n_used - 1] != '\n') --n_used;  // the unfinished last line
+        for (uint32_t drop = total_nl % 4; drop > 0 && n_used > 0; --drop) {
+            --n_used;
+            while (n_used > 0 && text[n_used - 1] != '\n') --n_used;
+        }
+    }
+    *n_used_out = n_used;
+    if (n_used == 0) {  // not one whole record in the window
+        *status = last ? 0u : 1u;
+        return MK_OK;
+    }
+    return extract_text_resident(m, dl, n_used, text[n_used - 1], logging, invert, rec_cap, n_rec_out, rec_start, keep, rows, rows_cap, n_rows, c, counts,
+                                 status);
     MK_ABI_END
 }
 

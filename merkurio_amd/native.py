@@ -53,7 +53,7 @@ EXPORTS = [
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
-    "mk_codec_times",
+    "mk_codec_times", "mk_codec_set_pass_limits", "mk_extract_fastq_bgzf",
 ]
 
 
@@ -205,6 +205,11 @@ def load(build_if_missing=True):
                                   C.POINTER(C.c_uint64)]
     L.mk_bgzf_eof.restype = C.POINTER(C.c_uint8 * 28)
     L.mk_codec_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.mk_codec_set_pass_limits.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.mk_extract_fastq_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+                                        C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_uint64,
+                                        C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                        C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(Counters), C.c_void_p]
@@ -517,6 +522,38 @@ class Matcher:
         out_rows = [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else []
         return status.value, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows, cnt.as_dict(counts)
 
+    def extract_fastq_bgzf(self, codec, head: bytes, blob: bytes, members, last, logging=True, invert=False):
+        """mk_extract_fastq_bgzf: head + the text of `members` (entries of bgzf_members(blob), out_off re-based to 0) ->
+        (status, text, n_used, rec_start, keep, rows, counters); the members are inflated into the ingest buffer on the device"""
+        mem = members.copy()
+        if len(mem):
+            mem["out_off"] -= mem["out_off"][0]
+        n_text = len(head) + int(mem["isize"].sum()) if len(mem) else len(head)
+        hb, bb = np.frombuffer(head, dtype=np.uint8), np.frombuffer(blob, dtype=np.uint8)
+        text = np.zeros(max(1, n_text), dtype=np.uint8)
+        cap = max(1, n_text // 8 + 2)
+        n_rec, status, nt, nu = C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        rec_start = np.zeros(cap + 1, dtype=np.uint64)
+        keep = np.zeros(cap, dtype=np.uint8)
+        rows = np.zeros(4096, dtype=ROW_DTYPE)
+        n_rows = C.c_uint64()
+        while True:
+            c2, k2 = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+            rc = load().mk_extract_fastq_bgzf(self._h, codec._h, hb.ctypes.data if len(hb) else None, len(hb), bb.ctypes.data if len(bb) else None,
+                                              len(bb), mem.ctypes.data if len(mem) else None, len(mem), int(bool(last)), text.ctypes.data, n_text,
+                                              C.byref(nt), C.byref(nu), int(logging), int(invert), cap, C.byref(n_rec), rec_start.ctypes.data,
+                                              keep.ctypes.data, rows.ctypes.data, len(rows), C.byref(n_rows), C.byref(c2), k2.ctypes.data,
+                                              C.byref(status))
+            if rc == MK_E_CAPACITY and n_rows.value > len(rows):
+                rows = np.zeros(n_rows.value, dtype=ROW_DTYPE)
+                continue
+            _check(rc)
+            break
+        n = n_rec.value
+        out_rows = [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else []
+        return (status.value, text[:nt.value].tobytes(), nu.value, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows,
+                c2.as_dict(k2))
+
     def extract_paired(self, seqs1, seqs2, logging=True, invert=False):
         d1, o1 = pack_records(seqs1)
         d2, o2 = pack_records(seqs2)
@@ -690,6 +727,9 @@ class Codec:
         _check(self._L.mk_bgzf_inflate(self._h, src.ctypes.data if src.size else None, src.size, members.ctypes.data if members.size else None,
                                        members.size, out.ctypes.data if out.size else None, out.size, C.byref(bad)))
         return out.tobytes()
+
+    def set_pass_limits(self, deflate_members=0, inflate_text_bytes=0):
+        _check(self._L.mk_codec_set_pass_limits(self._h, deflate_members, inflate_text_bytes))
 
     def times(self):
         ms = (C.c_float * 3)()

@@ -66,10 +66,18 @@ def test_deflate_sizes_around_a_block_and_a_device_pass(codec):
     for n in (1, 2, 3, 4, 5, 63, 64, 65, 65279, 65280, 65281, 2 * 65280, 2 * 65280 + 1):
         data = (base * (n // len(base) + 1))[:n]
         check_members(data, codec.deflate(data), 0)
-    # more members than one device pass takes (4096): 5 000 blocks of 4 KiB
+    # calls cut into several device passes (the pass limits are a tuning hook: results must not depend on them)
     data = bam_like(72000, seed=9)[:5000 * 4096 - 77]
-    blob = codec.deflate(data, 4096)
-    check_members(data, blob, 4096)
+    whole = codec.deflate(data, 4096)
+    check_members(data, whole, 4096)
+    try:
+        codec.set_pass_limits(deflate_members=777, inflate_text_bytes=1_000_000)
+        assert codec.deflate(data, 4096) == whole                      # 7 passes of 777 members
+        assert codec.deflate_pieces([data[:12345], data[12345:9_000_001], data[9_000_001:]], 4096) == whole  # pieces across passes
+        assert codec.inflate(whole) == data                            # 21 passes of ~1 MB of text
+        assert codec.inflate(zlib_bgzf(data[:3_000_000], level=6)) == data[:3_000_000]
+    finally:
+        codec.set_pass_limits()
     # text that cannot shrink is stored
     noise = bytes(rng.getrandbits(8) for _ in range(150000))
     blob = codec.deflate(noise)
