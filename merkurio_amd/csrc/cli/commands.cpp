@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <future>
+#include <memory>
 
 #include <algorithm>
 #include <cstring>
@@ -341,6 +342,17 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     // window is copied into page-locked memory, uploaded and indexed on the device (mk_extract_fastq_text); the
     // host reader below stays the fallback for everything the device refuses (and its byte-identical checker).
     const bool device_ingest = !paired && devs.size() == 1 && !a.host_ingest;
+    // ... and a bgzip'ed FASTQ is not even inflated here: its members go up as they are (mk_extract_fastq_bgzf)
+    bool bgzf_device = false;
+    struct RawBuffer {  // that path's window text: uninitialised memory (no fill pass), first touched while the HIP runtime starts
+        std::unique_ptr<char[]> p;
+        uint64_t cap = 0;
+        void need(uint64_t n) {
+            if (n <= cap) return;
+            p.reset(new char[n]);
+            cap = n;
+        }
+    } bgzf_text;
     const char *raw_text = nullptr;
     uint64_t raw_n = 0, raw_resume = 0;
     bool raw_more = false, raw_refused = false;
@@ -353,8 +365,30 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         if (paired) s2.open(*a.in_fastq_2);
         // (the first window is small and goes up from where it lies: page-locked buffers need the HIP runtime, which
         // is still starting on the matcher thread; the staging of window 2 then overlaps window 1)
-        if (device_ingest) raw_more = s1.raw_fill(std::min<uint64_t>(raw_window, 32ull << 20), &raw_text, &raw_n, &raw_resume);
-        if (!raw_more) more1 = s1.fill(window_bytes);
+        bgzf_device = device_ingest && !a.host_codec && s1.raw_is_bgzf();
+        if (device_ingest && !bgzf_device) raw_more = s1.raw_fill(std::min<uint64_t>(raw_window, 32ull << 20), &raw_text, &raw_n, &raw_resume);
+        if (!raw_more && !bgzf_device) more1 = s1.fill(window_bytes);
+        if (bgzf_device) {
+            // nothing to inflate or parse here; the window's text will come back from the device into this buffer: a copy
+            // into memory that was never touched takes a page fault per 4 KiB (0.15 s per GiB) -- take them now, on all
+            // host threads, while the matcher thread waits for the HIP runtime
+            const WindowSource &ws = s1.source();
+            uint64_t first = 0;
+            const uint64_t target = std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
+            for (size_t i = 0; i < ws.n_bgzf_members() && first < target; ++i) {
+                uint64_t off;
+                uint32_t len, isize, crc;
+                ws.bgzf_member_at(i, &off, &len, &isize, &crc);
+                first += isize;
+            }
+            bgzf_text.need(first + (1u << 20));
+            char *p = bgzf_text.p.get();
+            const uint64_t cap = bgzf_text.cap;
+            const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (size_t)(cap >> 24) + 1));
+            run_threads(T, [&](size_t t) {
+                for (uint64_t q = cap * t / T; q < cap * (t + 1) / T; q += 4096) p[q] = 0;
+            });
+        }
         if (paired) more2 = s2.fill(window_bytes);
     } catch (...) {
         fm.get();  // a matcher error comes first, as in the serial order of the reference
@@ -487,6 +521,144 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             cur ^= 1;
         }
     };
+    // what a device-indexed window leaves to the host: counters, log rows, the kept records written from the window's text
+    std::vector<uint64_t> rec_start;
+    std::vector<uint8_t> keep;
+    std::vector<mk_row> rows(4096);
+    auto accept_window = [&](const char *text, uint64_t n_text, uint64_t n_rec, uint64_t n_rows, const mk_counters &cb,
+                             const std::vector<uint32_t> &cnt_b) {
+        c.nb_records_tot += cb.nb_records_tot; c.nb_bases += cb.nb_bases;
+        c.nb_hits_tot[0] += cb.nb_hits_tot[0]; c.nb_records_hit[0] += cb.nb_records_hit[0];
+        c.nb_records_extracted += cb.nb_records_extracted;
+        for (size_t k = 0; k < counts.size(); ++k) counts[k] += cnt_b[k];
+        tm.mark("window: H2D + index + scan + D2H");
+        // id of a record: its header line without '@' and line end
+        auto id_of = [&](uint64_t r) {
+            const uint64_t b = rec_start[r] + 1;
+            const char *nl = (const char *)memchr(text + b, '\n', (size_t)(rec_start[r + 1] - b));
+            uint64_t e = nl ? (uint64_t)(nl - text) : rec_start[r + 1];
+            if (e > b && text[e - 1] == '\r') --e;
+            return std::pair<const char *, size_t>(text + b, (size_t)(e - b));
+        };
+        emit_log_rows(lg, pats, rows.data(), lg.active ? n_rows : 0, [&](const mk_row &r) { return id_of(r.rec); },
+                      [&](const mk_row &) -> const std::string & { return name1; });
+        if (!a.suppress_output) {
+            // kept records are written by the host reader's own code from the record's four lines
+            FastxFile one;
+            one.fastq = true;
+            one.data = text;
+            one.data_n = n_text;
+            for (uint64_t k = 0; k < n_rec; ++k)
+                if (keep[k]) {
+                    one.recs.clear();
+                    one.parse_span(rec_start[k], rec_start[k + 1]);
+                    // record.write(_, None) re-emits the four lines with a bare '+': a record that is
+                    // stored that way already (and ends in its line end) is written as one piece
+                    const FastxFile::Rec &r = one.recs[0];
+                    const uint64_t b = rec_start[k], e = rec_start[k + 1];
+                    const bool crlf = r.id_e < n_text && text[r.id_e] == '\r';
+                    const uint64_t nl = crlf ? 2 : 1;
+                    if (r.qual_b == r.raw_e + 2 * nl + 1 && r.qual_e + nl == e && text[e - 1] == '\n')
+                        w1.write(text + b, (size_t)(e - b));
+                    else
+                        one.write(0, w1);
+                }
+        }
+        tm.mark("window: rows + records out");
+    };
+    // ---- bgzip'ed FASTQ on one GPU: windows of members -> mk_extract_fastq_bgzf (inflated on the device straight into the
+    // ingest buffer; the text comes back for the record ids and the kept records) -> rows + kept records.  The unfinished
+    // record a window ends with is the next window's head.  A window the device refuses (not plain 4-line FASTQ) sends the
+    // host reader to the place in the member chain where that window's text began; it carries on from there.
+    if (bgzf_device) {
+        const WindowSource &ws = s1.source();
+        mk_codec *codec = nullptr;
+        mk_check(mk_codec_create(devs[0], &codec), "Error setting up the BGZF codec");
+        struct CodecGuard {  // (at the end of the process its gigabytes of device buffers are not freed one by one: 0.07 s)
+            mk_codec *c;
+            ~CodecGuard() {
+                if (!g_process_is_ending) mk_codec_destroy(c);
+            }
+        } guard{codec};
+        RawBuffer &textbuf = bgzf_text;
+        std::vector<char> head;
+        std::vector<mk_bgzf_member> grp;
+        const size_t nm = ws.n_bgzf_members();
+        size_t next = 0, head_member = 0;  // next member to take; the member the head's first byte lies in ...
+        uint64_t head_skip = 0;            // ... and how far into its text
+        // (a launch of the inflate kernel lasts as long as its slowest member whatever it holds: few, large windows)
+        const uint64_t target = std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
+        bool refused = false;
+        while (next < nm || !head.empty()) {
+            grp.clear();
+            uint64_t members_text = 0;
+            size_t g1 = next;
+            while (g1 < nm && (members_text < target || g1 == next)) {
+                mk_bgzf_member e{};
+                ws.bgzf_member_at(g1, &e.data_off, &e.data_len, &e.isize, &e.crc);
+                e.out_off = members_text;
+                members_text += e.isize;
+                grp.push_back(e);
+                ++g1;
+            }
+            const bool last = g1 >= nm;
+            const uint64_t cap_text = head.size() + members_text;
+            textbuf.need(cap_text + 16);
+            uint64_t n_rec = 0, n_rows = 0, n_text = 0, n_used = 0;
+            uint32_t status = 0;
+            mk_counters cb;
+            std::vector<uint32_t> cnt_b(counts.size(), 0);
+            uint64_t rec_cap = std::max<uint64_t>(rec_start.size() ? rec_start.size() - 1 : 0, cap_text / 64 + 16);
+            for (;;) {
+                if (rec_start.size() < rec_cap + 1) rec_start.resize(rec_cap + 1);
+                if (keep.size() < rec_cap) keep.resize(rec_cap);
+                memset(&cb, 0, sizeof(cb));
+                std::fill(cnt_b.begin(), cnt_b.end(), 0);
+                const int rc = mk_extract_fastq_bgzf(m, codec, (const uint8_t *)head.data(), head.size(), ws.file_bytes(), ws.file_size(), grp.data(),
+                                                     grp.size(), last, (uint8_t *)textbuf.p.get(), textbuf.cap, &n_text, &n_used, lg.active,
+                                                     a.invert_match, rec_cap, &n_rec, rec_start.data(), keep.data(), rows.data(), rows.size(), &n_rows,
+                                                     &cb, cnt_b.data(), &status);
+                if (rc == MK_E_CAPACITY && n_rec > rec_cap) {
+                    rec_cap = n_rec;
+                    continue;
+                }
+                if (rc == MK_E_CAPACITY && n_rows > rows.size()) {
+                    rows.resize(n_rows);
+                    continue;
+                }
+                if (rc == MK_E_CORRUPT) bail("Error while decompressing " + a.in_fastx);
+                mk_check(rc, "Error during matching");
+                break;
+            }
+            if (status != 0) {
+                refused = true;
+                break;
+            }
+            accept_window(textbuf.p.get(), n_used, n_rec, n_rows, cb, cnt_b);
+            // the next head: text[n_used, n_text), and where it lies in the member chain
+            if (n_used >= n_text) {
+                head_member = g1, head_skip = 0;
+            } else if (n_used < head.size()) {
+                head_skip += n_used;
+            } else {
+                const uint64_t x = n_used - head.size();  // offset in the members' text
+                size_t lo = 0, hi = grp.size();           // the last member whose text starts at or before x
+                while (hi - lo > 1) {
+                    const size_t mid = (lo + hi) / 2;
+                    if (grp[mid].out_off <= x) lo = mid;
+                    else hi = mid;
+                }
+                head_member = next + lo, head_skip = x - grp[lo].out_off;
+            }
+            head.assign(textbuf.p.get() + n_used, textbuf.p.get() + n_text);
+            next = g1;
+            if (last) break;  // (whole records to the end: an unfinished one was a refusal)
+        }
+        if (refused) {
+            s1.seek_bgzf(head_member, head_skip);
+            more1 = s1.fill(window_bytes);
+        }
+    }
     // ---- device ingest loop: raw text windows -> mk_extract_fastq_text -> rows + kept records --------------------
     if (raw_more) {
         struct Pinned {  // (not released at the end of the run: unpinning 2 x 150 MB costs more than the process has left to live)
@@ -519,9 +691,6 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                 if (done < hi) memcpy((char *)dst.p + done, src + done, (size_t)(hi - done));  // (no descriptor, or a short read)
             });
         };
-        std::vector<uint64_t> rec_start;
-        std::vector<uint8_t> keep;
-        std::vector<mk_row> rows(4096);
         int cur = 0;
         bool first = true;
         while (raw_more) {
@@ -571,44 +740,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                 if (status != 0) {
                     fell_back = true;  // not plain 4-line FASTQ: the host reader takes over from this window on
                 } else {
-                    c.nb_records_tot += cb.nb_records_tot; c.nb_bases += cb.nb_bases;
-                    c.nb_hits_tot[0] += cb.nb_hits_tot[0]; c.nb_records_hit[0] += cb.nb_records_hit[0];
-                    c.nb_records_extracted += cb.nb_records_extracted;
-                    for (size_t k = 0; k < counts.size(); ++k) counts[k] += cnt_b[k];
-                    tm.mark("window: H2D + index + scan + D2H");
-                    // id of a record: its header line without '@' and line end
-                    auto id_of = [&](uint64_t r) {
-                        const uint64_t b = rec_start[r] + 1;
-                        const char *nl = (const char *)memchr(text + b, '\n', (size_t)(rec_start[r + 1] - b));
-                        uint64_t e = nl ? (uint64_t)(nl - text) : rec_start[r + 1];
-                        if (e > b && text[e - 1] == '\r') --e;
-                        return std::pair<const char *, size_t>(text + b, (size_t)(e - b));
-                    };
-                    emit_log_rows(lg, pats, rows.data(), lg.active ? n_rows : 0, [&](const mk_row &r) { return id_of(r.rec); },
-                                  [&](const mk_row &) -> const std::string & { return name1; });
-                    if (!a.suppress_output) {
-                        // kept records are written by the host reader's own code from the record's four lines
-                        FastxFile one;
-                        one.fastq = true;
-                        one.data = text;
-                        one.data_n = n_text;
-                        for (uint64_t k = 0; k < n_rec; ++k)
-                            if (keep[k]) {
-                                one.recs.clear();
-                                one.parse_span(rec_start[k], rec_start[k + 1]);
-                                // record.write(_, None) re-emits the four lines with a bare '+': a record that is
-                                // stored that way already (and ends in its line end) is written as one piece
-                                const FastxFile::Rec &r = one.recs[0];
-                                const uint64_t b = rec_start[k], e = rec_start[k + 1];
-                                const bool crlf = r.id_e < n_text && text[r.id_e] == '\r';
-                                const uint64_t nl = crlf ? 2 : 1;
-                                if (r.qual_b == r.raw_e + 2 * nl + 1 && r.qual_e + nl == e && text[e - 1] == '\n')
-                                    w1.write(text + b, (size_t)(e - b));
-                                else
-                                    one.write(0, w1);
-                            }
-                    }
-                    tm.mark("window: rows + records out");
+                    accept_window(text, n_text, n_rec, n_rows, cb, cnt_b);
                 }
             } catch (...) {
                 next.wait();

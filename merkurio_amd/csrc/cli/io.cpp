@@ -720,6 +720,15 @@ bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n
 
 void FastxStream::raw_consume() { cursor = raw_next; }
 
+void FastxStream::seek_bgzf(size_t member, uint64_t skip) {
+    src.seek_member(member);
+    have_spare = false;
+    lens[0] = lens[1] = 0;
+    cur = 0;
+    while (lens[cur] <= skip && !src.exhausted()) src.more_into(bufs[cur], lens[cur], skip + (1u << 16) - lens[cur]);
+    cursor = std::min<uint64_t>(skip, lens[cur]);  // (fill() starts with the unconsumed tail of the current buffer)
+}
+
 void FastxStream::consume(size_t n) { cursor = n < view.recs.size() ? view.recs[n].id_b - 1 : cur_end; }
 
 // ---- SAM / BAM ------------------------------------------------------------------------------------

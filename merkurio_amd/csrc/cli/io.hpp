@@ -115,6 +115,19 @@ struct WindowSource {
     bool more_into(std::vector<char> &dst, uint64_t &len, uint64_t want);
     bool exhausted() const { return kind == PLAIN || src_eof; }
     const std::string &name() const { return path; }
+    // BGZF: the file as stored and its member table, for a caller that inflates on the device (extract's
+    // mk_extract_fastq_bgzf path); seek_member() makes member i the next one more_into() inflates
+    bool is_bgzf() const { return kind == BGZF; }
+    const uint8_t *file_bytes() const { return (const uint8_t *)src.p; }
+    uint64_t file_size() const { return src.n; }
+    size_t n_bgzf_members() const { return members.size(); }
+    void bgzf_member_at(size_t i, uint64_t *data_off, uint32_t *data_len, uint32_t *isize, uint32_t *crc) const {
+        *data_off = members[i].data_off, *data_len = (uint32_t)members[i].data_len, *isize = members[i].isize, *crc = members[i].crc;
+    }
+    void seek_member(size_t i) {
+        src_pos = i;
+        src_eof = i >= members.size();
+    }
     ~WindowSource();
     WindowSource() = default;
     WindowSource(const WindowSource &) = delete;
@@ -162,6 +175,11 @@ struct FastxStream {
     // the raw windows are slices of a plain (memory-mapped) file: window = file[resume - n, resume)
     bool raw_is_plain() const { return src.mapped() && src.is_file_mapping(); }
     void resume_at(uint64_t resume);
+    // bgzip'ed input whose first windows were inflated and indexed on the device (the caller walked source()'s members
+    // itself): the host reader takes over at the text that starts `skip` bytes into member `member`; then fill().
+    bool raw_is_bgzf() const { return src.is_bgzf(); }
+    const WindowSource &source() const { return src; }
+    void seek_bgzf(size_t member, uint64_t skip);
 
    private:
     WindowSource src;

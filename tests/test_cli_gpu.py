@@ -482,7 +482,13 @@ def test_device_ingest_equals_host_ingest(tmp_path):
     for name, text in files.items():
         (tmp_path / name).write_bytes(text.encode())
     (tmp_path / "plain.fastq.gz").write_bytes(gzip.compress(files["plain.fastq"].encode(), 1))
-    for name in list(files) + ["plain.fastq.gz"]:
+    # bgzip'ed (r04): the default path does not inflate these on the host at all -- windows of members go to
+    # mk_extract_fastq_bgzf, the unfinished record of a window is the next one's head (members of 20 000 bytes: every window
+    # ends inside a record); the blank line sends the host reader to the place in the member chain where its window began
+    bz = {n[:-6] + ".bgzf.fastq.gz": n for n in files}  # (the output's extension is derived from the input's name)
+    for name, src in bz.items():
+        (tmp_path / name).write_bytes(_bgzf(files[src].encode(), 20000))
+    for name in list(files) + ["plain.fastq.gz"] + list(bz):
         res = {}
         for mode in ("device", "host"):
             d = tmp_path / f"{name}.{mode}"
@@ -490,9 +496,14 @@ def test_device_ingest_equals_host_ingest(tmp_path):
             extra = ["--host-ingest"] if mode == "host" else []
             run(["extract", "-i", str(tmp_path / name), "-f", str(tmp_path / "k.txt"), "-o", str(d / "out"), "-l", str(d / "log.txt"), "-j",
                  str(d / "log.json"), "--window-mb", "1"] + extra)
-            res[mode] = (open(d / "out.fastq", "rb").read(), log_body(d / "log.txt"), json_stable(d / "log.json")[:2])
+            body = log_body(d / "log.txt").replace(name.encode() + b"\t", b"<file>\t")
+            res[mode] = (open(d / "out.fastq", "rb").read(), body, json_stable(d / "log.json")[:2])
         assert res["device"] == res["host"], name
         assert res["device"][0].count(b"\n@r") > 500
+        if name in bz:  # ... and the same records and rows as the plain file
+            plain_out = tmp_path / f"{bz[name]}.device"
+            assert res["device"][0] == open(plain_out / "out.fastq", "rb").read(), name
+            assert res["device"][1] == log_body(plain_out / "log.txt").replace(bz[name].encode() + b"\t", b"<file>\t"), name
     # a malformed record in the third window: both paths write the records before it and end with the reference's message
     bad = "".join(plain[:5000]) + "@broken\nACGT\n+\nII\n" + "".join(plain[5000:])
     (tmp_path / "bad.fastq").write_text(bad)
@@ -502,3 +513,15 @@ def test_device_ingest_equals_host_ingest(tmp_path):
         assert p.returncode != 0 and b"Error during FASTQ/A record parsing." in p.stderr
         outs.append(p.stdout)
     assert outs[0] == outs[1] and outs[0].count(b"\n@r") > 300
+    (tmp_path / "bad.bgzf.fastq.gz").write_bytes(_bgzf(bad.encode(), 20000))
+    p = run(["extract", "-i", str(tmp_path / "bad.bgzf.fastq.gz"), "-f", str(tmp_path / "k.txt"), "--window-mb", "1"], check=False)
+    # (its windows are cut at member boundaries: the records written before the failing window are a prefix of the same output)
+    assert p.returncode != 0 and b"Error during FASTQ/A record parsing." in p.stderr
+    assert (outs[0].startswith(p.stdout) or p.stdout.startswith(outs[0])) and p.stdout.count(b"\n@r") > 300
+    # a damaged member: the reference's reader would fail on it as well; no record of that window is written
+    blob = bytearray(_bgzf(files["plain.fastq"].encode(), 20000))
+    blob[len(blob) // 2] ^= 0x20
+    (tmp_path / "damaged.bgzf.fastq.gz").write_bytes(bytes(blob))
+    for extra in ([], ["--host-ingest"], ["--host-codec"]):
+        p = run(["extract", "-i", str(tmp_path / "damaged.bgzf.fastq.gz"), "-f", str(tmp_path / "k.txt"), "--window-mb", "1"] + extra, check=False)
+        assert p.returncode != 0 and b"Error while decompressing" in p.stderr, extra

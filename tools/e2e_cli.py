@@ -33,7 +33,7 @@ rec.tofile(fq)
 open(km, "wb").write(b"\n".join(p.tobytes() for p in pats) + b"\n")
 print(f"generated {n} reads ({os.path.getsize(fq) / 1e6:.0f} MB FASTQ) in {time.time() - t0:.1f} s", flush=True)
 GZ = bool(os.environ.get("MERKURIO_E2E_GZ"))
-m_small = min(n, 4_000_000)
+m_small = min(n, int(os.environ.get("MERKURIO_E2E_GZ_READS", "4000000")))
 raw_small = rec[:m_small].tobytes() if GZ else None
 # the timed runs are children of this process: drop its 12 GB of arrays first (a fork of a large parent is not free)
 del rec, bases, hdr
@@ -69,7 +69,10 @@ if GZ:
     small = os.path.join(tmp, "e2e_small.fastq")
     open(small, "wb").write(raw)
     t0 = time.time()
-    subprocess.run(f"gzip -1 -c {small} > {small}.gz", shell=True, check=True)
+    if m <= 4_000_000:
+        subprocess.run(f"gzip -1 -c {small} > {small}.gz", shell=True, check=True)
+    else:
+        open(small + ".gz", "wb").close()
 
     def member(b):
         chunk = raw[b:b + 0xff00]
@@ -85,8 +88,9 @@ if GZ:
     print(f"compressed {m} reads ({len(raw) / 1e6:.0f} MB): gzip -1 {os.path.getsize(small + '.gz') / 1e6:.0f} MB, BGZF {os.path.getsize(bg) / 1e6:.0f} MB, in {time.time() - t0:.1f} s", flush=True)
     run(f"plain, {m} reads, device ingest", small, [], m)
     run(f"plain, {m} reads, --host-ingest", small, ["--host-ingest"], m)
-    run(f"gzip (one member), {m} reads, device ingest", small + ".gz", [], m)
-    run(f"gzip (one member), {m} reads, --host-ingest", small + ".gz", ["--host-ingest"], m)
+    if m <= 4_000_000:
+        run(f"gzip (one member), {m} reads, device ingest", small + ".gz", [], m)
+        run(f"gzip (one member), {m} reads, --host-ingest", small + ".gz", ["--host-ingest"], m)
     for rep in range(2):
         run(f"BGZF, {m} reads, device ingest, members inflated on the device", bg, [], m)
         run(f"BGZF, {m} reads, device ingest, --host-codec (zlib on the host threads)", bg, ["--host-codec"], m)
