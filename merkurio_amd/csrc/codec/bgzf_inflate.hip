@@ -6,9 +6,9 @@
 // one before it -- but BGZF cuts a file into independent members of <= 64 KiB, thousands per window: the lanes of a
 // wave each decode their own member with the serial decoder of inflate_serial.hpp (the code the host harness checks
 // against zlib; that header says what shapes it), each lane's decoder block -- canonical code descriptions, symbol
-// orders, a 64-byte window of its stream: 836 B -- side by side in LDS (52 KiB per wave, 3 waves per CU).  Bound:
-// latency of dependent LDS / L2 accesses under divergence, hidden only by the number of members in flight (64 per
-// wave: 49 152 streams on the part) -- not HBM, not MFMA.
+// orders, a 64-byte window of its stream: 836 B -- side by side in dynamic LDS (52 KiB for a full wave of 64 members;
+// a call that does not fill the part is spread over narrower waves, see inflate_lanes).  Bound: latency of dependent
+// LDS / L2 accesses under divergence, hidden only by the number of members in flight -- not HBM, not MFMA.
 // The CRC-32 of every member's text is checked by mk_bgzf_crc_check_kernel (bgzf_deflate.hip) afterwards.
 #include <hip/hip_runtime.h>
 

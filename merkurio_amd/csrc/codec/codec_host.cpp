@@ -21,10 +21,10 @@ int ensure_device(void **p, size_t *cap, size_t need);
 
 namespace {
 
-// Members per device pass.  Deflate runs one wave per member on a resident grid of 3 waves per CU (768 on an MI355X):
-// 12 288 members = 16 full rounds, 765 MiB of text.  Inflate is bound by the latency of its longest lane, 35-60 ms per
-// launch whether it holds 64 waves or 768 (profiles/r04_codec_kernels.txt): a pass takes as many members as the part
-// holds streams (768 waves x 64 lanes), 3 GiB of text.
+// Members per device pass (mk_codec_set_pass_limits overrides).  Deflate deals its members from a counter to a resident
+// grid of 16 waves per CU, so a pass only has to be large: 49 152 members = 3.2 GB of text (its 64 KiB slot per member is
+// what bounds it).  Inflate is bound by the latency of its slowest lane, 25-60 ms per launch whatever it holds
+// (profiles/r04_codec_kernels.txt): a pass takes as many members as the part holds streams, 3 GiB of text.
 constexpr uint64_t kDeflateChunkBlocks = 49152;
 constexpr uint64_t kInflateChunkText = 3ull << 30;
 
