@@ -525,3 +525,26 @@ def test_device_ingest_equals_host_ingest(tmp_path):
     for extra in ([], ["--host-ingest"], ["--host-codec"]):
         p = run(["extract", "-i", str(tmp_path / "damaged.bgzf.fastq.gz"), "-f", str(tmp_path / "k.txt"), "--window-mb", "1"] + extra, check=False)
         assert p.returncode != 0 and b"Error while decompressing" in p.stderr, extra
+
+
+def test_bgzip_inputs_the_device_path_hands_back(golden, tmp_path):
+    """a bgzip'ed input goes to mk_extract_fastq_bgzf first; what is not plain FASTQ comes back to the host reader at member 0:
+    FASTA (the reference's sample), wrapped FASTQ; and the degenerate files: only an end-of-file member, one read"""
+    d = os.path.join(golden, "example-minimal")
+    fasta = open(os.path.join(d, "sample.fasta"), "rb").read()
+    (tmp_path / "s.fasta.gz").write_bytes(_bgzf(fasta * 40, 3000))
+    (tmp_path / "s.fasta").write_bytes(fasta * 40)
+    outs = [run(["extract", "-f", os.path.join(d, "kmers.txt"), "-i", str(tmp_path / n)]).stdout for n in ("s.fasta.gz", "s.fasta")]
+    assert outs[0] == outs[1] and outs[0].count(b">") >= 40
+    wrapped = b"".join(b"@w%d\nACGTACGTAC\nGTACGTTTTT\n+\nIIIIIIIIII\nIIIIIIIIII\n" % i for i in range(500))
+    (tmp_path / "w.fastq.gz").write_bytes(_bgzf(wrapped, 5000))
+    (tmp_path / "w.fastq").write_bytes(wrapped)
+    outs = [run(["extract", "-s", "ACGTTT", "-i", str(tmp_path / n), "--window-mb", "1"], check=False) for n in ("w.fastq.gz", "w.fastq")]
+    assert (outs[0].returncode, outs[0].stdout, outs[0].stderr) == (outs[1].returncode, outs[1].stdout, outs[1].stderr)
+    (tmp_path / "e.fastq.gz").write_bytes(_bgzf(b""))
+    p = run(["extract", "-s", "ACGT", "-i", str(tmp_path / "e.fastq.gz")], check=False)
+    (tmp_path / "e.fastq").write_bytes(b"")
+    q = run(["extract", "-s", "ACGT", "-i", str(tmp_path / "e.fastq")], check=False)
+    assert (p.returncode, p.stdout) == (q.returncode, q.stdout)
+    (tmp_path / "one.fastq.gz").write_bytes(_bgzf(b"@a\nTTACGTTT\n+\nIIIIIIII"))
+    assert run(["extract", "-s", "ACGT", "-i", str(tmp_path / "one.fastq.gz")]).stdout == b"@a\nTTACGTTT\n+\nIIIIIIII\n"
