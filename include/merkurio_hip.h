@@ -439,17 +439,32 @@ int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf
 /* mk_extract_fastq_text for a window of a bgzip'ed FASTQ: the members are uploaded as they are (a fifth of the text) and
  * inflated on the device STRAIGHT INTO the text buffer the ingest kernels read -- the text is never uploaded.  The window's
  * text = head[0, n_head) (the unfinished record the previous window ended with) followed by the members' text
- * (members[i].out_off = running sum of ISIZE from 0); it is copied to text[0, *n_text) for the caller (record ids, kept
- * records, the next head).  [0, *n_used) of it are whole 4-line records and are what is indexed and scanned, exactly as
- * mk_extract_fastq_text does (same outputs, same *status = 1 for text that is not plain FASTQ: the caller's own reader then
- * takes the window); the rest, text[*n_used, *n_text), is the next call's head.  last != 0: no text follows, a final line
- * without a line end counts, an unfinished record is a refusal (*status = 1).  A damaged member: MK_E_CORRUPT.
- * text_cap < n_head + sum of ISIZE: MK_E_CAPACITY.  The codec handle lends its device buffers and must be on the matcher's
- * device.  (The reference gets these records from needletail's gzip reader, src/cmd_extract.rs:281-282,321-328.) */
+ * (members[i].out_off = running sum of ISIZE from 0).  [0, io->n_used) of it are whole 4-line records and are what is indexed
+ * and scanned, exactly as mk_extract_fastq_text does (same outputs, same *status = 1 for text that is not plain FASTQ: the
+ * caller's own reader then takes the window); the rest, [io->n_used, io->n_text), is the next call's head.  What comes back
+ * of the text is the caller's choice (mk_window_text):
+ *   io->text != NULL: all of it, text[0, n_text) (text_cap >= n_head + sum of ISIZE, else MK_E_CAPACITY);
+ *   io->text == NULL: only io->tail[0, n_tail) = the next head, and io->kept[0, n_kept_bytes) = the text of the KEPT records
+ *     (keep[r] != 0), gathered on the device, back to back in record order -- record r's text is the next
+ *     rec_start[r + 1] - rec_start[r] bytes of it.  (With logging AND invert the rows name records that are not kept: use
+ *     the whole-text mode then.)  kept_cap too small: MK_E_CAPACITY with n_kept_bytes = the need; the last whole record must
+ *     end within the window's last MiB, else *status = 1.
+ * last != 0: no text follows, a final line without a line end counts, an unfinished record is a refusal (*status = 1).
+ * A damaged member: MK_E_CORRUPT.  The codec handle lends its device buffers and must be on the matcher's device.
+ * (The reference gets these records from needletail's gzip reader, src/cmd_extract.rs:281-282,321-328.) */
+typedef struct mk_window_text {
+    uint8_t *text;     /* in: whole-text mode buffer or NULL */
+    uint64_t text_cap;
+    uint8_t *tail;     /* in (text == NULL): the unfinished record at the window's end goes here */
+    uint64_t tail_cap;
+    uint8_t *kept;     /* in (text == NULL): the kept records' text goes here */
+    uint64_t kept_cap;
+    uint64_t n_text, n_used, n_tail, n_kept_bytes; /* out */
+} mk_window_text;
 int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, uint64_t n_head, const uint8_t *bgzf, uint64_t n_bgzf,
-                          const mk_bgzf_member *members, uint64_t n_members, int last, uint8_t *text, uint64_t text_cap, uint64_t *n_text,
-                          uint64_t *n_used, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec, uint64_t *rec_start, uint8_t *keep,
-                          mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *pattern_hit_counts, uint32_t *status);
+                          const mk_bgzf_member *members, uint64_t n_members, int last, mk_window_text *io, int logging, int invert,
+                          uint64_t rec_cap, uint64_t *n_rec, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap,
+                          uint64_t *n_rows, mk_counters *c, uint32_t *pattern_hit_counts, uint32_t *status);
 /* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,
  * *consumed = bytes of whole members, *text_bytes = sum of ISIZE.  MK_E_CORRUPT where a header is not BGZF; a trailing
  * partial member is not an error (*consumed < n).  Host code, no device. */

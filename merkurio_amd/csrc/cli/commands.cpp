@@ -368,7 +368,8 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         bgzf_device = device_ingest && !a.host_codec && s1.raw_is_bgzf();
         if (device_ingest && !bgzf_device) raw_more = s1.raw_fill(std::min<uint64_t>(raw_window, 32ull << 20), &raw_text, &raw_n, &raw_resume);
         if (!raw_more && !bgzf_device) more1 = s1.fill(window_bytes);
-        if (bgzf_device) {
+        if (bgzf_device && a.invert_match && lg.active) {
+            // (-v with a log: the whole text of a window comes back, see the loop below)
             // nothing to inflate or parse here; the window's text will come back from the device into this buffer: a copy
             // into memory that was never touched takes a page fault per 4 KiB (0.15 s per GiB) -- take them now, on all
             // host threads, while the matcher thread waits for the HIP runtime
@@ -589,6 +590,11 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         // (a launch of the inflate kernel lasts as long as its slowest member whatever it holds: few, large windows)
         const uint64_t target = std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
         bool refused = false;
+        const bool whole_text = a.invert_match && lg.active;
+        RawBuffer tailbuf;
+        uint64_t kept_need = 0;
+        std::vector<uint64_t> packed_start, kept_of;
+        std::vector<uint8_t> packed_keep;
         while (next < nm || !head.empty()) {
             grp.clear();
             uint64_t members_text = 0;
@@ -603,7 +609,19 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             }
             const bool last = g1 >= nm;
             const uint64_t cap_text = head.size() + members_text;
-            textbuf.need(cap_text + 16);
+            // what comes back of the window's text: only the kept records (gathered on the device) and the unfinished record
+            // at its end -- unless the log rows name records that are not kept (-v with a log): then all of it
+            mk_window_text io;
+            memset(&io, 0, sizeof(io));
+            if (whole_text) {
+                textbuf.need(cap_text + 16);
+                io.text = (uint8_t *)textbuf.p.get(), io.text_cap = textbuf.cap;
+            } else {
+                textbuf.need(std::max<uint64_t>(kept_need, std::min<uint64_t>(cap_text, std::max<uint64_t>(64u << 20, cap_text / 8))));
+                tailbuf.need(1u << 20);
+                io.kept = (uint8_t *)textbuf.p.get(), io.kept_cap = textbuf.cap;
+                io.tail = (uint8_t *)tailbuf.p.get(), io.tail_cap = tailbuf.cap;
+            }
             uint64_t n_rec = 0, n_rows = 0, n_text = 0, n_used = 0;
             uint32_t status = 0;
             mk_counters cb;
@@ -615,9 +633,15 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                 memset(&cb, 0, sizeof(cb));
                 std::fill(cnt_b.begin(), cnt_b.end(), 0);
                 const int rc = mk_extract_fastq_bgzf(m, codec, (const uint8_t *)head.data(), head.size(), ws.file_bytes(), ws.file_size(), grp.data(),
-                                                     grp.size(), last, (uint8_t *)textbuf.p.get(), textbuf.cap, &n_text, &n_used, lg.active,
-                                                     a.invert_match, rec_cap, &n_rec, rec_start.data(), keep.data(), rows.data(), rows.size(), &n_rows,
-                                                     &cb, cnt_b.data(), &status);
+                                                     grp.size(), last, &io, lg.active, a.invert_match, rec_cap, &n_rec, rec_start.data(), keep.data(),
+                                                     rows.data(), rows.size(), &n_rows, &cb, cnt_b.data(), &status);
+                n_text = io.n_text, n_used = io.n_used;
+                if (rc == MK_E_CAPACITY && !whole_text && io.n_kept_bytes > io.kept_cap) {  // (many reads kept: the need is known now)
+                    kept_need = io.n_kept_bytes + (io.n_kept_bytes >> 3);
+                    textbuf.need(kept_need);
+                    io.kept = (uint8_t *)textbuf.p.get(), io.kept_cap = textbuf.cap;
+                    continue;
+                }
                 if (rc == MK_E_CAPACITY && n_rec > rec_cap) {
                     rec_cap = n_rec;
                     continue;
@@ -634,7 +658,34 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                 refused = true;
                 break;
             }
-            accept_window(textbuf.p.get(), n_used, n_rec, n_rows, cb, cnt_b);
+            if (whole_text) {
+                accept_window(textbuf.p.get(), n_used, n_rec, n_rows, cb, cnt_b);
+            } else {
+                // the kept records lie back to back in what came down: their record table, and the rows' record numbers, in
+                // terms of that text (a row's record is a kept one: no -v here)
+                packed_start.clear();
+                kept_of.clear();
+                uint64_t at = 0;
+                for (uint64_t k = 0; k < n_rec; ++k)
+                    if (keep[k]) {
+                        kept_of.push_back(k);
+                        packed_start.push_back(at);
+                        at += rec_start[k + 1] - rec_start[k];
+                    }
+                packed_start.push_back(at);
+                if (at != io.n_kept_bytes) bail("Error during matching: the kept records' text does not have the size of its record table");
+                for (uint64_t r = 0; r < (lg.active ? n_rows : 0); ++r)
+                    rows[r].rec = (uint64_t)(std::lower_bound(kept_of.begin(), kept_of.end(), rows[r].rec) - kept_of.begin());
+                const uint64_t n_kept = kept_of.size();
+                packed_keep.assign(n_kept, 1);
+                rec_start.swap(packed_start);
+                keep.swap(packed_keep);
+                const uint64_t extracted = cb.nb_records_extracted;
+                accept_window(textbuf.p.get(), at, n_kept, n_rows, cb, cnt_b);
+                (void)extracted;
+                rec_start.swap(packed_start);
+                keep.swap(packed_keep);
+            }
             // the next head: text[n_used, n_text), and where it lies in the member chain
             if (n_used >= n_text) {
                 head_member = g1, head_skip = 0;
@@ -650,7 +701,8 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                 }
                 head_member = next + lo, head_skip = x - grp[lo].out_off;
             }
-            head.assign(textbuf.p.get() + n_used, textbuf.p.get() + n_text);
+            if (whole_text) head.assign(textbuf.p.get() + n_used, textbuf.p.get() + n_text);
+            else head.assign(tailbuf.p.get(), tailbuf.p.get() + io.n_tail);
             next = g1;
             if (last) break;  // (whole records to the end: an unfinished one was a refusal)
         }

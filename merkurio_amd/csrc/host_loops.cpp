@@ -301,9 +301,18 @@ void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_
 void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st);
 void launch_ingest_gather(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off,
                           uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st);
+void launch_ingest_select(const uint8_t *d_flags, uint32_t invert, const uint32_t *d_rec_start, uint64_t n_rec, uint32_t n_text, uint32_t *d_sel_len,
+                          hipStream_t st);
 uint32_t ingest_block_bytes();
 uint32_t ingest_scan_tile();
 }  // namespace mk
+
+// the text of the kept records, packed on the device and copied to the host (mk_extract_fastq_bgzf without a whole-text copy)
+struct KeptText {
+    uint8_t *text;
+    uint64_t cap;
+    uint64_t n_bytes;  // out (also when cap is too small: MK_E_CAPACITY)
+};
 
 extern "C" {
 
@@ -347,7 +356,7 @@ int mk_upload_text_ahead(mk_matcher *m, const uint8_t *text, uint64_t n_text) {
 // record table -- everything of mk_extract_fastq_text behind the upload.  last_byte = text[n_text - 1].
 static int extract_text_resident(mk_matcher *m, DeviceLoop &dl, uint64_t n_text, uint8_t last_byte, int logging, int invert, uint64_t rec_cap,
                                  uint64_t *n_rec_out, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
-                                 mk_counters *c, uint32_t *counts, uint32_t *status) {
+                                 mk_counters *c, uint32_t *counts, uint32_t *status, KeptText *kept = nullptr) {
     hipStream_t st = dl.st;
     int rc;
     const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
@@ -403,6 +412,7 @@ static int extract_text_resident(mk_matcher *m, DeviceLoop &dl, uint64_t n_text,
     if (n_seq == 0) {  // every sequence is empty: nothing can match
         std::fill(flags.begin(), flags.end(), 0);
         dl.found = 0;
+        if (kept && n_rec && hipMemsetAsync(m->d_flags, 0, n_rec, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
     } else if ((rc = dl.scan_resident(n_seq, n_rec, logging ? MK_MODE_HITS : MK_MODE_ANY, fixed, flags.data(), &flagged))) {
         return rc;
     }
@@ -414,6 +424,27 @@ static int extract_text_resident(mk_matcher *m, DeviceLoop &dl, uint64_t n_text,
         if ((rc = dl.order(m->algo == MK_ALGO_AC))) return rc;
         if ((rc = dl.rows_to_host(0, rows, rows_cap))) return rc;
         if ((rc = dl.pattern_counts(m->algo == MK_ALGO_AC, n_rec, counts))) return rc;
+    }
+    if (kept) {
+        // the kept records' text, back to back in record order: lengths by the flags (the scan's, still on the device), the
+        // offsets scan and the gather kernel of the sequences once more -- into the scan buffer, which has done its work
+        kept->n_bytes = 0;
+        if (n_rec) {
+            unsigned long long total = 0;
+            launch_ingest_select(m->d_flags, invert ? 1u : 0u, d_rec_start, n_rec, (uint32_t)n_text, d_seq_len, st);
+            launch_ingest_offsets(d_seq_len, n_rec, d_tile, (unsigned long long *)m->d_off, st);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, m->d_off + n_rec, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return fail(MK_E_HIP, "selection of the kept records failed");
+            kept->n_bytes = total;
+            if (total > kept->cap) return fail(MK_E_CAPACITY, "the kept records take %llu bytes", total);
+            if (total) {
+                launch_ingest_gather((const uint8_t *)m->d_text, d_rec_start, d_seq_len, (const unsigned long long *)m->d_off, 0, n_rec, m->d_seq, st);
+                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(kept->text, m->d_seq, total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return fail(MK_E_HIP, "copy of the kept records failed");
+            }
+        }
     }
     // record table -> host: where every record starts in the text, one more entry = the end of the text
     std::vector<uint32_t> rs(n_rec ? n_rec : 1);
@@ -476,13 +507,14 @@ int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, i
 }
 
 int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, uint64_t n_head, const uint8_t *bgzf, uint64_t n_bgzf,
-                          const mk_bgzf_member *members, uint64_t n_members, int last, uint8_t *text, uint64_t text_cap, uint64_t *n_text_out,
-                          uint64_t *n_used_out, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out, uint64_t *rec_start, uint8_t *keep,
+                          const mk_bgzf_member *members, uint64_t n_members, int last, mk_window_text *io, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out, uint64_t *rec_start, uint8_t *keep,
                           mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts, uint32_t *status) {
-    if (!m || !codec || !n_text_out || !n_used_out || !n_rec_out || !status || !c || (logging && !counts) || (n_head && !head) ||
+    if (!m || !codec || !io || !n_rec_out || !status || !c || (logging && !counts) || (n_head && !head) ||
         (n_members && (!bgzf || !members)))
         return fail(MK_E_INVALID_ARG, "null argument");
-    *n_text_out = *n_used_out = *n_rec_out = 0;
+    io->n_text = io->n_used = io->n_tail = io->n_kept_bytes = 0;
+    *n_rec_out = 0;
+    uint8_t *const text = io->text;  // != NULL: the whole window text goes back; NULL: its tail and the kept records only
     *status = 0;
     if (n_rows) *n_rows = 0;
     uint64_t n_text = n_head;
@@ -492,10 +524,11 @@ int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, u
             return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: member %llu lies outside its buffer or its text is not in sequence", (unsigned long long)i);
         n_text += b.isize;
     }
-    *n_text_out = n_text;
+    io->n_text = n_text;
     if (n_text == 0) return MK_OK;
     if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
-    if (!text || text_cap < n_text) return fail(MK_E_CAPACITY, "mk_extract_fastq_bgzf: the window's text takes %llu bytes", (unsigned long long)n_text);
+    if (text && io->text_cap < n_text) return fail(MK_E_CAPACITY, "mk_extract_fastq_bgzf: the window's text takes %llu bytes", (unsigned long long)n_text);
+    if (!text && (!io->tail || (io->kept_cap && !io->kept))) return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: neither a text buffer nor tail / kept buffers");
     MK_ABI_BEGIN
     if (codec->device != m->device) return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: the codec and the matcher are on different devices");
     if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
@@ -551,32 +584,53 @@ int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, u
     if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
     uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;
     launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);
+    // what the host must see: all of the text (mode with io->text), or only its end -- where the last whole record ends
+    // is found there -- and, later, the kept records
+    constexpr uint64_t kTailRegion = 1u << 20;
+    const uint64_t reg0 = text ? 0 : (n_text > kTailRegion ? n_text - kTailRegion : 0);  // host copy = text[reg0, n_text)
+    std::vector<uint8_t> region;
+    if (!text) region.resize(n_text - reg0);
+    uint8_t *const host = text ? text : region.data() - reg0;  // host[i] is valid for reg0 <= i < n_text
     if (hipMemcpyAsync(&total_nl, d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(text, m->d_text, n_text, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        hipMemcpyAsync(host + reg0, (const uint8_t *)m->d_text + reg0, n_text - reg0, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
         return fail(MK_E_HIP, "download of the text failed");
     dl.mark(1);
     // whole records only: the window starts at a record start, a record is four lines
     uint64_t n_used = n_text;
     if (last) {
-        const uint64_t lines = (uint64_t)total_nl + (text[n_text - 1] != '\n' ? 1 : 0);
+        const uint64_t lines = (uint64_t)total_nl + (host[n_text - 1] != '\n' ? 1 : 0);
         if (lines % 4 != 0) {  // an unfinished record at the end of the input: the caller's reader words that error
             *status = 1;
             return MK_OK;
         }
     } else {
-        while (n_used > 0 && text[n_used - 1] != '\n') --n_used;  // the unfinished last line
-        for (uint32_t drop = total_nl % 4; drop > 0 && n_used > 0; --drop) {
+        while (n_used > reg0 && host[n_used - 1] != '\n') --n_used;  // the unfinished last line
+        for (uint32_t drop = total_nl % 4; drop > 0 && n_used > reg0; --drop) {
             --n_used;
-            while (n_used > 0 && text[n_used - 1] != '\n') --n_used;
+            while (n_used > reg0 && host[n_used - 1] != '\n') --n_used;
+        }
+        if (n_used == reg0 && reg0 > 0) {  // the last record start lies further back than the region that came down
+            *status = 1;
+            return MK_OK;
         }
     }
-    *n_used_out = n_used;
+    io->n_used = n_used;
     if (n_used == 0) {  // not one whole record in the window
         *status = last ? 0u : 1u;
         return MK_OK;
     }
-    return extract_text_resident(m, dl, n_used, text[n_used - 1], logging, invert, rec_cap, n_rec_out, rec_start, keep, rows, rows_cap, n_rows, c, counts,
-                                 status);
+    KeptText kept{io->kept, io->kept_cap, 0};
+    if (!text) {
+        io->n_tail = n_text - n_used;
+        if (io->n_tail > io->tail_cap) return fail(MK_E_CAPACITY, "mk_extract_fastq_bgzf: the unfinished record at the window's end takes %llu bytes", (unsigned long long)io->n_tail);
+        memcpy(io->tail, host + n_used, io->n_tail);
+    }
+    const uint8_t last_byte = n_used > reg0 ? host[n_used - 1] : (uint8_t)'\n';
+    rc = extract_text_resident(m, dl, n_used, last_byte, logging, invert, rec_cap, n_rec_out, rec_start, keep, rows, rows_cap, n_rows, c, counts, status,
+                               text ? nullptr : &kept);
+    io->n_kept_bytes = kept.n_bytes;
+    return rc;
     MK_ABI_END
 }
 

@@ -247,6 +247,23 @@ __global__ __launch_bounds__(256) void mk_ingest_gather_kernel(const uint8_t *__
     for (uint32_t k = sub; k < len; k += 16) dst[k] = src[k];
 }
 
+// length of record i's text if the record is kept (hit != invert), else 0: the lengths the offsets scan and the gather
+// kernel then pack the kept records with
+__global__ __launch_bounds__(256) void mk_ingest_select_kernel(const uint8_t *__restrict__ flags, uint32_t invert, const uint32_t *__restrict__ rec_start,
+                                                              uint64_t n_rec, uint32_t n_text, uint32_t *__restrict__ sel_len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const uint32_t end = i + 1 < n_rec ? rec_start[i + 1] : n_text;
+    sel_len[i] = ((flags[i] != 0) != (invert != 0)) ? end - rec_start[i] : 0u;
+}
+
+void launch_ingest_select(const uint8_t *d_flags, uint32_t invert, const uint32_t *d_rec_start, uint64_t n_rec, uint32_t n_text, uint32_t *d_sel_len,
+                          hipStream_t st) {
+    if (!n_rec) return;
+    hipLaunchKernelGGL(mk_ingest_select_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, d_flags, invert, d_rec_start, n_rec, n_text,
+                       d_sel_len);
+}
+
 void launch_ingest_count(const uint8_t *d_text, uint64_t n, uint32_t *d_block_cnt, uint32_t *d_total, hipStream_t st) {
     const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
     hipLaunchKernelGGL(mk_ingest_count_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_cnt);

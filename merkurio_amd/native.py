@@ -87,6 +87,12 @@ class MatcherOptions(C.Structure):
                          1 if force_single_class else int(length_classes), int(force_split_len), int(force_stride2), int(force_q2))
 
 
+class WindowText(C.Structure):
+    """mk_window_text (include/merkurio_hip.h): what mk_extract_fastq_bgzf hands back of a window's text"""
+    _fields_ = [("text", C.c_void_p), ("text_cap", C.c_uint64), ("tail", C.c_void_p), ("tail_cap", C.c_uint64), ("kept", C.c_void_p),
+                ("kept_cap", C.c_uint64), ("n_text", C.c_uint64), ("n_used", C.c_uint64), ("n_tail", C.c_uint64), ("n_kept_bytes", C.c_uint64)]
+
+
 class Counters(C.Structure):
     _fields_ = [("nb_records_tot", C.c_uint64), ("nb_bases", C.c_uint64), ("nb_hits_tot", C.c_uint64 * 2),
                 ("nb_records_hit", C.c_uint64 * 2), ("nb_records_extracted", C.c_uint64)]
@@ -207,9 +213,8 @@ def load(build_if_missing=True):
     L.mk_codec_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mk_codec_set_pass_limits.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.mk_extract_fastq_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
-                                        C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_uint64,
-                                        C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
-                                        C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
+                                        C.POINTER(WindowText), C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(Counters), C.c_void_p]
@@ -522,17 +527,24 @@ class Matcher:
         out_rows = [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else []
         return status.value, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows, cnt.as_dict(counts)
 
-    def extract_fastq_bgzf(self, codec, head: bytes, blob: bytes, members, last, logging=True, invert=False):
+    def extract_fastq_bgzf(self, codec, head: bytes, blob: bytes, members, last, logging=True, invert=False, whole_text=True):
         """mk_extract_fastq_bgzf: head + the text of `members` (entries of bgzf_members(blob), out_off re-based to 0) ->
-        (status, text, n_used, rec_start, keep, rows, counters); the members are inflated into the ingest buffer on the device"""
+        (status, text, n_used, rec_start, keep, rows, counters); the members are inflated into the ingest buffer on the device.
+        whole_text=False: `text` is a pair (tail, kept) -- the unfinished record at the window's end and the kept records' text"""
         mem = members.copy()
         if len(mem):
             mem["out_off"] -= mem["out_off"][0]
         n_text = len(head) + int(mem["isize"].sum()) if len(mem) else len(head)
         hb, bb = np.frombuffer(head, dtype=np.uint8), np.frombuffer(blob, dtype=np.uint8)
         text = np.zeros(max(1, n_text), dtype=np.uint8)
+        tail = np.zeros(1 << 20, dtype=np.uint8)
+        io = WindowText()
+        if whole_text:
+            io.text, io.text_cap = text.ctypes.data, n_text
+        else:
+            io.tail, io.tail_cap, io.kept, io.kept_cap = tail.ctypes.data, tail.size, text.ctypes.data, 64
         cap = max(1, n_text // 8 + 2)
-        n_rec, status, nt, nu = C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        n_rec, status = C.c_uint64(), C.c_uint32()
         rec_start = np.zeros(cap + 1, dtype=np.uint64)
         keep = np.zeros(cap, dtype=np.uint8)
         rows = np.zeros(4096, dtype=ROW_DTYPE)
@@ -540,19 +552,21 @@ class Matcher:
         while True:
             c2, k2 = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
             rc = load().mk_extract_fastq_bgzf(self._h, codec._h, hb.ctypes.data if len(hb) else None, len(hb), bb.ctypes.data if len(bb) else None,
-                                              len(bb), mem.ctypes.data if len(mem) else None, len(mem), int(bool(last)), text.ctypes.data, n_text,
-                                              C.byref(nt), C.byref(nu), int(logging), int(invert), cap, C.byref(n_rec), rec_start.ctypes.data,
-                                              keep.ctypes.data, rows.ctypes.data, len(rows), C.byref(n_rows), C.byref(c2), k2.ctypes.data,
-                                              C.byref(status))
+                                              len(bb), mem.ctypes.data if len(mem) else None, len(mem), int(bool(last)), C.byref(io), int(logging),
+                                              int(invert), cap, C.byref(n_rec), rec_start.ctypes.data, keep.ctypes.data, rows.ctypes.data,
+                                              len(rows), C.byref(n_rows), C.byref(c2), k2.ctypes.data, C.byref(status))
             if rc == MK_E_CAPACITY and n_rows.value > len(rows):
                 rows = np.zeros(n_rows.value, dtype=ROW_DTYPE)
+                continue
+            if rc == MK_E_CAPACITY and not whole_text and io.n_kept_bytes > io.kept_cap:  # (the first call states the need: the retry path)
+                io.kept_cap = io.n_kept_bytes
                 continue
             _check(rc)
             break
         n = n_rec.value
         out_rows = [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else []
-        return (status.value, text[:nt.value].tobytes(), nu.value, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows,
-                c2.as_dict(k2))
+        out_text = text[:io.n_text].tobytes() if whole_text else (tail[:io.n_tail].tobytes(), text[:io.n_kept_bytes].tobytes())
+        return (status.value, out_text, io.n_used, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows, c2.as_dict(k2))
 
     def extract_paired(self, seqs1, seqs2, logging=True, invert=False):
         d1, o1 = pack_records(seqs1)

@@ -504,6 +504,15 @@ def test_device_ingest_equals_host_ingest(tmp_path):
             plain_out = tmp_path / f"{bz[name]}.device"
             assert res["device"][0] == open(plain_out / "out.fastq", "rb").read(), name
             assert res["device"][1] == log_body(plain_out / "log.txt").replace(bz[name].encode() + b"\t", b"<file>\t"), name
+    # -v with a log: the rows name records that are not kept -- the device path brings the whole text of a window back then
+    res = []
+    for extra in ([], ["--host-ingest"]):
+        d = tmp_path / ("inv" + "".join(extra))
+        d.mkdir()
+        run(["extract", "-i", str(tmp_path / "plain.bgzf.fastq.gz"), "-f", str(tmp_path / "k.txt"), "-v", "-o", str(d / "out"), "-l", str(d / "log.txt"),
+             "--window-mb", "1"] + extra)
+        res.append((open(d / "out.fastq", "rb").read(), log_body(d / "log.txt")))
+    assert res[0] == res[1] and res[0][0].count(b"\n@r") > 3000
     # a malformed record in the third window: both paths write the records before it and end with the reference's message
     bad = "".join(plain[:5000]) + "@broken\nACGT\n+\nII\n" + "".join(plain[5000:])
     (tmp_path / "bad.fastq").write_text(bad)

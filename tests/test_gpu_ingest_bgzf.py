@@ -39,22 +39,29 @@ def setup():
     c.close()
 
 
-def through_windows(m, c, text, members_per_window, block=65280, **kw):
-    """the whole file in windows of `members_per_window` members -> (keep per record, rows with file-wide record numbers, counters summed)"""
+def through_windows(m, c, text, members_per_window, block=65280, whole_text=True, **kw):
+    """the whole file in windows of `members_per_window` members -> (keep per record, rows with file-wide record numbers, counters summed
+    [, the kept records' text as it came back, whole_text=False: only that and each window's unfinished tail come back])"""
     blob = zlib_bgzf(text, block, level=6)
     mem, used, total = mk.bgzf_members(blob)
     assert used == len(blob) and total == len(text)
     head, keep, rows, rec0, at = b"", [], [], 0, 0
     sums = None
-    got_text = b""
+    got_text, got_kept = b"", b""
     while at < len(mem) or head:
         group = mem[at:at + members_per_window]
         at += len(group)
         last = at >= len(mem)
-        status, wtext, n_used, rec_start, k, r, cnt = m.extract_fastq_bgzf(c, head, blob, group, last, **kw)
+        status, wtext, n_used, rec_start, k, r, cnt = m.extract_fastq_bgzf(c, head, blob, group, last, whole_text=whole_text, **kw)
         assert status == 0, status
-        assert wtext[:len(head)] == head
-        got_text += wtext[len(head):]
+        if whole_text:
+            assert wtext[:len(head)] == head
+            got_text += wtext[len(head):]
+        else:
+            tail, kept_text = wtext
+            assert len(kept_text) == sum(rec_start[i + 1] - rec_start[i] for i in range(len(k)) if k[i])
+            got_kept += kept_text
+            wtext = b"\0" * n_used + tail  # (what follows only needs the tail behind n_used)
         assert rec_start[-1] == n_used if rec_start else n_used == 0
         keep += k
         rows += [(f, rec0 + rec, p, pos) for f, rec, p, pos in r]
@@ -71,6 +78,8 @@ def through_windows(m, c, text, members_per_window, block=65280, **kw):
         if last:
             assert head == b""
             break
+    if not whole_text:
+        return keep, rows, sums, got_kept
     assert got_text == text
     return keep, rows, sums
 
@@ -87,6 +96,14 @@ def test_windows_of_members_equal_the_text_entry(setup, flavour):
         assert keep == keep0 and rows == rows0 and cnt == cnt0, (flavour, per_window, block)
     keep, rows, cnt = through_windows(m, c, text, 5, 30000, logging=False, invert=True)
     assert keep == [not k for k in keep0] and rows == []
+    # only the kept records and each window's unfinished tail come back (gathered on the device): the same results, and the
+    # kept text is the kept records of the file, back to back
+    want_kept = b"".join(text[rec_start[i]:rec_start[i + 1]] for i in range(len(keep0)) if keep0[i])
+    for per_window, block in ((1000, 65280), (2, 20000), (9, 777)):
+        keep, rows, cnt, kept_text = through_windows(m, c, text, per_window, block, whole_text=False, logging=True)
+        assert keep == keep0 and rows == rows0 and cnt == cnt0 and kept_text == want_kept, (flavour, per_window, block)
+    keep, rows, cnt, kept_text = through_windows(m, c, text, 4, 30000, whole_text=False, logging=False, invert=True)
+    assert keep == [not k for k in keep0] and kept_text == b"".join(text[rec_start[i]:rec_start[i + 1]] for i in range(len(keep0)) if not keep0[i])
 
 
 def test_refusals_and_damage(setup):
