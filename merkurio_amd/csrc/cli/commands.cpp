@@ -680,9 +680,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
                 packed_keep.assign(n_kept, 1);
                 rec_start.swap(packed_start);
                 keep.swap(packed_keep);
-                const uint64_t extracted = cb.nb_records_extracted;
                 accept_window(textbuf.p.get(), at, n_kept, n_rows, cb, cnt_b);
-                (void)extracted;
                 rec_start.swap(packed_start);
                 keep.swap(packed_keep);
             }
