@@ -1144,7 +1144,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     std::vector<mk_counters> dev_c(ms.size());
     std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
     for (auto &x : dev_c) memset(&x, 0, sizeof(x));
-    bool more_windows = sam.fill(window_bytes);
+    // (the first window is small: nothing can run beside its read; the later, large ones are read beside their predecessors)
+    bool more_windows = sam.fill(std::min<uint64_t>(window_bytes, 128ull << 20));
     while (more_windows) {
         const size_t n = sam.recs.size();
         tm.mark("window: read (inflate) + index");
