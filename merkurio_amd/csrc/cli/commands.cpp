@@ -588,9 +588,11 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         size_t next = 0, head_member = 0;  // next member to take; the member the head's first byte lies in ...
         uint64_t head_skip = 0;            // ... and how far into its text
         // (a launch of the inflate kernel lasts as long as its slowest member whatever it holds: few, large windows)
-        const uint64_t target = std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
-        bool refused = false;
         const bool whole_text = a.invert_match && lg.active;
+        // (... and when the text stays on the device -- only the kept records come back -- --window-mb's reason, the host's
+        // memory, does not apply: windows of 3 GiB unless the flag was given)
+        const uint64_t target = (!whole_text && a.window_mb == 1024) ? (3ull << 30) : std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
+        bool refused = false;
         RawBuffer tailbuf;
         uint64_t kept_need = 0;
         std::vector<uint64_t> packed_start, kept_of;
