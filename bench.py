@@ -646,9 +646,80 @@ def codec_configs(mk, megabytes=1024, reps=3):
                     "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
         if text != data:
             raise RuntimeError("BGZF round trip on the device does not reproduce its input")
+        out.append(bgzf_window_config(mk, codec, reps))
     finally:
         codec.close()
     return out
+
+
+def bgzf_window_config(mk, codec, reps, n_reads=3_000_000, L=150, n_pat=10_000):
+    """One window of a bgzip'ed FASTQ through mk_extract_fastq_bgzf: the members go up as they are, are inflated
+    straight into the ingest buffer, indexed, gathered, scanned; the unfinished tail and the kept records come back.
+    `ms_per_call` is the whole call (host buffers in and out), against mk_extract_fastq_text on the same text (the text
+    uploaded instead); the flags of the two are compared in the run."""
+    import ctypes as C
+    import numpy as np
+    lib = mk.load()
+    rng = np.random.default_rng(5)
+    pats = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n_pat, 31))]
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n_reads, L))]
+    for i in range(0, n_reads, 100):
+        bases[i, 7:38] = pats[i % n_pat]
+    H = 13
+    rec = np.empty((n_reads, H + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, :H] = np.array([b"@r%010d\n" % i for i in range(n_reads)], dtype="S13").view(np.uint8).reshape(n_reads, H)
+    rec[:, H:H + L] = bases
+    rec[:, H + L:H + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, H + L + 3:H + 2 * L + 3] = ord("I")
+    rec[:, -1] = ord("\n")
+    text = rec.tobytes()
+    del rec, bases
+    blob = codec.deflate(text)
+    mem, used, total = mk.bgzf_members(blob)
+    m = mk.Matcher([p.tobytes() for p in pats], device=0)
+    bb = np.frombuffer(blob, dtype=np.uint8)
+    tb = np.frombuffer(text, dtype=np.uint8)
+    cap = n_reads + 16
+    rec_start, keep, keep2 = np.zeros(cap + 1, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint8)
+    tail, kept = np.zeros(1 << 20, dtype=np.uint8), np.zeros(len(text) // 8, dtype=np.uint8)
+    counts = np.zeros(n_pat, dtype=np.uint32)
+    n_rec, n_rows, status = C.c_uint64(), C.c_uint64(), C.c_uint32()
+
+    def bgzf_call():
+        io = mk.WindowText()
+        io.tail, io.tail_cap, io.kept, io.kept_cap = tail.ctypes.data, tail.size, kept.ctypes.data, kept.size
+        cnt = mk.Counters()
+        mk._check(lib.mk_extract_fastq_bgzf(m.handle, codec._h, None, 0, bb.ctypes.data, bb.size, mem.ctypes.data, len(mem), 1, C.byref(io), 0, 0, cap,
+                                            C.byref(n_rec), rec_start.ctypes.data, keep.ctypes.data, None, 0, C.byref(n_rows), C.byref(cnt),
+                                            counts.ctypes.data, C.byref(status)))
+        return io, cnt
+
+    def text_call():
+        cnt = mk.Counters()
+        mk._check(lib.mk_extract_fastq_text(m.handle, tb.ctypes.data, tb.size, 0, 0, cap, C.byref(n_rec), rec_start.ctypes.data, keep2.ctypes.data, None, 0,
+                                            C.byref(n_rows), C.byref(cnt), counts.ctypes.data, C.byref(status)))
+        return cnt
+
+    best = {}
+    for name, fn in (("bgzf", bgzf_call), ("text", text_call)):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        best[name] = (min(ts), r)
+    io, cnt = best["bgzf"][1]
+    same = bool(status.value == 0 and np.array_equal(keep[:n_reads], keep2[:n_reads]) and n_rec.value == n_reads)
+    if not same:
+        raise RuntimeError("mk_extract_fastq_bgzf and mk_extract_fastq_text disagree on the same reads")
+    return {"workload": f"bgzip'ed FASTQ window: {n_reads} x {L} bp reads = {len(text) / 1e6:.0f} MB of text in {len(mem)} members ({len(blob) / 1e6:.0f} MB), "
+                        f"{n_pat} 31-mers, any-hit flags; mk_extract_fastq_bgzf, tail + kept records back",
+            "kernel": "mk_bgzf_inflate_kernel + ingest + " + m.kernel_name, "ms_per_call": round(best["bgzf"][0] * 1e3, 1),
+            "text_gb_per_s_call": round(len(text) / best["bgzf"][0] / 1e9, 2), "gbases_per_s_call": round(n_reads * L / best["bgzf"][0] / 1e9, 2),
+            "ms_per_call_text_entry": round(best["text"][0] * 1e3, 1), "records_kept": int(keep[:n_reads].sum()), "kept_bytes_back": int(io.n_kept_bytes),
+            "flags_equal_to_text_entry": same, "bound": "latency of the inflate launch + PCIe of the members (a fifth of the text)",
+            "kernel_ms": None, "frac": None, "traffic": None, "traffic_source": "a host-buffer call, not a kernel: end-to-end figure"}
 
 
 def host_cores():
