@@ -1236,7 +1236,6 @@ BamWriter::~BamWriter() {
 void BamWriter::use_device(int device) { device_ = mk_bgzf_deflate_pieces ? device : -1; }
 
 constexpr size_t kBgzfBlock = 0xff00;
-constexpr size_t kFlushBytes = 1536 * kBgzfBlock;  // 100 MB of text per flush: two rounds of the deflate kernel's resident waves
 
 void BamWriter::put(const void *p, size_t n) {  // small writes (header, single records) share an open piece
     if (pieces.empty() || pieces.back().size() + n > pieces.back().capacity()) {
@@ -1245,14 +1244,14 @@ void BamWriter::put(const void *p, size_t n) {  // small writes (header, single 
     }
     pieces.back().insert(pieces.back().end(), (const uint8_t *)p, (const uint8_t *)p + n);
     pieces_bytes += n;
-    if (pieces_bytes >= kFlushBytes + kBgzfBlock) flush(false);
+    if (pieces_bytes >= (run_members + 1) * kBgzfBlock) flush(false);
 }
 
 void BamWriter::put_encoded(std::vector<uint8_t> &&bytes) {
     if (bytes.empty()) return;
     pieces_bytes += bytes.size();
     pieces.push_back(std::move(bytes));
-    if (pieces_bytes >= kFlushBytes + kBgzfBlock) flush(false);
+    if (pieces_bytes >= (run_members + 1) * kBgzfBlock) flush(false);
 }
 
 // one BGZF member: gzip header with the BC extra field, raw deflate, crc32, isize

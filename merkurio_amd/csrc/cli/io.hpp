@@ -281,6 +281,7 @@ struct BamWriter {
     void put_encoded(std::vector<uint8_t> &&bytes);
     void close();
     double deflate_seconds = 0;  // inside the flush threads (timing mode)
+    size_t run_members = 1536;   // members per run handed to the writer thread (100 MB of text: two rounds of the deflate kernel's waves)
 
    private:
     using Run = std::vector<std::vector<uint8_t>>;  // a run of whole members, as the pieces it arrived in

@@ -299,6 +299,63 @@ def test_windowed_sam_bam_reader(tmp_path, golden):
     assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16, "prefetch")
 
 
+def test_bam_writer_pieces_queue_and_encoder(tmp_path):
+    """BamWriter without a device (the --host-codec path; the device path differs in the deflate call only): records
+    encoded by the allocation-free encoder, handed over in pieces of 1 / 7 / 5 000 records or one by one, cut into 65 280-byte
+    members by the writer's queue and thread -- the BAM gunzips to the same stream whatever the pieces, its members are
+    whole BGZF members with an end-of-file marker, and the records read back (SamFile) are the SAM lines that went in,
+    optional fields of every type included."""
+    import gzip
+    import random
+    import struct
+    cli_dir = os.path.join(ROOT, "merkurio_amd/csrc/cli")
+    common = [os.path.join(cli_dir, "io.cpp"), os.path.join(cli_dir, "decompress.cpp"), os.path.join(cli_dir, "util.cpp"), "-lz", "-ldl", "-lpthread"]
+    wexe, rexe = str(tmp_path / "bw"), str(tmp_path / "ss")
+    subprocess.run(["g++", "-std=c++17", *_HARNESS_FLAGS, "-w", "-I", cli_dir, "-o", wexe, os.path.join(ROOT, "tests/helpers/bam_writer_harness.cpp"), *common], check=True)
+    subprocess.run(["g++", "-std=c++17", *_HARNESS_FLAGS, "-w", "-I", cli_dir, "-o", rexe, os.path.join(ROOT, "tests/helpers/sam_stream_harness.cpp"), *common], check=True)
+    rnd = random.Random(31)
+    n = 40000  # 7 MB of BAM records, > 100 members
+    header = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:100000\n@SQ\tSN:chrUn_x\tLN:5000\n"
+    lines = []
+    for i in range(n):
+        L = rnd.choice((0, 1, 36, 101, 150))
+        seq = "".join(rnd.choice("ACGTNacgtRY=") for _ in range(L)) or "*"
+        qual = "".join(chr(33 + rnd.randrange(42)) for _ in range(L)) if L and i % 11 else "*"
+        mapped = i % 3 == 0 and L > 0
+        cigar = f"{L}M" if mapped and i % 2 else (f"5S{L - 10}M2I3S" if mapped and L > 12 else "*")
+        tags = ["NM:i:%d" % rnd.choice((0, 7, 255, 256, 70000, -1, -200, -40000)), "XA:A:q", "XF:f:1.5", "RG:Z:grp%d" % (i % 3), "XH:H:1AE301",
+                "XB:B:c,-1,2,3", "XS:B:S,1,65535", "XI:B:i,-5,70000", "XE:B:f,0.5,2", "XC:B:C"][:rnd.randrange(11)]
+        lines.append("\t".join([f"read{i}/x", str(rnd.choice((0, 4, 16, 99))), "chr1" if mapped else "*", str(rnd.randrange(1, 90000) if mapped else 0),
+                                str(rnd.randrange(61)), cigar, rnd.choice(("=", "*", "chrUn_x")), str(rnd.randrange(5000)), str(rnd.randrange(-500, 500)),
+                                seq, qual] + tags))
+    (tmp_path / "in.sam").write_text(header + "\n".join(lines) + "\n")
+    streams = []
+    for per, run_members in ((0, 1536), (1, 2), (7, 5), (5000, 1)):  # (runs of 1 ... 5 members: dozens of runs through the writer's queue)
+        out = tmp_path / f"o{per}.bam"
+        r = subprocess.run([wexe, str(tmp_path / "in.sam"), str(out), str(per), str(run_members)], capture_output=True, text=True)
+        assert r.stdout.strip() == f"#records {n}", (per, r.stdout, r.stderr)
+        raw = out.read_bytes()
+        assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+        at, members = 0, 0
+        while at < len(raw):  # whole members, every one but the last two of 65 280 bytes of text
+            assert raw[at:at + 4] == b"\x1f\x8b\x08\x04" and raw[at + 12:at + 16] == b"BC\x02\x00"
+            at += struct.unpack_from("<H", raw, at + 16)[0] + 1
+            members += 1
+        assert at == len(raw) and members > 100
+        streams.append(gzip.decompress(raw))
+    assert streams[0] == streams[1] == streams[2] == streams[3] and streams[0][:4] == b"BAM\x01"
+    back = subprocess.run([rexe, str(tmp_path / "o7.bam"), str(1 << 20)], capture_output=True, text=True).stdout
+    got = [l.split("\t|", 1)[1] for l in back.split("\n") if "\t|" in l]
+    # what comes back is the line that went in, up to what BAM does not keep: sequence case, 'i' values as the smallest type
+    def norm(l):
+        f = l.split("\t")
+        f[9] = f[9].upper()
+        if f[6] == "=" and f[2] == "*":
+            f[6] = "*"  # "the same reference" of an unmapped read is no reference
+        return "\t".join(f)
+    assert len(got) == n and [norm(l) for l in got] == [norm(l) for l in lines]
+
+
 def test_log_rows_are_formatted_like_serde_json(tmp_path):
     """the CLI writes a hit's text row and its pretty JSON object directly (several host threads format the rows of a
     batch): the bytes must be what serde_json's pretty printer + the reference's re-indentation produce
