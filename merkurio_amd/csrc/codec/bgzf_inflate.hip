@@ -19,7 +19,7 @@ namespace mkz {
 
 static_assert(kPad >= kStreamPad, "input buffers carry the decoder's padding");
 
-// blockDim.x = the lanes of a wave that hold a member (8, 16, 32 or 64): LDS is sized for them at launch
+// blockDim.x = the lanes of a wave that hold a member (1, 2, 4 ... 64): LDS is sized for them at launch
 __global__ __launch_bounds__(64) void mk_bgzf_inflate_kernel(const uint8_t *__restrict__ in, uint64_t n_in, const Member *__restrict__ members,
                                                              uint32_t n_members, uint8_t *__restrict__ out, int32_t *__restrict__ status) {
     extern __shared__ uint32_t lanes[];
@@ -31,12 +31,14 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_kernel(const uint8_t *__re
 }
 
 // The lanes of a wave turn the decoder's loop together, so a wave is as slow as its slowest lane on every turn, and a launch
-// lasts as long as its slowest wave whatever it holds.  A call that does not fill the part's lanes is therefore spread over
-// MORE, NARROWER waves: the lockstep maximum is taken over fewer members and the waves of a SIMD fill each other's waits
-// (132 VGPRs: 3 waves per SIMD, 12 per CU).  Full waves only when there are members for all of them.
+// lasts as long as its slowest wave whatever it holds.  A call is therefore spread over as many waves as the part holds at
+// once (111 VGPRs: 4 waves per SIMD, 16 per CU, 4 096 on an MI355X) and each wave gets as FEW members as that allows -- down
+// to one: 4 012 members (256 MB of text) take 26 ms with one lane per wave, 48 ms with eight, and 64 lanes in lockstep cost
+// 2.3 x the single-lane latency of a member (profiles/r04_codec_inflate_steps.txt).  Full waves only when there are members
+// for all of them.
 uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
-    uint32_t lanes = 8;
-    while (lanes < 64 && (n_members + lanes - 1) / lanes > (uint32_t)num_cus * 12) lanes *= 2;
+    uint32_t lanes = 1;
+    while (lanes < 64 && (n_members + lanes - 1) / lanes > (uint32_t)num_cus * 16) lanes *= 2;
     return lanes;
 }
 

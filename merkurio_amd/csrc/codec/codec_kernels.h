@@ -42,7 +42,7 @@ void launch_pack(const uint8_t *slots, const uint32_t *slot_len, uint64_t *slot_
 
 // Inflate: member i of `in` -> out[out_off, out_off + isize); status[i] = 0 or an error code of inflate_serial.hpp.
 // `in` readable up to in + n_in + kPad.
-// (8 to 64 members per wave, by how many there are: inflate_lanes)
+// (1 to 64 members per wave, by how many there are: inflate_lanes)
 uint32_t inflate_lanes(uint32_t n_members, int num_cus);
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s);
