@@ -144,3 +144,24 @@ def test_a_large_window(setup):
     assert status == 0 and n_used == len(text) and wtext == text and len(keep) == 3000 * 150
     s0, r0, keep0, _, cnt0 = m.extract_fastq_text(unit, logging=False)
     assert keep == keep0 * 150 and cnt["extracted"] == cnt0["extracted"] * 150
+
+
+def test_fuzz_windows(setup):
+    """seeded: read flavours x member sizes x members per window x what comes back (whole text / tail + kept records) x logging / -v --
+    always the results of mk_extract_fastq_text on the same text"""
+    import os
+    rng, kmers, m, c = setup
+    for seed in range(int(os.environ.get("MERKURIO_FUZZ_BGZF", "24"))):
+        r = random.Random(500 + seed)
+        text = fastq(r, r.randrange(1, 1500), kmers, crlf=r.random() < 0.25, final_newline=r.random() < 0.7,
+                     lens=r.choice(((150,), (36, 75, 100, 151), (31, 32, 40), (250,))))
+        logging = r.random() < 0.6
+        invert = r.random() < 0.3
+        status, rec_start, keep0, rows0, cnt0 = m.extract_fastq_text(text, logging=logging, invert=invert)
+        assert status == 0
+        per_window, block = r.choice((1, 2, 5, 50, 10000)), r.choice((65280, r.randrange(600, 65281)))
+        whole = invert and logging or r.random() < 0.4
+        res = through_windows(m, c, text, per_window, block, whole_text=whole, logging=logging, invert=invert)
+        assert res[0] == keep0 and res[1] == rows0 and res[2] == cnt0, (seed, per_window, block, whole, logging, invert)
+        if not whole:
+            assert res[3] == b"".join(text[rec_start[i]:rec_start[i + 1]] for i in range(len(keep0)) if keep0[i]), seed
