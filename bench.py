@@ -614,6 +614,21 @@ def codec_configs(mk, megabytes=1024, reps=3):
     data = unit * max(1, megabytes * (1 << 20) // len(unit))
     codec = mk.Codec()
     out = []
+    # what the reference runs on its reader / writer threads, on one host core, on a 16 MB sample of the same text (zlib: the
+    # checker of the codec tests; the reference's flate2 backend is of the same class)
+    import zlib
+    sample = data[:256 * 65280]
+    t0 = time.perf_counter()
+    zs = []
+    for i in range(0, len(sample), 65280):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        zs.append(co.compress(sample[i:i + 65280]) + co.flush())
+    z_def = len(sample) / (time.perf_counter() - t0) / 1e6
+    t0 = time.perf_counter()
+    for z in zs:
+        zlib.decompress(z, -15)
+    z_inf = len(sample) / (time.perf_counter() - t0) / 1e6
+    z_ratio = len(sample) / (sum(map(len, zs)) + 26 * len(zs))
     try:
         best = None
         for _ in range(reps):
@@ -627,6 +642,8 @@ def codec_configs(mk, megabytes=1024, reps=3):
                     "kernel": "mk_bgzf_crc_kernel + mk_bgzf_deflate_kernel + mk_bgzf_pack_kernel", "kernel_ms": round(best[1], 2),
                     "ms_per_call": round(best[0] * 1e3, 1), "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1),
                     "text_gb_per_s_kernels": round(len(data) / best[1] / 1e6, 1), "compression_ratio": round(len(data) / len(blob), 2),
+                    "cpu_baseline": {"value": round(z_def / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib level 6, 65 280-byte members",
+                                     "compression_ratio": round(z_ratio, 2), "sample": "the first 16.7 MB of the same text"},
                     "bound": "latency (serial parse per member; not HBM, not MFMA)",
                     "frac": round((len(data) + len(blob)) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                     "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
@@ -641,6 +658,8 @@ def codec_configs(mk, megabytes=1024, reps=3):
         out.append({"workload": f"BGZF inflate (tag's BAM input): the {(len(data) + 65279) // 65280} members above -> {len(data) / 1e6:.0f} MB, CRC-32 checked",
                     "kernel": "mk_bgzf_inflate_kernel + mk_bgzf_crc_check_kernel", "kernel_ms": round(best[1], 2), "ms_per_call": round(best[0] * 1e3, 1),
                     "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1), "text_gb_per_s_kernels": round(len(data) / best[1] / 1e6, 1),
+                    "cpu_baseline": {"value": round(z_inf / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib inflate of its own level 6 members",
+                                     "sample": "the first 16.7 MB of the same text"},
                     "round_trip_equal": bool(text == data), "bound": "latency (one lane per member, 64 serial decoders per wave; not HBM, not MFMA)",
                     "frac": round((len(data) + len(blob)) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                     "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
