@@ -297,6 +297,28 @@ def test_windowed_sam_bam_reader(tmp_path, golden):
     assert ref["x.sam"] == want and ref["b.bam"] == want and ref["g.bam"] == want and ref["u.bam"] == want
     assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16)
     assert "#error Error during BAM record parsing: truncated file" in run_h("trunc.bam", 1 << 16, "prefetch")
+    # a window of >= 32 MB: the record chain is walked in pieces on all host threads (starts found by four consistent records in
+    # a row, every piece must end exactly on the next one's start) -- the same records as the serial walk of small windows;
+    # names / qualities that look like record headers do not derail it (a false start fails the validation: serial walk)
+    big = bytearray()
+    rnd2 = random.Random(3)
+    for i in range(180000):
+        L = rnd2.choice((36, 100, 151, 250))
+        name = (b"r%d" % i if i % 1000 else struct.pack("<i", 40) + b"xx") + b"\0"  # some names start like a block_size field
+        s_ = bytes(rnd2.choice(b"\x11\x12\x14\x18\x21\x22\x24\x28\x41\x42\x44\x48\x81\x82\x84\x88") for _ in range((L + 1) // 2))
+        rec = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, L, -1, -1, 0) + name + s_ + bytes([40] * L) + b"NMC\x03"
+        big += struct.pack("<i", len(rec)) + rec
+    raw_big = b"BAM\x01" + struct.pack("<i", len(ht)) + ht + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<I", 1000) + bytes(big)
+    assert len(raw_big) > 36 << 20
+    (tmp_path / "big.bam").write_bytes(raw_big)
+    o_par, o_ser = run_h("big.bam", 1 << 30), run_h("big.bam", 1 << 22)
+    assert o_par.rsplit("#windows", 1)[0] == o_ser.rsplit("#windows", 1)[0] and o_par.rsplit("#windows", 1)[1].split() == ["1", "records", "180000"]
+    (tmp_path / "bigtrunc.bam").write_bytes(raw_big[:-9])
+    assert "#error Error during BAM record parsing: truncated file" in run_h("bigtrunc.bam", 1 << 30)
+    broken = bytearray(raw_big)
+    broken[len(raw_big) // 2:len(raw_big) // 2 + 4] = struct.pack("<i", 7)  # a block_size < 32 in the middle (or inside a record: then nothing happens)
+    (tmp_path / "bigbroken.bam").write_bytes(bytes(broken))
+    assert run_h("bigbroken.bam", 1 << 30).rsplit("#windows", 1)[0] == run_h("bigbroken.bam", 1 << 22).rsplit("#windows", 1)[0]
 
 
 def test_bam_writer_pieces_queue_and_encoder(tmp_path):
