@@ -1096,8 +1096,12 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
                     {  // one allocation for the slice's output instead of a doubling series of copies
                         size_t est = 0;
                         for (size_t i = kept.size() * t / T; i < kept.size() * (t + 1) / T; ++i) est += sam.recs[b0 + kept[i]].len + 24 + a.tag.size();
-                        if (to_bam) out.bin[t].reserve(est);
-                        else out.txt[t].reserve(est);
+                        if (to_bam) {
+                            out.bin[t] = bw.take_buffer();  // (one the writer thread has written out, if there is one)
+                            out.bin[t].reserve(est);
+                        } else {
+                            out.txt[t].reserve(est);
+                        }
                     }
                     for (size_t i = kept.size() * t / T; i < kept.size() * (t + 1) / T; ++i) {
                         const size_t k = kept[i], g = b0 + k;

@@ -1322,6 +1322,14 @@ void BamWriter::put(const void *p, size_t n) {  // small writes (header, single 
     if (pieces_bytes >= (run_members + 1) * kBgzfBlock) flush(false);
 }
 
+std::vector<uint8_t> BamWriter::take_buffer() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (free_.empty()) return {};
+    std::vector<uint8_t> b = std::move(free_.back());
+    free_.pop_back();
+    return b;
+}
+
 void BamWriter::put_encoded(std::vector<uint8_t> &&bytes) {
     if (bytes.empty()) return;
     pieces_bytes += bytes.size();
@@ -1434,6 +1442,14 @@ void BamWriter::compress_and_write(Run &run_) {
             bail(std::string("Error writing BAM file: ") + mk_last_error());
         deflate_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (fwrite(z_.data(), 1, zn, f) != zn) bail("Error writing BAM file");
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (auto &p : run_)
+                if (p.capacity() >= (1u << 20) && free_.size() < 64) {
+                    p.clear();
+                    free_.push_back(std::move(p));
+                }
+        }
         run_.clear();
         return;
     }

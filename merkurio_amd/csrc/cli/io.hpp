@@ -279,6 +279,9 @@ struct BamWriter {
     // slow part of SAM -> BAM and runs on every host thread), then put_encoded() in record order
     void encode_record(const std::string &sam_line, std::vector<uint8_t> &dst) const;
     void put_encoded(std::vector<uint8_t> &&bytes);
+    // an empty buffer for the next slice of encoded records: one the writer thread is done with (its pages are mapped
+    // already: a fresh 16 MB vector costs 4 000 page faults), or a new one
+    std::vector<uint8_t> take_buffer();
     void close();
     double deflate_seconds = 0;  // inside the flush threads (timing mode)
     size_t run_members = 1536;   // members per run handed to the writer thread (100 MB of text: two rounds of the deflate kernel's waves)
@@ -300,6 +303,7 @@ struct BamWriter {
     std::thread writer_;
     bool closing_ = false, busy_ = false;
     std::exception_ptr failed_;
+    std::vector<std::vector<uint8_t>> free_;  // buffers of written runs (guarded by mu_)
 };
 
 }  // namespace cli
