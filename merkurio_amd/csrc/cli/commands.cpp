@@ -9,6 +9,7 @@
 
 #include <future>
 #include <memory>
+#include <mutex>
 
 #include <algorithm>
 #include <cstring>
@@ -1017,6 +1018,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         std::vector<std::vector<uint8_t>> bin;  // BAM output: per-thread encoded records, in order
         std::vector<std::string> txt;           // SAM output
     };
+    std::mutex txt_pool_mu;
+    std::vector<std::string> txt_pool;
     auto emit = [&](BatchOut &o) {  // (takes the batch's encoded records with it)
         if (lg.active)
             emit_log_rows(
@@ -1028,6 +1031,14 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
                 [&](const mk_row &) -> const std::string & { return in_name; });
         for (auto &b : o.bin) bw.put_encoded(std::move(b));  // moved, not copied: the pieces are joined on the device
         for (auto &t : o.txt) w.write(t);
+        {  // the text buffers go back to the encoder threads (pages mapped: a fresh one costs a fault per 4 KiB)
+            std::lock_guard<std::mutex> lk(txt_pool_mu);
+            for (auto &t : o.txt)
+                if (t.capacity() >= (1u << 20) && txt_pool.size() < 64) {
+                    t.clear();
+                    txt_pool.push_back(std::move(t));
+                }
+        }
     };
     // scan buffers of one device thread, reused by every batch of every window
     struct TagBuffers {
@@ -1100,6 +1111,13 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
                             out.bin[t] = bw.take_buffer();  // (one the writer thread has written out, if there is one)
                             out.bin[t].reserve(est);
                         } else {
+                            {
+                                std::lock_guard<std::mutex> lk(txt_pool_mu);
+                                if (!txt_pool.empty()) {
+                                    out.txt[t] = std::move(txt_pool.back());
+                                    txt_pool.pop_back();
+                                }
+                            }
                             out.txt[t].reserve(est);
                         }
                     }
