@@ -400,7 +400,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
     // from here on (the HIP runtime is up) the members of a bgzip'ed input are inflated by the device codec (mk_bgzf_inflate)
-    if (!a.host_codec) set_bgzf_device(devs[0]);
+    if (!a.host_codec) set_bgzf_device(devs[0], a.device_codec_always);
     tm.mark("matcher create (HIP init), remainder");
     // writers: src/cmd_extract.rs:297-318, :420-460
     Sink w1, w2;
@@ -982,7 +982,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
     // from here on (the HIP runtime is up) the BGZF members of a BAM window are inflated by the device codec (mk_bgzf_inflate)
-    if (!a.host_codec) set_bgzf_device(devs[0]);
+    if (!a.host_codec) set_bgzf_device(devs[0], a.device_codec_always);
     tm.mark("matcher (HIP init), remainder");
     if (out_ext != "sam" && out_ext != "bam" && out_ext != "STDOUT") bail("Output file must be a BAM or SAM file.");
     Sink w;

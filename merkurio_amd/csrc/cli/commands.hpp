@@ -29,6 +29,9 @@ struct CommonArgs {
     int window_mb = 1024;  // --window-mb: text (decompressed) read, indexed and held per window of an extract input
     int batch_mb = 128;  // --batch-mb: sequence bytes per GPU batch (tools/batch_mb.sh: 128-256 MB is fastest end to end)
     bool host_codec = false;   // --host-codec: BGZF members are deflated / inflated by zlib on the host threads instead of the device codec
+    bool device_codec_always = false;  // --device-codec-always: BGZF input goes through the device codec however few members a call holds (tests: the
+                                       // reference's own small BAM / bgzip'ed fixtures through mk_bgzf_inflate)
+    bool window_mb_given = false;      // --window-mb was on the command line (its default does not bind the paths that keep the text on the device)
     bool host_ingest = false;  // --host-ingest: extract parses FASTQ records on the host threads even where the device could index them
 };
 

@@ -132,23 +132,35 @@ static int g_bgzf_device = -1;
 static std::mutex g_bgzf_mu;
 static mk_codec *g_bgzf_codec = nullptr;
 static double g_bgzf_device_seconds = 0;
-void set_bgzf_device(int device) { g_bgzf_device = mk_bgzf_inflate ? device : -1; }
+static size_t g_bgzf_device_min_members = 0;  // set below
+void set_bgzf_device(int device, bool always);
 double bgzf_device_seconds() { return g_bgzf_device_seconds; }
 // A launch of the inflate kernel takes 35-60 ms whether it holds 64 members or 49 152 (one lane per member, bound by
 // the latency of a lane's serial decode: profiles/r04_codec_kernels.txt); zlib on 16 host threads inflates ~4 GB/s.
 // Below ~0.5 GB of text per call the host threads are done first (extract's 128 MB raw windows: 0.63-0.70 s on the
 // host, 0.89-0.91 s through the device: profiles/r04_e2e_extract_bgzf.txt).
 constexpr size_t kDeviceInflateMinMembers = 8192;
+void set_bgzf_device(int device, bool always) {
+    g_bgzf_device = mk_bgzf_inflate ? device : -1;
+    g_bgzf_device_min_members = always ? 1 : kDeviceInflateMinMembers;
+}
 
 // inflates members [m0, m1) into out + (member.out_off - mem[m0].out_off): on the device (one lane per member,
 // mk_bgzf_inflate: stream errors, ISIZE and CRC-32 checked there) or on the host threads
 static void bgzf_inflate_range(const uint8_t *d, const std::vector<BgzfMember> &mem, size_t m0, size_t m1, char *out,
                                const std::string &path) {
     const size_t cnt = m1 - m0;
-    if (g_bgzf_device >= 0 && cnt >= kDeviceInflateMinMembers) {
+    // (a device-side failure that is not about the data -- no memory for a third set of codec buffers next to the matcher's
+    // and the BAM writer's, a lost device -- is no reason to give up on an input zlib can read: said once, then the host path)
+    auto device_gave_up = [&](const char *what) {
+        fprintf(stderr, "Warning: BGZF input is inflated on the host threads from here on (%s: %s)\n", what, mk_last_error());
+        g_bgzf_device = -1;
+    };
+    std::unique_lock<std::mutex> lock(g_bgzf_mu);
+    if (g_bgzf_device >= 0 && cnt >= g_bgzf_device_min_members && !g_bgzf_codec && mk_codec_create(g_bgzf_device, &g_bgzf_codec) != MK_OK)
+        device_gave_up("mk_codec_create");
+    if (g_bgzf_device >= 0 && cnt >= g_bgzf_device_min_members) {
         const auto t0 = std::chrono::steady_clock::now();
-        std::lock_guard<std::mutex> lock(g_bgzf_mu);
-        if (!g_bgzf_codec && mk_codec_create(g_bgzf_device, &g_bgzf_codec) != MK_OK) bail(std::string("Error while decompressing ") + path + ": " + mk_last_error());
         const size_t base = mem[m0].out_off, in_lo = mem[m0].data_off;
         std::vector<mk_bgzf_member> tab(cnt);
         uint64_t text = 0, in_hi = in_lo;
@@ -161,10 +173,13 @@ static void bgzf_inflate_range(const uint8_t *d, const std::vector<BgzfMember> &
         uint64_t bad = 0;
         const int rc = mk_bgzf_inflate(g_bgzf_codec, d + in_lo, in_hi - in_lo, tab.data(), cnt, (uint8_t *)out, text, &bad);
         if (rc == MK_E_CORRUPT) bail("Error while decompressing " + path);
-        if (rc != MK_OK) bail(std::string("Error while decompressing ") + path + ": " + mk_last_error());
-        g_bgzf_device_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return;
+        if (rc == MK_OK) {
+            g_bgzf_device_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            return;
+        }
+        device_gave_up("mk_bgzf_inflate");
     }
+    lock.unlock();
     const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), cnt / 16 + 1));
     const size_t base = mem[m0].out_off;
     run_threads(T, [&](size_t t) {
@@ -1586,7 +1601,11 @@ void put_le(std::vector<uint8_t> &r, T v) {
 
 void BamWriter::encode_record(const std::string &line, std::vector<uint8_t> &dst) const {
     Field fld[11];
-    std::vector<Field> more;  // optional fields (no allocation until a record has more than the vector's capacity keeps)
+    // optional fields: the first 32 in place (every tagged record has at least one: a local vector allocated per record),
+    // a vector only for a record with more
+    Field opt[32];
+    std::vector<Field> opt_more;
+    size_t n_opt = 0;
     size_t nf = 0;
     {
         const char *d = line.data();
@@ -1596,7 +1615,8 @@ void BamWriter::encode_record(const std::string &line, std::vector<uint8_t> &dst
             const void *t = b <= n ? memchr(d + b, '\t', n - b) : nullptr;
             const size_t e = t ? (size_t)((const char *)t - d) : n;
             if (nf < 11) fld[nf] = Field{d + b, e - b};
-            else more.push_back(Field{d + b, e - b});
+            else if (n_opt < 32) opt[n_opt++] = Field{d + b, e - b};
+            else opt_more.push_back(Field{d + b, e - b}), ++n_opt;
             ++nf;
             if (!t) break;
             b = e + 1;
@@ -1663,7 +1683,8 @@ void BamWriter::encode_record(const std::string &line, std::vector<uint8_t> &dst
             for (int32_t i = 0; i < l_seq; ++i) o[i] = (uint8_t)(q[i] - 33);
         }
     }
-    for (const Field &t : more) {  // TAG:TYPE:VALUE
+    for (size_t ti = 0; ti < n_opt; ++ti) {  // TAG:TYPE:VALUE
+        const Field &t = ti < 32 ? opt[ti] : opt_more[ti - 32];
         if (t.n < 5 || t.p[2] != ':' || t.p[4] != ':') bail("Error writing record to output file: bad optional field");
         r.insert(r.end(), (const uint8_t *)t.p, (const uint8_t *)t.p + 2);
         const char type = t.p[3];

@@ -24,7 +24,7 @@ unsigned io_threads();
 void set_io_threads_cap(unsigned n);
 // BGZF input (BAM, bgzip'ed FASTA/FASTQ) is inflated by the device codec on this HIP device from now on (windows of at
 // least a few hundred members; < 0: zlib on the host threads); seconds spent in those calls so far
-void set_bgzf_device(int device);
+void set_bgzf_device(int device, bool always = false);
 double bgzf_device_seconds();
 
 // runs fn(t) for t in [0, T) on T host threads; the first cli::Error is re-raised on the caller

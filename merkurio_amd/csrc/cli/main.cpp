@@ -22,7 +22,7 @@ const Spec kCommon[] = {{'s', "kmer-seq", 2},      {'f', "kmer-file", 1},    {'r
                         {'l', "out-log", 3},       {'j', "json-log", 3},     {'S', "suppress-output", 0},    {'v', "invert-match", 0},
                         {'I', "case-insensitive", 0}, {'L', "lowercase", 0}, {'U', "uppercase", 0},          {'q', "q-size", 1},
                         {'a', "aho-corasick", 0},  {0, "device", 1},         {0, "batch-mb", 1},           {0, "gpus", 1},                 {0, "window-mb", 1},
-                        {0, "host-ingest", 0},     {0, "host-codec", 0}};
+                        {0, "host-ingest", 0},     {0, "host-codec", 0},     {0, "device-codec-always", 0}};
 const Spec kExtract[] = {{'i', "in-fastx", 1}, {'1', "in-fastx", 1}, {'2', "in-fastq-2", 1}, {'o', "out-fastx", 1}};
 const Spec kTag[] = {{'i', "in-file", 1}, {'o', "out-file", 1}, {'t', "tag", 1}, {'p', "threads", 1}, {'m', "filter-matching", 0}};
 
@@ -51,14 +51,16 @@ void print_help(const char *sub) {
              "      --batch-mb <MB>          sequence bytes per GPU batch [128]\n"
              "      --window-mb <MB>         input text read and held per window [1024]\n"
              "      --host-ingest            parse FASTQ records on the host threads (default: a single FASTQ input is indexed on the GPU)\n"
-             "      --host-codec             bgzip'ed input inflated by zlib on the host threads (default: on the GPU)");
+             "      --host-codec             bgzip'ed input inflated by zlib on the host threads (default: on the GPU)\n"
+             "      --device-codec-always    BGZF members go through the GPU codec however few they are (default: from 8192 members per call)");
     } else {
         puts("Usage: merkurio tag [OPTIONS] --in-file <IN_FILE> <--kmer-seq <KMER_SEQ>...|--kmer-file <KMER_FILE>>\n\n"
              "  -i, --in-file <PATH>         SAM/BAM input\n  -o, --out-file <PATH>        SAM output (stdout if absent)\n"
              "  -s, --kmer-seq <SEQ>... | -f, --kmer-file <PATH>\n  -t, --tag <TAG>              two-character tag [km]\n"
              "  -m, --filter-matching        keep only records with a hit\n  -v, --invert-match           keep only records without a hit\n"
              "  -p, --threads <N>            at most N host threads for the BAM/SAM codec work [all cores]\n  -r -c -l -j -S -I -L -U -q -a --device --gpus --batch-mb  as for extract\n"
-             "      --host-codec             BGZF members deflated by zlib on the host threads (default: on the GPU)");
+             "      --host-codec             BGZF members deflated by zlib on the host threads (default: on the GPU)\n"
+             "      --device-codec-always    BGZF input inflated on the GPU however few members a window holds");
     }
 }
 
@@ -180,6 +182,8 @@ void fill_common(const Parsed &p, CommonArgs &c, bool has_out) {
     if (auto v = p.get("batch-mb")) c.batch_mb = (int)std::max<size_t>(1, to_num((*v)[0], "--batch-mb"));
     if (p.get("host-ingest")) c.host_ingest = true;
     if (p.get("host-codec")) c.host_codec = true;
+    if (p.get("device-codec-always")) c.device_codec_always = true;
+    c.window_mb_given = p.get("window-mb") != nullptr;
     // clap ArgGroups (src/cmd_extract.rs:33-62, src/cmd_tag.rs:29-66)
     if (c.kmer_seq.empty() == !c.kmer_file) {
         if (c.kmer_file)
@@ -201,7 +205,12 @@ void fill_common(const Parsed &p, CommonArgs &c, bool has_out) {
 // the process leaves without running the HIP runtime's exit handlers and the destructors of a job that is over --
 // 0.15 s of a 0.6 s run on 20 M reads (profiles/r04_e2e_extract.txt).  Errors take the ordinary way out.
 static int leave(int rc) {
-    fflush(stdout);
+    // (the exit handlers are skipped: this flush is the last chance to notice records or log text on stdout that hit
+    // ENOSPC / EPIPE -- such a run must not end with status 0)
+    if (fflush(stdout) != 0 || ferror(stdout)) {
+        fprintf(stderr, "Error: writing to standard output failed\n");
+        if (rc == 0) rc = 1;
+    }
     fflush(stderr);
     if (rc == 0) _exit(0);
     return rc;

@@ -197,7 +197,19 @@ int mk_bgzf_members(const uint8_t *in, uint64_t n, mk_bgzf_member *members, uint
         uint32_t crc, isize;
         memcpy(&crc, h + size - 8, 4), memcpy(&isize, h + size - 4, 4);
         if (isize > 65536) return mk::fail(MK_E_CORRUPT, "BGZF member with ISIZE %u at byte %llu", isize, (unsigned long long)at);
-        if (members && k < cap) members[k] = mk_bgzf_member{at + 12 + xlen, text, (uint32_t)(size - 12 - xlen - 8), isize, crc, 0};
+        // RFC 1952's optional fields between the extra field and the DEFLATE stream (bgzip sets none of them, a gzip member
+        // that carries a BC subfield may): FNAME / FCOMMENT are zero-terminated, FHCRC is two bytes; reserved bits refuse
+        uint64_t skip = 12 + (uint64_t)xlen;
+        if (h[3] & 0xE0) return mk::fail(MK_E_UNSUPPORTED, "gzip member with reserved FLG bits (0x%02x) at byte %llu", h[3], (unsigned long long)at);
+        for (int bit = 3; bit <= 4; ++bit)
+            if (h[3] & (1 << bit)) {
+                const void *z = skip < size - 8 ? memchr(h + skip, 0, (size_t)(size - 8 - skip)) : nullptr;
+                if (!z) return mk::fail(MK_E_CORRUPT, "gzip member with an unterminated %s at byte %llu", bit == 3 ? "FNAME" : "FCOMMENT", (unsigned long long)at);
+                skip = (uint64_t)((const uint8_t *)z - h) + 1;
+            }
+        if (h[3] & 2) skip += 2;
+        if (skip + 8 > size) return mk::fail(MK_E_CORRUPT, "BGZF member whose header fields overrun BSIZE at byte %llu", (unsigned long long)at);
+        if (members && k < cap) members[k] = mk_bgzf_member{at + skip, text, (uint32_t)(size - skip - 8), isize, crc, 0};
         ++k, text += isize, at += size;
     }
     *n_members = k;

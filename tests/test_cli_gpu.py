@@ -98,12 +98,18 @@ def test_extract_paired(golden, tmp_path):
     ("simple", "simple.sam", ["-m"], "simple.extracted.sam"),
     ("simple-inv", "simple.sam", ["-v"], "simple-inv.extracted.sam"),
     ("simple-bam", "simple.bam", [], "simple.tagged.extracted.sam"),
+    # the reference's BAM through the DEVICE inflater (by default its two members stay below the threshold and take zlib)
+    ("simple-bam", "simple.bam", ["--device-codec-always"], "simple.tagged.extracted.sam"),
+    ("simple-bam", "simple.bam", ["--host-codec"], "simple.tagged.extracted.sam"),
 ])
 def test_tag_fixtures(golden, tmp_path, name, inp, extra, out):
     fx = os.path.join(golden, "fixtures")
     o = tmp_path / "out.sam"
-    run(["tag", "-i", os.path.join(fx, "input", inp), "-o", str(o), "-s", "CTC", "-r", "-l", str(tmp_path / "x.log"), "-j",
-         str(tmp_path / "x.json"), "-p", "2", *extra])
+    p = subprocess.run([BIN, "tag", "-i", os.path.join(fx, "input", inp), "-o", str(o), "-s", "CTC", "-r", "-l", str(tmp_path / "x.log"), "-j",
+                        str(tmp_path / "x.json"), "-p", "2", *extra], capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    # (timing mode says whether the device codec inflated anything)
+    assert (b"BGZF inflate calls of the device codec" in p.stderr) == ("--device-codec-always" in extra)
     assert sam_without_own_pg(o) == sam_without_own_pg(os.path.join(fx, "tag", out))
     own = [ln for ln in o.read_bytes().split(b"\n") if ln.startswith(b"@PG\tID:merkurio")]
     assert len(own) == 1 and own[0].startswith(b"@PG\tID:merkurio\tPN:merkurio\tCL:") and b"\tVN:" in own[0]
@@ -117,9 +123,10 @@ def test_tag_fixtures(golden, tmp_path, name, inp, extra, out):
 def test_tag_aho_corasick_vector(golden, tmp_path):
     """tests/fixtures/extract/log.json: tag -i simple.bam -S -s CTC AC CT AA T A C G GA AG -r -j log.json"""
     fx = os.path.join(golden, "fixtures")
-    run(["tag", "-i", os.path.join(fx, "input/simple.bam"), "-S", "-s", "CTC", "AC", "CT", "AA", "T", "A", "C", "G", "GA", "AG", "-r",
-         "-j", str(tmp_path / "log.json")])
-    check_json(tmp_path / "log.json", os.path.join(fx, "extract/log.json"))
+    for extra in ([], ["--device-codec-always"]):
+        run(["tag", "-i", os.path.join(fx, "input/simple.bam"), "-S", "-s", "CTC", "AC", "CT", "AA", "T", "A", "C", "G", "GA", "AG", "-r",
+             "-j", str(tmp_path / "log.json"), *extra])
+        check_json(tmp_path / "log.json", os.path.join(fx, "extract/log.json"))
 
 
 def test_example_minimal_stdout(golden):

@@ -7,6 +7,7 @@ and ISIZE are checked field by field (bit-exact text; the compressed bytes are t
 inflate: members written by zlib at every level / strategy, and by the device, come back byte for byte; damaged members
 are refused with MK_E_CORRUPT and the index of the first one."""
 import gzip
+import os
 import random
 import struct
 import zlib
@@ -232,3 +233,77 @@ def test_fuzz_both_directions(codec):
                          {"level": rng.randrange(1, 10), "flush_every": rng.randrange(50, 20000)}))
         zb = zlib_bgzf(data, rng.randrange(1, 65281) if rng.random() < 0.3 else 65280, **kw)
         assert codec.inflate(zb) == data, (seed, "zlib -> device inflate", kw)
+
+
+# ---- members the REFERENCE holds (r05): every other test here inflates members this suite wrote itself (zlib or the device) ----
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sam_records_of_bam(raw):
+    """(header text, [SAM fields decoded from the binary records]) of an inflated BAM stream -- just enough of SAM spec 4.2
+    to compare with the reference's simple.sam: QNAME FLAG POS MAPQ SEQ"""
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", raw, at)[0]
+        at += 4 + l_name + 4
+    recs = []
+    while at < len(raw):
+        bs = struct.unpack_from("<i", raw, at)[0]
+        r = raw[at + 4:at + 4 + bs]
+        at += 4 + bs
+        _, pos, l_name, mapq, _, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHi", r, 0)
+        name = r[32:32 + l_name - 1]
+        sq = r[32 + l_name + 4 * n_cig:]
+        seq = bytes(b"=ACMGRSVTWYHKDBN"[(sq[k >> 1] >> (4 if k % 2 == 0 else 0)) & 15] for k in range(l_seq))
+        recs.append((name, flag, pos + 1, mapq, seq))
+    return text, recs
+
+
+def test_reference_bam_fixture_through_the_device_inflater(codec):
+    """tests/fixtures/input/simple.bam (the reference's only BAM; in the CLI its 2 members stay below the device threshold and
+    take zlib): walked by mk_bgzf_members, inflated by mk_bgzf_inflate, compared with zlib's text AND with the records of the
+    reference's own simple.sam (src/cmd_tag.rs:1095-1132 reads this pair)"""
+    blob = open(os.path.join(GOLDEN, "fixtures/input/simple.bam"), "rb").read()
+    mem, used, text = mk.bgzf_members(blob)
+    assert used == len(blob) and len(mem) == 2 and int(mem[1]["isize"]) == 0  # one data member + the end-of-file marker
+    raw = codec.inflate(blob)
+    assert raw == gzip.decompress(blob) and len(raw) == text
+    header, recs = _sam_records_of_bam(raw)
+    sam = open(os.path.join(GOLDEN, "fixtures/input/simple.sam"), "rb").read().split(b"\n")
+    sam_recs = [ln.split(b"\t") for ln in sam if ln and not ln.startswith(b"@")]
+    assert [(f[0], int(f[1]), int(f[3]), int(f[4]), f[9]) for f in sam_recs] == recs and len(recs) == 3
+    assert [ln for ln in header.split(b"\n") if ln.startswith(b"@SQ")] == [ln for ln in sam if ln.startswith(b"@SQ")]
+
+
+def test_reference_gzip_fixture_through_the_device_inflater(codec):
+    """tests/data/sample.fasta.gz (needletail's gzip reader, src/cmd_extract.rs:281): one gzip member with FNAME, written by
+    gzip(1) -- no BC subfield, so the member table is built here from RFC 1952's fields; the DEFLATE stream itself is the
+    reference's bytes.  The text must be the reference's sample.fasta."""
+    blob = open(os.path.join(GOLDEN, "data/sample.fasta.gz"), "rb").read()
+    assert blob[:3] == b"\x1f\x8b\x08" and blob[3] == 0x08  # FNAME only
+    data_off = blob.index(b"\0", 10) + 1
+    crc, isize = struct.unpack_from("<II", blob, len(blob) - 8)
+    mem = np.zeros(1, dtype=mk.MEMBER_DTYPE)
+    mem[0]["data_off"], mem[0]["out_off"], mem[0]["data_len"], mem[0]["isize"], mem[0]["crc"] = data_off, 0, len(blob) - 8 - data_off, isize, crc
+    text = codec.inflate(blob, mem, isize)
+    assert text == open(os.path.join(GOLDEN, "data/sample.fasta"), "rb").read() == gzip.decompress(blob)
+    # ... and as BGZF written by the device from that text: walked and inflated again, still the reference's file
+    again = codec.deflate(text, 500)
+    assert codec.inflate(again) == text and gzip.decompress(again + mk.bgzf_eof()) == text
+    # a gzip member that carries BC *and* FNAME / FCOMMENT / FHCRC: mk_bgzf_members skips the optional fields (r04 ADVICE)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    payload = co.compress(text) + co.flush()
+    for flg, fields in ((4 | 8, b"name.fa\0"), (4 | 16, b"a comment\0"), (4 | 8 | 16, b"n\0c\0"), (4 | 2, b"\x12\x34"), (4 | 2 | 8 | 16 | 1, b"n\0c\0\x12\x34")):
+        bsize = 18 + len(fields) + len(payload) + 8 - 1
+        m = bytes([0x1f, 0x8b, 8, flg, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", bsize) + fields + payload + \
+            struct.pack("<II", zlib.crc32(text), len(text))
+        tab, used, n_text = mk.bgzf_members(m)
+        assert used == len(m) and n_text == len(text) and int(tab[0]["data_off"]) == 18 + len(fields)
+        assert codec.inflate(m) == text
+    with pytest.raises(mk.MerkurioError):
+        mk.bgzf_members(bytes([0x1f, 0x8b, 8, 4 | 0x20]) + m[4:])
