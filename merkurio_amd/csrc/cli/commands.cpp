@@ -973,6 +973,10 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
 
     SamFile sam;
     try {
+        if (a.device_codec_always && !a.host_codec) {  // (the header's members too: the HIP runtime has to be up first)
+            fm.wait();
+            set_bgzf_device(devs[0], true);
+        }
         sam.open(a.in_file);  // "Input file must be a BAM or SAM file." for other extensions; header only
     } catch (...) {
         fm.get();  // a matcher error comes first, as in the serial order of the reference

@@ -265,12 +265,12 @@ def _sam_records_of_bam(raw):
 
 
 def test_reference_bam_fixture_through_the_device_inflater(codec):
-    """tests/fixtures/input/simple.bam (the reference's only BAM; in the CLI its 2 members stay below the device threshold and
+    """tests/fixtures/input/simple.bam (the reference's only BAM; in the CLI its 3 members stay below the device threshold and
     take zlib): walked by mk_bgzf_members, inflated by mk_bgzf_inflate, compared with zlib's text AND with the records of the
     reference's own simple.sam (src/cmd_tag.rs:1095-1132 reads this pair)"""
     blob = open(os.path.join(GOLDEN, "fixtures/input/simple.bam"), "rb").read()
     mem, used, text = mk.bgzf_members(blob)
-    assert used == len(blob) and len(mem) == 2 and int(mem[1]["isize"]) == 0  # one data member + the end-of-file marker
+    assert used == len(blob) and len(mem) == 3 and int(mem[2]["isize"]) == 0  # header member, record member, end-of-file marker
     raw = codec.inflate(blob)
     assert raw == gzip.decompress(blob) and len(raw) == text
     header, recs = _sam_records_of_bam(raw)
