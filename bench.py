@@ -350,6 +350,7 @@ def main():
     reduce_counters()  # hit-count / summary vector (RCCL over xGMI), once per job
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -357,6 +358,22 @@ def main():
     kernel_ms = m.kernel_times_ms()
     cnt = d_cnt.cpu().numpy()
     summ = cnt[len(patterns):]
+    # what every rank saw of its own shard (N > 1: gathered on rank 0 -- the first real multi-GPU run should say which rank
+    # sat on which device, what its kernel took and how many ranks RCCL counted in its communicator)
+    comm_ranks = None
+    if reduce_via.startswith("mk_comm"):
+        import ctypes
+        seen_n = ctypes.c_int(0)
+        mk._check(lib.mk_comm_size(m.handle, ctypes.byref(seen_n)))
+        comm_ranks = seen_n.value
+    mine = {"rank": rank, "local_rank": local_rank, "device": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
+            "records": n_rec, "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+            "kernel_ms_max": round(float(np.max(kernel_ms)), 4), "step_wall_ms_this_rank": round(dt_local / args.steps * 1e3, 4),
+            "ncclCommCount": comm_ranks}
+    per_rank = [mine]
+    if use_dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         total_bases = (n_bytes * world if args.ragged else total * L) * n_mates * args.steps
@@ -418,6 +435,7 @@ def main():
                                             note="mk_order_hits_device: histogram + scatter + LDS sort per bin, inside the timed step")
             # the scan and the ordering together against the same algorithmic bytes
             out["roofline"]["frac_scan_plus_order"] = round(algo_bytes / ((k_avg_ms + o_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["ranks"] = per_rank
         if rehearsal:
             out["rehearsal"] = True
             out["rehearsal_note"] = f"{world} ranks share {n_dev} GPU(s): functional check, not a scaling measurement"
@@ -425,16 +443,141 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.paired and not args.ragged:
             out["cpu_baseline"] = cpu_baseline(mk, m, patterns, seed, n_rec, L, args.plant_every, mates[0][2],
                                                args.cpu_seconds)
-        default_workload = (args.records, L, args.patterns, args.k, args.mode, args.plant_every, args.rc) == \
-            (100_000_000, 150, 10_000, 31, "any", 100, False) and options is None
+        default_workload = default_workload_flag(args, options)
         if world == 1 and default_workload and not (args.no_other_configs or args.paired or args.ragged or args.with_offsets):
             out["other_configs"] = other_configs(mk, lib, torch, dev, dev_index, m, mates[0], n_rec, L, seed, st)
+    if world > 1 and default_workload_flag(args, options) and not (args.no_other_configs or args.paired or args.ragged or args.with_offsets):
+        # BASELINE's multi-GPU configurations next to the headline (every rank takes part; rank 0 reports): config 3
+        # (paired, pairs unsplit) and config 5 (500 k 21-mers, level-1 filter in global memory), one shard per rank
+        del mates, d_keep
+        torch.cuda.empty_cache()
+        # (these extra runs hold collectives of their own; whatever happens in them, the headline line must reach the driver:
+        # if they have not come back after three minutes, rank 0 prints the line without them and the job ends)
+        import threading
+
+        def give_up():
+            out["other_configs"] = "not finished within 180 s: the headline above stands on its own"
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(180.0, give_up) if rank == 0 else None
+        if watchdog:
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            oc = other_configs_multi(mk, lib, torch, dist if use_dist else None, rehearsal, dev, dev_index, m, rank, world, seed, st, barrier)
+        except Exception as e:  # this rank's failure is reported; its peers meet the watchdog
+            oc = f"failed on rank {rank}: {e!r}"
+        if watchdog:
+            watchdog.cancel()
+        if rank == 0:
+            out["other_configs"] = oc
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()
         if reduce_via.startswith("mk_comm"):  # every rank is past its last collective: drop the C ABI's communicator now,
             lib.mk_comm_destroy(m.handle)     # not at interpreter exit
         dist.destroy_process_group()
+
+
+def default_workload_flag(args, options):
+    return (args.records, args.read_len, args.patterns, args.k, args.mode, args.plant_every, args.rc, args.scaling) == \
+        (100_000_000, 150, 10_000, 31, "any", 100, False, "weak") and options is None
+
+
+def other_configs_multi(mk, lib, torch, dist, rehearsal, dev, dev_index, m0, rank, world, seed, st, barrier, steps=5, warmup=2):
+    """N > 1: BASELINE's own multi-GPU configurations, weak-scaled like the headline (every rank one 8-GPU-job shard):
+    config 3 -- extract paired, 2 x 6.25 M x 150 bp mates per rank, the headline's 10 k 31-mers, a pair is kept if either mate
+    hits, pairs never split; config 5 -- 12.5 M x 250 bp per rank, 500 k 21-mers (level-1 filter in global memory).
+    Same contract as the headline: barrier + synchronize on both sides, the slowest rank's wall time, aggregate bases over
+    all ranks; per-rank kernel times gathered next to it."""
+    import numpy as np
+    res = []
+
+    def timed(step, m, launches):
+        for _ in range(warmup):
+            step()
+        barrier()
+        m.enable_timing(launches * steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        k = m.kernel_times_ms()
+        mine = {"rank": rank, "device": dev_index, "kernel_ms_avg": round(float(np.mean(k)), 4), "wall_ms_per_step": round(dt / steps * 1e3, 4)}
+        allr = [mine]
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+        return dt, allr
+
+    def entry(label, m, n_rec, L, launches, dt, allr, extra):
+        algo = n_rec * L + 9 * n_rec
+        k_ms = float(np.mean([r["kernel_ms_avg"] for r in allr]))
+        r = {"workload": label, "n_gpus": world, "scaling": "weak", "kernel": m.kernel_name, "steps": steps, "launches_per_step": launches,
+             "ms_per_step": round(dt / steps * 1e3, 4), "value_gbases_per_s": round(launches * n_rec * L * world * steps / dt / 1e9, 1),
+             "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": algo, "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "job_frac_of_n_x_peak": round(launches * algo * world * steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4), "ranks": allr,
+             "traffic": None, "traffic_source": "multi-GPU run: no PMC pass"}
+        r.update(extra)
+        res.append(r)
+
+    # ---- config 3: this rank's pairs [rank * n3, (rank + 1) * n3) of the job's two mate files
+    n3, L3 = 6_250_000, 150
+    pair = []
+    for f in range(2):
+        d_seq = torch.empty(n3 * L3 + 64, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n3 + 1, dtype=torch.int64, device=dev)
+        d_flags = torch.empty((n3 + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+        mk._check(lib.mk_synth_reads_device_range(m0.handle, seed + 20 + f, rank * n3, n3, L3, 100, d_seq.data_ptr(), d_off.data_ptr(), st))
+        pair.append((d_seq, d_off, d_flags))
+    d_keep = torch.empty_like(pair[0][2])
+    d_nh = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_cnt = torch.zeros(len(m0.patterns) + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+    mk._check(lib.mk_matcher_set_fixed_record_length(m0.handle, L3))
+    mk._check(lib.mk_matcher_hint_hit_density(m0.handle, 10))
+
+    def step3():
+        for d_seq, d_off, d_flags in pair:
+            mk._check(lib.mk_scan_device(m0.handle, d_seq.data_ptr(), n3 * L3, d_off.data_ptr(), n3, mk.MK_MODE_ANY, d_flags.data_ptr(), None, 0,
+                                         d_nh.data_ptr(), d_cnt.data_ptr(), st))
+        torch.bitwise_or(pair[0][2], pair[1][2], out=d_keep)
+
+    dt, allr = timed(step3, m0, 2)
+    kept = torch.tensor([int(d_keep[:n3].sum().item())], dtype=torch.int64, device="cpu" if (rehearsal or dist is None) else dev)
+    if dist is not None:
+        dist.all_reduce(kept)
+    entry(f"config 3: extract paired, 2 x {n3 * world} x {L3} bp mates in the job ({n3} pairs per GPU), {len(m0.patterns)} 31-mers, any-hit flags, "
+          "pair kept if either mate hits, pairs unsplit", m0, n3, L3, 2, dt, allr, {"pairs_kept_in_the_job": int(kept.item())})
+    del pair, d_keep
+
+    # ---- config 5: this rank's reads of the 100 M x 250 bp job, 500 k 21-mers
+    n5, L5 = 12_500_000, 250
+    pats = mk.parse_pattern_list(kmer_seq=make_patterns(500_000, 21, seed=13))[:500_000]
+    m5 = mk.Matcher(pats, device=dev_index)
+    d_seq = torch.empty(n5 * L5 + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n5 + 1, dtype=torch.int64, device=dev)
+    d_flags = torch.empty((n5 + 7) // 4 * 4, dtype=torch.uint8, device=dev)
+    mk._check(lib.mk_synth_reads_device_range(m5.handle, seed + 7, rank * n5, n5, L5, 100, d_seq.data_ptr(), d_off.data_ptr(), st))
+    d_cnt5 = torch.zeros(len(pats) + mk.MK_NUM_SUMMARY, dtype=torch.int64, device=dev)
+    mk._check(lib.mk_matcher_set_fixed_record_length(m5.handle, L5))
+    mk._check(lib.mk_matcher_hint_hit_density(m5.handle, 10))
+
+    def step5():
+        mk._check(lib.mk_scan_device(m5.handle, d_seq.data_ptr(), n5 * L5, d_off.data_ptr(), n5, mk.MK_MODE_ANY, d_flags.data_ptr(), None, 0,
+                                     d_nh.data_ptr(), d_cnt5.data_ptr(), st))
+
+    dt, allr = timed(step5, m5, 1)
+    entry(f"config 5: extract, {n5 * world} x {L5} bp in the job ({n5} reads per GPU), {len(pats)} 21-mers (level-1 filter in global memory), "
+          "any-hit flags", m5, n5, L5, 1, dt, allr, {"filter": dict(m5.filter_info(), **m5.filter_mode())})
+    m5.close()
+    return res
 
 
 def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, st, steps=5, warmup=2):

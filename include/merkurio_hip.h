@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 5
+#define MK_ABI_VERSION 6
 
 /* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
 #define MK_OK 0
@@ -280,6 +280,9 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
  * consecutive records, 2 bins on the top bits of the whole (record, end, pattern) key, 3 library merge sort; the number of
  * bins and the largest bin (paths 1 and 2) */
 int mk_matcher_order_info(const mk_matcher *m, uint32_t *path, uint32_t *n_bins, uint32_t *max_bin);
+/* (v6) how often each of those paths ran over the handle's life, driver-loop calls included: calls[p] for p = 0..3.  A host
+ * program can tell from calls[3] whether its data ever sent the ordering to the library sort. */
+int mk_matcher_order_stats(const mk_matcher *m, uint64_t calls[4]);
 
 /* name of the scan kernel variant the last mk_scan_device on this handle launched, and its
  * launch geometry (for profiling / roofline bookkeeping) */

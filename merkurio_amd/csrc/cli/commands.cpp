@@ -51,6 +51,25 @@ static void release_matchers(const std::vector<mk_matcher *> &ms) {
     for (mk_matcher *x : ms) mk_matcher_destroy(x);
 }
 
+// How the emission order of the job's hit tuples was restored (order_hits.hip): calls per path over all handles.  The
+// reference's JSON `meta_information` has a fixed key set (the fixture comparators check it), so this goes to stderr: in
+// timing mode always, and as a note whenever the library merge sort (path 3, the slow fallback for batches that defeat both
+// binnings) ran at all -- real data should tell whether it ever does.
+static void report_order_paths(const std::vector<mk_matcher *> &ms) {
+    uint64_t tot[4] = {0, 0, 0, 0};
+    for (mk_matcher *m : ms) {
+        uint64_t c4[4] = {0, 0, 0, 0};
+        if (m && mk_matcher_order_stats(m, c4) == MK_OK)
+            for (int k = 0; k < 4; ++k) tot[k] += c4[k];
+    }
+    if (getenv("MERKURIO_TIMING"))
+        fprintf(stderr, "[timing] emission-order calls: %llu without work, %llu on record bins, %llu on whole-key bins, %llu library sort\n",
+                (unsigned long long)tot[0], (unsigned long long)tot[1], (unsigned long long)tot[2], (unsigned long long)tot[3]);
+    if (tot[3])
+        fprintf(stderr, "Note: %llu of %llu emission-order calls fell back to the library merge sort (hit tuples that defeat both binnings)\n",
+                (unsigned long long)tot[3], (unsigned long long)(tot[1] + tot[2] + tot[3]));
+}
+
 static void mk_check(int rc, const char *what) {
     if (rc != MK_OK) bail(std::string(what) + ": " + mk_last_error());
 }
@@ -902,6 +921,7 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     if (tm.on && (call_ms[0] + call_ms[1] + call_ms[2] + call_ms[3]) > 0)
         fprintf(stderr, "[timing] inside the batch calls: upload %.3f s, device %.3f s, download %.3f s, host loop %.3f s\n", call_ms[0] * 1e-3,
                 call_ms[1] * 1e-3, call_ms[2] * 1e-3, call_ms[3] * 1e-3);
+    report_order_paths(ms);
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, paired);
@@ -1218,6 +1238,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         fprintf(stderr, "[timing] BGZF deflate on its own threads (%s): %.3f s\n", a.host_codec ? "zlib, host" : "device codec", bw.deflate_seconds);
     if (getenv("MERKURIO_TIMING") && bgzf_device_seconds() > 0)
         fprintf(stderr, "[timing] BGZF inflate calls of the device codec (inside the window reads): %.3f s\n", bgzf_device_seconds());
+    report_order_paths(ms);
     if (lg.active) {
         lg.text.flush();
         write_summary(lg.text, pats, counts, c, false);

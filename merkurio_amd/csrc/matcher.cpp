@@ -782,7 +782,14 @@ int mk_order_hits_device(mk_matcher *m, void *d_hits, uint64_t n_hits, void *str
 
 // ac: Aho-Corasick emission order; !ac: (record, pattern, position) -- BNDMq's emission order and, for any matcher,
 // the order in which a record's distinct patterns are adjacent and ascending (sets.hip)
+static int order_hits_on_device_impl(mk_matcher *m, void *d_hits, uint64_t n_hits, bool ac_order, void *stream);
 int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool ac_order, void *stream) {
+    const int rc = order_hits_on_device_impl(m, d_hits, n_hits, ac_order, stream);
+    if (rc == MK_OK) ++m->order_path_calls[m->order_path & 3];  // (mk_matcher_order_stats: does the library sort ever fire on real data?)
+    return rc;
+}
+static int order_hits_on_device_impl(mk_matcher *m, void *d_hits, uint64_t n_hits, bool ac_order, void *stream) {
+    using namespace mk;
     m->order_path = 0;
     if (n_hits < 2) return MK_OK;
     if (!d_hits) return fail(MK_E_INVALID_ARG, "null buffer");
@@ -896,6 +903,12 @@ int mk::order_hits_on_device(mk_matcher *m, void *d_hits, uint64_t n_hits, bool 
 }
 
 extern "C" {
+
+int mk_matcher_order_stats(const mk_matcher *m, uint64_t calls[4]) {
+    if (!m || !calls) return fail(MK_E_INVALID_ARG, "null argument");
+    for (int i = 0; i < 4; ++i) calls[i] = m->order_path_calls[i];
+    return MK_OK;
+}
 
 int mk_matcher_order_info(const mk_matcher *m, uint32_t *path, uint32_t *n_bins, uint32_t *max_bin) {
     if (!m) return fail(MK_E_INVALID_ARG, "null matcher");

@@ -68,6 +68,7 @@ struct mk_matcher {
     uint64_t last_n_rec = 0;  // records of the last mk_scan_device: the binning bound of mk_order_hits_device
     // what the last mk_order_hits_device did: 0 nothing, 1 record bins, 2 (record, A) bins, 3 library sort
     uint32_t order_path = 0, order_bins = 0, order_max_bin = 0;
+    uint64_t order_path_calls[4] = {0, 0, 0, 0};  // successful ordering calls by path, over the handle's life (mk_matcher_order_stats)
     bool order_prepared = false;  // the ordering kernels' dynamic-LDS limit has been raised on this device
     // scratch of the driver loops (host_loops.cpp): pattern sets, counters, rows
     void *d_aux = nullptr;

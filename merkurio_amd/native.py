@@ -47,7 +47,7 @@ EXPORTS = [
     "mk_abi_version", "mk_last_error", "mk_device_count", "mk_read_kmers_from_text", "mk_parse_pattern_list",
     "mk_reverse_complement", "mk_canonical", "mk_recommend_aho_corasick", "mk_tune_q_value", "mk_generate_masks",
     "mk_free", "mk_matcher_create", "mk_matcher_create_ex", "mk_plan_geometry", "mk_matcher_destroy", "mk_matcher_algo", "mk_matcher_num_patterns",
-    "mk_matcher_filter_info", "mk_matcher_class_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_kernel_name",
+    "mk_matcher_filter_info", "mk_matcher_class_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_order_stats", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
     "mk_extract_single", "mk_extract_fastq_text", "mk_upload_text_ahead", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",

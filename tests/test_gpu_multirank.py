@@ -211,6 +211,23 @@ def test_bench_starts_its_own_ranks_and_strong_scaling_is_the_same_job():
     assert [weak["summary"][k] for k in keys] == [one["summary"][k] for k in keys]
 
 
+def test_bench_default_job_at_two_ranks_reports_every_rank_and_the_multi_gpu_configs():
+    """The driver's own command line at N = 2 (rehearsal: both ranks on the one GPU): the JSON line names every rank's
+    device, kernel time and communicator size, and carries BASELINE's multi-GPU configurations -- config 3 (paired, pairs
+    unsplit) and config 5 (500 k 21-mers) -- sharded over the same ranks."""
+    out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["records_total"] == 200_000_000
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["records"] == 100_000_000 and r["kernel_ms_avg"] > 0 for r in out["ranks"])
+    assert all("device" in r and "ncclCommCount" in r and "device_name" in r for r in out["ranks"])
+    oc = out["other_configs"]
+    assert isinstance(oc, list) and len(oc) == 2, oc
+    c3, c5 = oc
+    assert c3["workload"].startswith("config 3") and c3["launches_per_step"] == 2 and c3["n_gpus"] == 2 and len(c3["ranks"]) == 2
+    assert 0 < c3["pairs_kept_in_the_job"] < 2 * 6_250_000 * 0.05
+    assert c5["workload"].startswith("config 5") and c5["filter"]["in_lds"] == 0 and len(c5["ranks"]) == 2
+    assert all(e["value_gbases_per_s"] > 0 and 0 < e["frac"] < 1 for e in oc)
+
+
 def _agree_worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
