@@ -468,6 +468,60 @@ int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, u
                           const mk_bgzf_member *members, uint64_t n_members, int last, mk_window_text *io, int logging, int invert,
                           uint64_t rec_cap, uint64_t *n_rec, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap,
                           uint64_t *n_rows, mk_counters *c, uint32_t *pattern_hit_counts, uint32_t *status);
+/* -------------------------------------------------------------------------------------
+ * Text windows of one or two input files (v6) -- the general form of mk_extract_fastq_text / mk_extract_fastq_bgzf: FASTQ or
+ * FASTA, one input (the loop of src/cmd_extract.rs:321-406) or two (paired: :463-612), plain text or BGZF members, with heads.
+ * Replaces needletail's parse_fastx_file + record.seq() for these loops (src/cmd_extract.rs:281-282, 412-418, 321-328, 463-468).
+ *
+ * A source's window text = head[0, n_head) ++ body, the body being text[0, n_text) (uploaded; fastest from mk_host_alloc memory;
+ * mk_upload_text_ahead of the same pointer and size beforehand overlaps the copy with the previous window) or the text of
+ * members[0, n_members) of bgzf[0, n_bgzf) (inflated on the device, never uploaded; needs `codec` on the matcher's device).  The
+ * window starts at a record start.  ends_at_record != 0: its end is a record end (the end of the input, or a place the caller
+ * chose); == 0: it may end anywhere -- the unfinished record stays behind as the tail.  The head is how a caller hands the
+ * previous window's tail back in.
+ * The records are indexed on the device: FASTQ -- '@' line, sequence, '+' line, quality of the same length, LF or CRLF, no blank
+ * lines; FASTA -- '>' header lines, every other line sequence, which reaches the matcher without its '\n' / '\r' bytes
+ * (record.seq(); a hit may span a line break: tests/fixtures/extract/fixed-width.log:8).  Anything else sets *status = 1 and
+ * produces nothing: the caller's own reader takes that window (and words the reference's parse errors).
+ * *n_rec = the records (two sources: PAIRS, record i of one with record i of the other) the call has processed = the smallest
+ * number of whole records any source holds; per source: n_rec_seen = whole records it held, rec_start[0 .. *n_rec] = their offsets
+ * in the window text (rec_start[*n_rec] = n_used, the bytes the processed records take), n_tail = n_window - n_used.  Outputs
+ * keep / rows / counters / pattern_hit_counts: as mk_extract_single, resp. mk_extract_paired (row.rec = index in the window,
+ * row.file = source).  What comes back of the text is the caller's choice, per source:
+ *   tail (tail_cap):  the text behind the processed records, the next window's head     (MK_E_CAPACITY: n_tail = the need)
+ *   kept (kept_cap):  the text of the KEPT records back to back, record r's being rec_start[r + 1] - rec_start[r] bytes -- for
+ *                     callers that do not hold the text themselves (BGZF bodies)          (MK_E_CAPACITY: n_kept_bytes = the need)
+ *   all  (all_cap):   the whole window text (logging with invert: rows name records that are not kept)
+ * A damaged BGZF member: MK_E_CORRUPT.  More than rec_cap records: MK_E_CAPACITY with *n_rec = the need.
+ * --------------------------------------------------------------------------------------- */
+#define MK_TEXT_FASTQ 0
+#define MK_TEXT_FASTA 1
+typedef struct mk_window_source {
+    /* in */
+    const uint8_t *head;
+    uint64_t n_head;
+    const uint8_t *text;
+    uint64_t n_text;
+    const uint8_t *bgzf;
+    uint64_t n_bgzf;
+    const mk_bgzf_member *members; /* out_off = running sum of ISIZE from 0 */
+    uint64_t n_members;
+    uint32_t ends_at_record;
+    uint32_t reserved;
+    uint64_t *rec_start; /* room for rec_cap + 1, or NULL */
+    uint8_t *tail;
+    uint64_t tail_cap;
+    uint8_t *kept;
+    uint64_t kept_cap;
+    uint8_t *all;
+    uint64_t all_cap;
+    /* out */
+    uint64_t n_window, n_used, n_tail, n_kept_bytes, n_rec_seen;
+} mk_window_source;
+int mk_extract_window(mk_matcher *m, mk_codec *codec, uint32_t format, uint32_t n_sources, mk_window_source *sources, int logging, int invert,
+                      uint64_t rec_cap, uint64_t *n_rec, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *counters,
+                      uint32_t *pattern_hit_counts, uint32_t *status);
+
 /* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,
  * *consumed = bytes of whole members, *text_bytes = sum of ISIZE.  MK_E_CORRUPT where a header is not BGZF; a trailing
  * partial member is not an error (*consumed < n).  Host code, no device. */

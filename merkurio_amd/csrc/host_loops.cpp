@@ -290,29 +290,318 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
     MK_ABI_END
 }
 
-// ---- FASTQ text in, records out: the window's raw bytes are uploaded as they are, indexed and
-// gathered on the device (ingest.hip), then the extract loop runs as in mk_extract_single
+// ---- text windows in, records out (r05: FASTA, paired inputs, heads): the raw bytes of a window of every
+// input file go to the device as they are (plain text is uploaded, BGZF members are inflated there), are indexed and gathered on
+// the device (ingest.hip), then the extract loop runs as in mk_extract_single / mk_extract_paired
 }  // extern "C"
 
 namespace mk {
 void launch_ingest_count(const uint8_t *d_text, uint64_t n, uint32_t *d_block_cnt, uint32_t *d_total, hipStream_t st);
 void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start,
                            uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status, hipStream_t st);
+void launch_ingest_lines(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start, hipStream_t st);
 void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st);
 void launch_ingest_gather(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off,
-                          uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st);
+                          uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st, uint32_t skip_from = 0xFFFFFFFFu);
 void launch_ingest_select(const uint8_t *d_flags, uint32_t invert, const uint32_t *d_rec_start, uint64_t n_rec, uint32_t n_text, uint32_t *d_sel_len,
                           hipStream_t st);
+void launch_ingest_fasta_count(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl_block_off, const uint32_t *d_line_start,
+                               unsigned long long *d_block64, hipStream_t st);
+void launch_ingest_fasta_emit(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl_block_off, const uint32_t *d_line_start,
+                              unsigned long long *d_block64, uint8_t *d_seq, uint32_t *d_rec_start, unsigned long long *d_off, hipStream_t st);
+void launch_ingest_or_flags(uint8_t *d_flags, const uint8_t *d_other, uint64_t n, hipStream_t st);
 uint32_t ingest_block_bytes();
 uint32_t ingest_scan_tile();
 }  // namespace mk
 
-// the text of the kept records, packed on the device and copied to the host (mk_extract_fastq_bgzf without a whole-text copy)
-struct KeptText {
-    uint8_t *text;
-    uint64_t cap;
-    uint64_t n_bytes;  // out (also when cap is too small: MK_E_CAPACITY)
+namespace {
+
+// One input of a window on the device: its text in slot T (m->txt[k]) and what the index kernels made of it
+struct WindowSide {
+    mk_matcher::TextSlot *T = nullptr;
+    uint64_t n_window = 0;  // bytes of text (head + body)
+    uint8_t last_byte = '\n';
+    uint32_t total_nl = 0;
+    uint64_t n_avail = 0;   // whole records found
+    uint64_t n_used = 0;    // bytes of the first n records (n = what the call processes)
+    uint32_t fixed = 0;     // > 0: every sequence has this length (FASTQ)
+    uint64_t seq_total = 0; // FASTA: sequence bytes of all records
+    uint32_t *d_block = nullptr, *d_total = nullptr, *d_st = nullptr, *d_line = nullptr, *d_rec_start = nullptr, *d_seq_start = nullptr,
+             *d_seq_len = nullptr;
+    unsigned long long *d_tile = nullptr, *d_block64 = nullptr, *d_fa_off = nullptr;
 };
+
+constexpr uint32_t kBigRecord = 1u << 20;  // records from here on are copied one by one when the kept records are packed
+
+// text of a source -> T->d_text[0, n_window): head, then the body (uploaded, taken from an upload-ahead slot, or inflated from
+// BGZF members).  Enqueued on st; the caller synchronises.  *corrupt_member: index of a damaged member (MK_E_CORRUPT).
+int window_assemble(mk_matcher *m, mk_codec *codec, mk_window_source &S, WindowSide &W, DeviceLoop &dl) {
+    hipStream_t st = dl.st;
+    int rc;
+    uint64_t body = S.n_text;
+    for (uint64_t i = 0; i < S.n_members; ++i) {
+        const mk_bgzf_member &b = S.members[i];
+        if (b.data_off > S.n_bgzf || b.data_len > S.n_bgzf - b.data_off || b.isize > 65536 || b.out_off != body - S.n_text)
+            return fail(MK_E_INVALID_ARG, "mk_extract_window: member %llu lies outside its buffer or its text is not in sequence", (unsigned long long)i);
+        body += b.isize;
+    }
+    if (S.n_text && S.n_members) return fail(MK_E_INVALID_ARG, "mk_extract_window: a source is plain text or BGZF members, not both");
+    W.n_window = S.n_head + body;
+    S.n_window = W.n_window;
+    if (W.n_window == 0) return MK_OK;
+    if (W.n_window >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)W.n_window);
+    mk_matcher::TextSlot &T = *W.T;
+    // a body that mk_upload_text_ahead has already sent (same pointer, same size): without a head its buffer BECOMES the text
+    // buffer, with one it is copied behind the head on the device
+    bool ahead = false;
+    if (S.n_text) {
+        std::lock_guard<std::mutex> lk(m->ahead_mu);
+        for (auto &a : m->ahead) {
+            if (!a.text || a.text != S.text || ahead) continue;
+            if (a.n != S.n_text) {  // (another window out of the same buffer: stale)
+                if (hipEventSynchronize(a.ev) != hipSuccess) return fail(MK_E_HIP, "hipEventSynchronize failed");
+                a.text = nullptr;
+                continue;
+            }
+            if (hipStreamWaitEvent(st, a.ev, 0) != hipSuccess) return fail(MK_E_HIP, "hipStreamWaitEvent failed");
+            if (S.n_head == 0) {
+                std::swap(T.d_text, a.d);
+                std::swap(T.d_text_cap, a.cap);
+            } else {
+                if ((rc = ensure_device(&T.d_text, &T.d_text_cap, W.n_window + 64))) return rc;
+                if (hipMemcpyAsync((uint8_t *)T.d_text + S.n_head, a.d, S.n_text, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return fail(MK_E_HIP, "copy of the uploaded window failed");
+                // (the slot may be refilled by the uploader as soon as it is marked free: let the copy out of it finish first)
+                if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "copy of the uploaded window failed");
+            }
+            a.text = nullptr;
+            ahead = true;
+        }
+    }
+    if (!ahead && (rc = ensure_device(&T.d_text, &T.d_text_cap, W.n_window + 64))) return rc;
+    if (S.n_head && hipMemcpyAsync(T.d_text, S.head, S.n_head, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the head failed");
+    if (S.n_text && !ahead && hipMemcpyAsync((uint8_t *)T.d_text + S.n_head, S.text, S.n_text, hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(MK_E_HIP, "upload of the text failed");
+    if (S.n_members) {
+        if (!codec) return fail(MK_E_INVALID_ARG, "mk_extract_window: BGZF members need a codec handle");
+        if (codec->device != m->device) return fail(MK_E_INVALID_ARG, "mk_extract_window: the codec and the matcher are on different devices");
+        // the members' bytes and their table go up (a fifth of the text), the text is inflated behind the head in place
+        std::lock_guard<std::mutex> lock(codec->mu);
+        uint64_t in_lo = S.members[0].data_off, in_hi = in_lo;
+        std::vector<mkz::Member> part(S.n_members);
+        for (uint64_t i = 0; i < S.n_members; ++i) {
+            in_lo = std::min<uint64_t>(in_lo, S.members[i].data_off);
+            in_hi = std::max<uint64_t>(in_hi, S.members[i].data_off + S.members[i].data_len);
+        }
+        for (uint64_t i = 0; i < S.n_members; ++i)
+            part[i] = mkz::Member{S.members[i].data_off - in_lo, S.n_head + S.members[i].out_off, S.members[i].data_len, S.members[i].isize, S.members[i].crc, 0};
+        const uint64_t cn = in_hi - in_lo;
+        if ((rc = ensure_device(&codec->d_in, &codec->in_cap, cn + mkz::kPad)) ||
+            (rc = ensure_device(&codec->d_aux, &codec->aux_cap, (S.n_members + 1) * sizeof(mkz::Member))) ||
+            (rc = ensure_device(&codec->d_len, &codec->len_cap, (S.n_members + 1) * 4ull)))
+            return rc;
+        if (hipMemcpyAsync(codec->d_in, S.bgzf + in_lo, cn, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemsetAsync((uint8_t *)codec->d_in + cn, 0, mkz::kPad, st) != hipSuccess ||
+            hipMemcpyAsync(codec->d_aux, part.data(), S.n_members * sizeof(mkz::Member), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(MK_E_HIP, "upload of the members failed");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the members failed");
+        dl.mark(1);
+        mkz::launch_inflate((const uint8_t *)codec->d_in, cn, (const mkz::Member *)codec->d_aux, (uint32_t)S.n_members, (uint8_t *)T.d_text,
+                            (int32_t *)codec->d_len, codec->num_cus, st);
+        mkz::launch_crc_check((const uint8_t *)T.d_text, (const mkz::Member *)codec->d_aux, (uint32_t)S.n_members, (int32_t *)codec->d_len, st);
+        std::vector<int32_t> st_words(S.n_members);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(st_words.data(), codec->d_len, S.n_members * 4ull, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "BGZF inflate failed");
+        dl.mark(2);
+        for (uint64_t i = 0; i < S.n_members; ++i)
+            if (st_words[i])
+                return fail(MK_E_CORRUPT, st_words[i] > 0 ? "BGZF member %llu: CRC-32 of the inflated text differs from the trailer's (status %d)"
+                                                           : "BGZF member %llu does not inflate to its ISIZE (decoder status %d)",
+                            (unsigned long long)i, st_words[i]);
+    }
+    return MK_OK;
+}
+
+// line table, whole records and their tables for the text in W.T (enqueued work waited for): W.n_avail, d_rec_start[n_avail + 1],
+// FASTQ: d_seq_start / d_seq_len / W.fixed; FASTA: the sequences already lie in d_seq_out with offsets d_fa_off[n_avail + 1].
+// *status = 1: this text is not what the device takes (the caller's reader decides what it is).
+int window_index(mk_matcher *m, uint32_t format, bool ends_at_record, WindowSide &W, uint8_t *d_seq_out, hipStream_t st, uint32_t *status) {
+    mk_matcher::TextSlot &T = *W.T;
+    int rc;
+    const uint64_t n_text = W.n_window;
+    const uint8_t *d_text = (const uint8_t *)T.d_text;
+    const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
+    // d_ing_a: newline count per block | total | status, min, max | (FASTA) u64 per block + 1
+    const size_t a_words = (size_t)n_blocks + 8;
+    if ((rc = ensure_device(&T.d_ing_a, &T.d_ing_a_cap, a_words * 4 + 16 + ((size_t)n_blocks + 2) * 8))) return rc;
+    W.d_block = (uint32_t *)T.d_ing_a;
+    W.d_total = W.d_block + n_blocks;
+    W.d_st = W.d_total + 1;
+    W.d_block64 = (unsigned long long *)(((uintptr_t)(W.d_block + a_words) + 15) & ~(uintptr_t)15);
+    launch_ingest_count(d_text, n_text, W.d_block, W.d_total, st);
+    uint8_t first_last[2] = {0, 0};
+    if (hipMemcpyAsync(&W.total_nl, W.d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&first_last[0], d_text, 1, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&first_last[1], d_text + n_text - 1, 1, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "newline count failed");
+    W.last_byte = first_last[1];
+    const uint32_t total_nl = W.total_nl;
+    if (format == MK_TEXT_FASTA) {
+        if (first_last[0] != '>') {  // blank lines or anything else in front of the first header: the host reader's business
+            *status = 1;
+            return MK_OK;
+        }
+        // line table | record starts | (u64) sequence offsets
+        const size_t max_rec = (size_t)total_nl + 2;  // (a header per line at most)
+        const size_t ws = ((size_t)total_nl + 4) * 4 + (max_rec + 2) * 4 + 16 + (max_rec + 2) * 8;
+        if ((rc = ensure_device(&T.d_ing_b, &T.d_ing_b_cap, ws))) return rc;
+        W.d_line = (uint32_t *)T.d_ing_b;
+        W.d_rec_start = W.d_line + total_nl + 4;
+        W.d_fa_off = (unsigned long long *)(((uintptr_t)(W.d_rec_start + max_rec + 2) + 15) & ~(uintptr_t)15);
+        launch_ingest_lines(d_text, n_text, W.d_block, W.d_total, W.d_line, st);
+        if (hipMemsetAsync(W.d_block64 + n_blocks, 0, 8, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
+        launch_ingest_fasta_count(d_text, n_text, W.d_block, W.d_line, W.d_block64, st);
+        unsigned long long totals = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&totals, W.d_block64 + n_blocks, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "FASTA indexing failed");
+        const uint64_t heads = totals >> 32;
+        W.seq_total = totals & 0xFFFFFFFFull;
+        launch_ingest_fasta_emit(d_text, n_text, W.d_block, W.d_line, W.d_block64, d_seq_out, W.d_rec_start, W.d_fa_off, st);
+        if (hipGetLastError() != hipSuccess) return fail(MK_E_HIP, "FASTA gather failed to launch");
+        // a record is whole once the next header (or the end of the input) has been seen
+        W.n_avail = ends_at_record ? heads : (heads ? heads - 1 : 0);
+        W.fixed = 0;
+        return MK_OK;
+    }
+    uint64_t n_lines = total_nl;
+    if (ends_at_record) {
+        n_lines += W.last_byte != '\n' ? 1 : 0;
+        if (n_lines % 4 != 0) {  // not whole 4-line records: the caller's reader decides what this text is
+            *status = 1;
+            return MK_OK;
+        }
+    }
+    const uint64_t n_rec = n_lines / 4;
+    W.n_avail = n_rec;
+    // workspace: line starts | record starts (+1) | sequence starts | sequence lengths | tile sums
+    const size_t n_tiles = n_rec / ingest_scan_tile() + 2;
+    const size_t ws = ((size_t)total_nl + 4 + 3 * (n_rec + 2) + 8) * 4 + n_tiles * 8 + 64;
+    if ((rc = ensure_device(&T.d_ing_b, &T.d_ing_b_cap, ws))) return rc;
+    W.d_line = (uint32_t *)T.d_ing_b;
+    W.d_rec_start = W.d_line + total_nl + 4;
+    W.d_seq_start = W.d_rec_start + n_rec + 2;
+    W.d_seq_len = W.d_seq_start + n_rec + 2;
+    W.d_tile = (unsigned long long *)(((uintptr_t)(W.d_seq_len + n_rec + 2) + 15) & ~(uintptr_t)15);
+    const uint32_t st_init[3] = {0u, 0xFFFFFFFFu, 0u};
+    if (hipMemcpyAsync(W.d_st, st_init, sizeof(st_init), hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
+    launch_ingest_records(d_text, n_text, W.d_block, W.d_total, W.d_line, n_rec, W.d_rec_start, W.d_seq_start, W.d_seq_len, W.d_st, st);
+    uint32_t st_host[3] = {0, 0, 0};
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(st_host, W.d_st, sizeof(st_host), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "record indexing failed");
+    if (st_host[0]) {  // some record is not '@' / sequence / '+' / quality of equal length
+        *status = 1;
+        return MK_OK;
+    }
+    W.fixed = (n_rec && st_host[1] == st_host[2] && st_host[1] > 0) ? st_host[1] : 0;
+    return MK_OK;
+}
+
+// the first n records of side W -> m->d_seq / m->d_off, scanned: flags (host + m->d_flags), tuples in m->d_hits (dl.found)
+int window_scan(mk_matcher *m, uint32_t format, WindowSide &W, uint64_t n, DeviceLoop &dl, uint32_t mode, uint8_t *flags, uint64_t *flagged, uint64_t *n_seq_out) {
+    hipStream_t st = dl.st;
+    int rc;
+    unsigned long long n_seq = 0;
+    if ((rc = ensure_device((void **)&m->d_flags, &m->d_flags_cap, n + 8))) return rc;
+    uint32_t fixed = 0;
+    if (format == MK_TEXT_FASTA) {
+        // (the sequences were compacted into d_seq by the index step; their offsets become the batch's)
+        if ((rc = ensure_device((void **)&m->d_off, &m->d_off_cap, (n + 1) * sizeof(uint64_t)))) return rc;
+        if (hipMemcpyAsync(m->d_off, W.d_fa_off, (n + 1) * 8, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(&n_seq, W.d_fa_off + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "copy of the sequence offsets failed");
+    } else {
+        fixed = W.fixed;
+        n_seq = (unsigned long long)n * fixed;
+        if ((rc = ensure_device((void **)&m->d_off, &m->d_off_cap, (n + 1) * sizeof(uint64_t)))) return rc;
+        if (!fixed) {
+            launch_ingest_offsets(W.d_seq_len, n, W.d_tile, (unsigned long long *)m->d_off, st);
+            if (hipMemcpyAsync(&n_seq, m->d_off + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                return fail(MK_E_HIP, "offset scan failed");
+        }
+        launch_ingest_gather((const uint8_t *)W.T->d_text, W.d_seq_start, W.d_seq_len, (const unsigned long long *)m->d_off, fixed, n, m->d_seq, st);
+        if (hipGetLastError() != hipSuccess) return fail(MK_E_HIP, "ingest kernels failed to launch");
+    }
+    m->ragged = !fixed;
+    *n_seq_out = n_seq;
+    *flagged = 0;
+    // FASTA: one record of 4 GiB or more cannot be addressed by mk_hit.pos (as mk_scan_batch refuses it)
+    if (n_seq == 0) {  // every sequence is empty: nothing can match
+        std::fill(flags, flags + n, 0);
+        dl.found = 0;
+        if (n && hipMemsetAsync(m->d_flags, 0, n, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
+        return MK_OK;
+    }
+    if (format != MK_TEXT_FASTA) return dl.scan_resident(n_seq, n, mode, fixed, flags, flagged);
+    // FASTA: the compacted sequences lie in the slot's own buffer -- it stands in for the scan buffer for this scan
+    mk_matcher::TextSlot &T = *W.T;
+    void *seq = m->d_seq;
+    size_t cap = m->d_seq_cap;
+    m->d_seq = (uint8_t *)T.d_fa_seq, m->d_seq_cap = T.d_fa_seq_cap;
+    rc = dl.scan_resident(n_seq, n, mode, 0, flags, flagged);
+    T.d_fa_seq = m->d_seq, T.d_fa_seq_cap = m->d_seq_cap;
+    m->d_seq = (uint8_t *)seq, m->d_seq_cap = cap;
+    return rc;
+}
+
+// text of the kept records of side W (keep flags in d_keep, already final: invert applied by the caller as 0), packed -> host
+int window_kept(mk_matcher *m, uint32_t format, WindowSide &W, uint64_t n, const uint8_t *d_keep, const std::vector<uint32_t> &rs, const uint8_t *keep_host,
+                mk_window_source &S, DeviceLoop &dl) {
+    hipStream_t st = dl.st;
+    S.n_kept_bytes = 0;
+    if (!n) return MK_OK;
+    int rc;
+    // lengths by the flags, the offsets scan and the gather kernel of the sequences once more -- into the scan buffer, which has
+    // done its work.  (FASTA has no per-record length table of its own: one is carved behind the record starts' u64 table.)
+    uint32_t *d_len = W.d_seq_len;
+    unsigned long long *d_tile = W.d_tile;
+    if (format == MK_TEXT_FASTA) {
+        const size_t n_tiles = n / ingest_scan_tile() + 2;
+        if ((rc = ensure_device(&m->d_aux, &m->d_aux_cap, (n + 2) * 4 + n_tiles * 8 + 64))) return rc;
+        d_len = (uint32_t *)m->d_aux;
+        d_tile = (unsigned long long *)(((uintptr_t)(d_len + n + 2) + 15) & ~(uintptr_t)15);
+    }
+    unsigned long long total = 0;
+    launch_ingest_select(d_keep, 0u, W.d_rec_start, n, (uint32_t)W.n_used, d_len, st);
+    if ((rc = ensure_device((void **)&m->d_off, &m->d_off_cap, (n + 1) * sizeof(uint64_t)))) return rc;
+    launch_ingest_offsets(d_len, n, d_tile, (unsigned long long *)m->d_off, st);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, m->d_off + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "selection of the kept records failed");
+    S.n_kept_bytes = total;
+    if (total > S.kept_cap) return fail(MK_E_CAPACITY, "the kept records take %llu bytes", total);
+    if (!total) return MK_OK;
+    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, total + 64))) return rc;
+    launch_ingest_gather((const uint8_t *)W.T->d_text, W.d_rec_start, d_len, (const unsigned long long *)m->d_off, 0, n, m->d_seq, st, kBigRecord);
+    // chromosome-sized records: one device copy each
+    uint64_t at = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        if (!keep_host[r]) continue;
+        const uint64_t len = (r + 1 < n ? rs[r + 1] : W.n_used) - rs[r];
+        if (len >= kBigRecord && hipMemcpyAsync(m->d_seq + at, (const uint8_t *)W.T->d_text + rs[r], len, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(MK_E_HIP, "copy of a kept record failed");
+        at += len;
+    }
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(S.kept, m->d_seq, total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "copy of the kept records failed");
+    return MK_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -337,9 +626,18 @@ int mk_upload_text_ahead(mk_matcher *m, const uint8_t *text, uint64_t n_text) {
     if (!m->stream_ahead && hipStreamCreateWithFlags(&m->stream_ahead, hipStreamNonBlocking) != hipSuccess)
         return fail(MK_E_HIP, "hipStreamCreate failed");
     mk_matcher::AheadSlot *slot = nullptr;
+    // a slot that still holds an earlier window from this very buffer is stale (the host did not come back for it and is now
+    // refilling the buffer): its copy must have finished reading before the new bytes are trusted -- the caller has of course
+    // already overwritten them, so all that is left to do is to wait and take the slot over
+    for (auto &a : m->ahead)
+        if (a.text == text) {
+            if (hipEventSynchronize(a.ev) != hipSuccess) return fail(MK_E_HIP, "hipEventSynchronize failed");
+            a.text = nullptr;
+            slot = &a;
+        }
     for (auto &a : m->ahead)
         if (!a.text && !slot) slot = &a;
-    if (!slot) return MK_OK;  // two windows wait already: this one will upload itself
+    if (!slot) return MK_OK;  // every slot waits already: this window will upload itself
     if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) return fail(MK_E_HIP, "hipEventCreate failed");
     int rc = ensure_device(&slot->d, &slot->cap, n_text + 64);
     if (rc) return rc;
@@ -352,116 +650,189 @@ int mk_upload_text_ahead(mk_matcher *m, const uint8_t *text, uint64_t n_text) {
     MK_ABI_END
 }
 
-// The window's text is in m->d_text[0, n_text) (uploaded, or inflated there): index, gather, scan, order, rows, counts,
-// record table -- everything of mk_extract_fastq_text behind the upload.  last_byte = text[n_text - 1].
-static int extract_text_resident(mk_matcher *m, DeviceLoop &dl, uint64_t n_text, uint8_t last_byte, int logging, int invert, uint64_t rec_cap,
-                                 uint64_t *n_rec_out, uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows,
-                                 mk_counters *c, uint32_t *counts, uint32_t *status, KeptText *kept = nullptr) {
+int mk_extract_window(mk_matcher *m, mk_codec *codec, uint32_t format, uint32_t n_sources, mk_window_source *src, int logging, int invert,
+                      uint64_t rec_cap, uint64_t *n_rec_out, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c,
+                      uint32_t *counts, uint32_t *status) {
+    if (!m || !src || !n_rec_out || !status || !c || (logging && !counts)) return fail(MK_E_INVALID_ARG, "null argument");
+    if (n_sources < 1 || n_sources > 2) return fail(MK_E_INVALID_ARG, "mk_extract_window: one source (single file) or two (paired files)");
+    if (format > MK_TEXT_FASTA) return fail(MK_E_INVALID_ARG, "mk_extract_window: unknown text format %u", format);
+    *n_rec_out = 0;
+    *status = 0;
+    if (n_rows) *n_rows = 0;
+    for (uint32_t k = 0; k < n_sources; ++k) {
+        mk_window_source &S = src[k];
+        S.n_window = S.n_used = S.n_tail = S.n_kept_bytes = S.n_rec_seen = 0;
+        if ((S.n_head && !S.head) || (S.n_text && !S.text) || (S.n_members && (!S.bgzf || !S.members)) || (S.kept_cap && !S.kept) ||
+            (S.all_cap && !S.all) || (S.tail_cap && !S.tail))
+            return fail(MK_E_INVALID_ARG, "mk_extract_window: a size without its buffer in source %u", k);
+    }
+    MK_ABI_BEGIN
+    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
+    DeviceLoop dl(m);
     hipStream_t st = dl.st;
     int rc;
-    const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
-    if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
-    uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;  // | total | status, min, max
-    launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);
-    uint32_t total_nl = 0;
-    if (hipMemcpyAsync(&total_nl, d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return fail(MK_E_HIP, "newline count failed");
-    const uint64_t n_lines = (uint64_t)total_nl + (last_byte != '\n' ? 1 : 0);
-    if (n_lines % 4 != 0) {  // not whole 4-line records: the caller's reader decides what this text is
-        *status = 1;
-        return MK_OK;
+    const bool paired = n_sources == 2;
+    const bool ac = m->algo == MK_ALGO_AC;
+    WindowSide W[2];
+    // ---- the text of every source on the device, then what the index kernels make of it
+    uint64_t most = 0;
+    for (uint32_t k = 0; k < n_sources; ++k) {
+        W[k].T = &m->txt[k];
+        if ((rc = window_assemble(m, codec, src[k], W[k], dl))) return rc;
+        most = std::max(most, W[k].n_window);
     }
-    const uint64_t n_rec = n_lines / 4;
-    *n_rec_out = n_rec;
-    if (n_rec > rec_cap || !rec_start || !keep)
-        return fail(MK_E_CAPACITY, "%llu records in the window, room for %llu", (unsigned long long)n_rec, (unsigned long long)rec_cap);
-    // workspace: line starts | record starts | sequence starts | sequence lengths | tile sums
-    const size_t n_tiles = n_rec / ingest_scan_tile() + 2;
-    const size_t ws = ((size_t)total_nl + 2 + 3 * n_rec + 8) * 4 + n_tiles * 8 + 64;
-    if ((rc = ensure_device(&m->d_ing_b, &m->d_ing_b_cap, ws))) return rc;
-    uint32_t *d_line = (uint32_t *)m->d_ing_b;
-    uint32_t *d_rec_start = d_line + total_nl + 2 + ((total_nl & 1) ? 1 : 0);
-    uint32_t *d_seq_start = d_rec_start + n_rec, *d_seq_len = d_seq_start + n_rec;
-    unsigned long long *d_tile = (unsigned long long *)(((uintptr_t)(d_seq_len + n_rec) + 15) & ~(uintptr_t)15);
-    uint32_t *d_st = d_total + 1;
-    const uint32_t st_init[3] = {0u, 0xFFFFFFFFu, 0u};
-    if (hipMemcpyAsync(d_st, st_init, sizeof(st_init), hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
-    launch_ingest_records((const uint8_t *)m->d_text, n_text, d_block, d_total, d_line, n_rec, d_rec_start, d_seq_start, d_seq_len, d_st, st);
-    uint32_t st_host[3] = {0, 0, 0};
-    if (hipMemcpyAsync(st_host, d_st, sizeof(st_host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return fail(MK_E_HIP, "record indexing failed");
-    if (st_host[0]) {  // some record is not '@' / sequence / '+' / quality of equal length
-        *status = 1;
-        *n_rec_out = 0;
-        return MK_OK;
-    }
-    const uint32_t fixed = (n_rec && st_host[1] == st_host[2] && st_host[1] > 0) ? st_host[1] : 0;
-    unsigned long long n_seq = (unsigned long long)n_rec * fixed;
-    if ((rc = ensure_device((void **)&m->d_flags, &m->d_flags_cap, n_rec + 8))) return rc;
-    if ((rc = ensure_device((void **)&m->d_off, &m->d_off_cap, (n_rec + 1) * sizeof(uint64_t)))) return rc;
-    if (!fixed) {
-        launch_ingest_offsets(d_seq_len, n_rec, d_tile, (unsigned long long *)m->d_off, st);
-        if (hipMemcpyAsync(&n_seq, m->d_off + n_rec, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return fail(MK_E_HIP, "offset scan failed");
-    }
-    launch_ingest_gather((const uint8_t *)m->d_text, d_seq_start, d_seq_len, (const unsigned long long *)m->d_off, fixed, n_rec, m->d_seq, st);
-    if (hipGetLastError() != hipSuccess) return fail(MK_E_HIP, "ingest kernels failed to launch");
-    m->ragged = !fixed;
-    std::vector<uint8_t> flags(n_rec ? n_rec : 1);
-    uint64_t flagged = 0;
-    if (n_seq == 0) {  // every sequence is empty: nothing can match
-        std::fill(flags.begin(), flags.end(), 0);
-        dl.found = 0;
-        if (kept && n_rec && hipMemsetAsync(m->d_flags, 0, n_rec, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
-    } else if ((rc = dl.scan_resident(n_seq, n_rec, logging ? MK_MODE_HITS : MK_MODE_ANY, fixed, flags.data(), &flagged))) {
-        return rc;
-    }
-    if (logging) {  // the loop body of mk_extract_single (src/cmd_extract.rs:321-406)
-        c->nb_records_tot += n_rec;
-        c->nb_bases += n_seq;
-        c->nb_hits_tot[0] += dl.found;
-        c->nb_records_hit[0] += flagged;
-        if ((rc = dl.order(m->algo == MK_ALGO_AC))) return rc;
-        if ((rc = dl.rows_to_host(0, rows, rows_cap))) return rc;
-        if ((rc = dl.pattern_counts(m->algo == MK_ALGO_AC, n_rec, counts))) return rc;
-    }
-    if (kept) {
-        // the kept records' text, back to back in record order: lengths by the flags (the scan's, still on the device), the
-        // offsets scan and the gather kernel of the sequences once more -- into the scan buffer, which has done its work
-        kept->n_bytes = 0;
-        if (n_rec) {
-            unsigned long long total = 0;
-            launch_ingest_select(m->d_flags, invert ? 1u : 0u, d_rec_start, n_rec, (uint32_t)n_text, d_seq_len, st);
-            launch_ingest_offsets(d_seq_len, n_rec, d_tile, (unsigned long long *)m->d_off, st);
-            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, m->d_off + n_rec, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
-                return fail(MK_E_HIP, "selection of the kept records failed");
-            kept->n_bytes = total;
-            if (total > kept->cap) return fail(MK_E_CAPACITY, "the kept records take %llu bytes", total);
-            if (total) {
-                launch_ingest_gather((const uint8_t *)m->d_text, d_rec_start, d_seq_len, (const unsigned long long *)m->d_off, 0, n_rec, m->d_seq, st);
-                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(kept->text, m->d_seq, total, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess)
-                    return fail(MK_E_HIP, "copy of the kept records failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the window failed");
+    dl.mark(1);
+    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, most + 64))) return rc;
+    uint64_t n = ~0ull;
+    for (uint32_t k = 0; k < n_sources; ++k) {
+        if (W[k].n_window == 0) {  // nothing of this input in the window
+            W[k].n_avail = 0;
+        } else {
+            uint8_t *fa_seq = nullptr;
+            if (format == MK_TEXT_FASTA) {  // the index step compacts the sequences already: every input has a buffer of its own for them
+                if ((rc = ensure_device(&W[k].T->d_fa_seq, &W[k].T->d_fa_seq_cap, W[k].n_window + 64))) return rc;
+                fa_seq = (uint8_t *)W[k].T->d_fa_seq;
             }
+            if ((rc = window_index(m, format, src[k].ends_at_record != 0, W[k], fa_seq, st, status))) return rc;
+            if (*status) return MK_OK;
+        }
+        src[k].n_rec_seen = W[k].n_avail;
+        n = std::min(n, W[k].n_avail);
+    }
+    *n_rec_out = n;
+    if (n > rec_cap || !keep) return fail(MK_E_CAPACITY, "%llu records in the window, room for %llu", (unsigned long long)n, (unsigned long long)rec_cap);
+    // ---- record tables -> host; bytes of the n records per source; the tails
+    std::vector<uint32_t> rs[2];
+    for (uint32_t k = 0; k < n_sources; ++k) {
+        rs[k].assign(n + 1, 0);
+        if (W[k].n_window && hipMemcpyAsync(rs[k].data(), W[k].d_rec_start, (n + 1) * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+            return fail(MK_E_HIP, "copy of the record table failed");
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "copy of the record table failed");
+    for (uint32_t k = 0; k < n_sources; ++k) {
+        mk_window_source &S = src[k];
+        // all of a window that ends at a record end belongs to its records (a last line without '\n' included)
+        W[k].n_used = (n == W[k].n_avail && S.ends_at_record) ? W[k].n_window : (W[k].n_window ? rs[k][n] : 0);
+        rs[k][n] = (uint32_t)W[k].n_used;
+        S.n_used = W[k].n_used;
+        S.n_tail = W[k].n_window - W[k].n_used;
+        if (S.rec_start)
+            for (uint64_t r = 0; r <= n; ++r) S.rec_start[r] = rs[k][r];
+        if (S.tail || S.tail_cap) {
+            if (S.n_tail > S.tail_cap) return fail(MK_E_CAPACITY, "mk_extract_window: the text behind the window's records takes %llu bytes", (unsigned long long)S.n_tail);
+            if (S.n_tail && hipMemcpyAsync(S.tail, (const uint8_t *)W[k].T->d_text + W[k].n_used, S.n_tail, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return fail(MK_E_HIP, "download of the tail failed");
+        }
+        if (S.all) {
+            if (W[k].n_window > S.all_cap) return fail(MK_E_CAPACITY, "mk_extract_window: the window's text takes %llu bytes", (unsigned long long)W[k].n_window);
+            if (W[k].n_window && hipMemcpyAsync(S.all, W[k].T->d_text, W[k].n_window, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return fail(MK_E_HIP, "download of the text failed");
         }
     }
-    // record table -> host: where every record starts in the text, one more entry = the end of the text
-    std::vector<uint32_t> rs(n_rec ? n_rec : 1);
-    if (n_rec && hipMemcpy(rs.data(), d_rec_start, n_rec * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the record table failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "download of the text failed");
     dl.mark(1);
-    dl.host_begin();
-    for (uint64_t r = 0; r < n_rec; ++r) {
-        rec_start[r] = rs[r];
-        keep[r] = (uint8_t)((flags[r] != 0) != (invert != 0));
-        c->nb_records_extracted += keep[r];
+    if (n == 0) return MK_OK;
+    // ---- the loop bodies (src/cmd_extract.rs:321-406 single, :463-612 paired) on the first n records of every source
+    const uint32_t mode = logging ? MK_MODE_HITS : MK_MODE_ANY;
+    std::vector<uint8_t> f[2];
+    uint64_t flagged[2] = {0, 0}, n_seq[2] = {0, 0};
+    unsigned long long found[2] = {0, 0};
+    for (uint32_t k = 0; k < n_sources; ++k) {
+        f[k].resize(n);
+        if ((rc = window_scan(m, format, W[k], n, dl, mode, f[k].data(), &flagged[k], &n_seq[k]))) return rc;
+        found[k] = dl.found;
+        if (paired && k == 0) {
+            // mate 1's flags (the kept text is selected on the device) and tuples wait while mate 2 is scanned
+            if ((rc = ensure_device((void **)&m->d_flags2, &m->d_flags2_cap, n + 8))) return rc;
+            if (hipMemcpyAsync(m->d_flags2, m->d_flags, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(MK_E_HIP, "copy of the flags failed");
+            if (logging && found[0]) {
+                if ((rc = ensure_device(&m->d_pair, &m->d_pair_cap, found[0] * sizeof(mk_hit)))) return rc;
+                if (hipMemcpyAsync(m->d_pair, m->d_hits, found[0] * sizeof(mk_hit), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return fail(MK_E_HIP, "copy of the first mate's tuples failed");
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "copy of the first mate's results failed");
+        }
     }
-    rec_start[n_rec] = n_text;
+    uint64_t total_rows = 0;
+    if (logging && !paired) {
+        c->nb_records_tot += n;
+        c->nb_bases += n_seq[0];
+        c->nb_hits_tot[0] += found[0];
+        c->nb_records_hit[0] += flagged[0];
+        if ((rc = dl.order(ac))) return rc;
+        if ((rc = dl.rows_to_host(0, rows, rows_cap))) return rc;
+        if ((rc = dl.pattern_counts(ac, n, counts))) return rc;
+        total_rows = found[0];
+    } else if (logging) {
+        c->nb_records_tot += 2 * n;  // :472
+        c->nb_bases += n_seq[0] + n_seq[1];
+        c->nb_hits_tot[0] += found[0];
+        c->nb_hits_tot[1] += found[1];
+        c->nb_records_hit[0] += flagged[0];
+        c->nb_records_hit[1] += flagged[1];
+        total_rows = found[0] + found[1];
+        const unsigned long long n1 = found[0], n2 = found[1];
+        if (!ac && std::max(n_seq[0], n_seq[1]) >= (1ull << 31))  // (BNDMq's pair order keeps the mate in bit 31 of the position)
+            return fail(MK_E_UNSUPPORTED, "mk_extract_window: paired windows of 2 GiB of sequence or more under BNDMq");
+        if (total_rows) {
+            // one list: mate 2's tuples (already in the scan buffer), then mate 1's, the mate marked inside a key field
+            if ((n1 + n2) * sizeof(mk_hit) > m->d_hits_cap) {  // grow the scan buffer, keeping mate 2's tuples
+                void *bigger = nullptr;
+                size_t cap = 0;
+                if ((rc = ensure_device(&bigger, &cap, (n1 + n2) * sizeof(mk_hit)))) return rc;
+                if (n2 && hipMemcpy(bigger, m->d_hits, n2 * sizeof(mk_hit), hipMemcpyDeviceToDevice) != hipSuccess) {
+                    (void)hipFree(bigger);
+                    return fail(MK_E_HIP, "copy of the second mate's tuples failed");
+                }
+                if (m->d_hits) (void)hipFree(m->d_hits);
+                m->d_hits = (mk_hit *)bigger;
+                m->d_hits_cap = cap;
+            }
+            if (n1 && hipMemcpyAsync(m->d_hits + n2, m->d_pair, n1 * sizeof(mk_hit), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return fail(MK_E_HIP, "copy of the first mate's tuples failed");
+            launch_pair_mark(m->d_hits, n2, 1, ac, st);
+            launch_pair_mark(m->d_hits + n2, n1, 0, ac, st);
+            dl.found = total_rows;
+            const uint64_t bound = m->last_n_rec;
+            if (ac) m->last_n_rec = 2 * n;  // record' = 2 * record + mate: the bins of the ordering
+            rc = dl.order(ac);
+            m->last_n_rec = bound;
+            if (rc) return rc;
+            if ((rc = dl.pair_rows_to_host(ac, rows, rows_cap))) return rc;
+            if ((rc = dl.pair_counts(ac, counts))) return rc;
+        }
+    }
+    // ---- keep (single :400-405, paired :600-606), on the host for the caller and on the device for the kept records' text
+    dl.host_begin();
+    for (uint64_t r = 0; r < n; ++r) {
+        const bool hit = f[0][r] || (paired && f[1][r]);
+        keep[r] = (uint8_t)(hit != (invert != 0));
+        c->nb_records_extracted += (paired ? 2u : 1u) * keep[r];
+    }
+    dl.mark(1);
+    bool want_kept = false;
+    for (uint32_t k = 0; k < n_sources; ++k) want_kept = want_kept || src[k].kept != nullptr || src[k].kept_cap != 0;
+    if (want_kept) {
+        if ((rc = ensure_device((void **)&m->d_flags2, &m->d_flags2_cap, n + 8))) return rc;
+        if (hipMemcpyAsync(m->d_flags2, keep, n, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the keep flags failed");
+        int cap_rc = MK_OK;
+        for (uint32_t k = 0; k < n_sources; ++k) {
+            if (!src[k].kept && !src[k].kept_cap) continue;
+            rc = window_kept(m, format, W[k], n, m->d_flags2, rs[k], keep, src[k], dl);
+            if (rc == MK_E_CAPACITY) cap_rc = rc;  // (every source reports its need before the call returns)
+            else if (rc) return rc;
+        }
+        if (cap_rc) return cap_rc;
+    }
     dl.finish();
-    if (n_rows) *n_rows = dl.found;
-    if (logging && rows && dl.found > rows_cap) return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)dl.found);
+    if (n_rows) *n_rows = total_rows;
+    if (logging && rows && total_rows > rows_cap) return fail(MK_E_CAPACITY, "rows buffer too small: need %llu", (unsigned long long)total_rows);
     return MK_OK;
+    MK_ABI_END
 }
+
+// (v4 / v5 entry points, kept: one FASTQ source whose window ends at a record end / one bgzip'ed FASTQ source with a head)
 int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, int logging, int invert, uint64_t rec_cap, uint64_t *n_rec_out,
                           uint64_t *rec_start, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *c, uint32_t *counts,
                           uint32_t *status) {
@@ -470,40 +841,11 @@ int mk_extract_fastq_text(mk_matcher *m, const uint8_t *text, uint64_t n_text, i
     *status = 0;
     if (n_rows) *n_rows = 0;
     if (n_text == 0) return MK_OK;
-    if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
-    MK_ABI_BEGIN
-    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
-    DeviceLoop dl(m);
-    hipStream_t st = dl.st;
-    int rc;
-    // the text, and the (upper-bounded) scan buffer it is gathered into.  A window that mk_upload_text_ahead has
-    // already sent (same pointer, same size) is taken from its buffer: the copy ran beside the previous window's work
-    bool ahead = false;
-    {
-        std::lock_guard<std::mutex> lk(m->ahead_mu);
-        for (auto &a : m->ahead) {
-            if (!a.text) continue;
-            if (a.text == text && a.n == n_text && !ahead) {
-                std::swap(m->d_text, a.d);
-                std::swap(m->d_text_cap, a.cap);
-                if (hipStreamWaitEvent(st, a.ev, 0) != hipSuccess) return fail(MK_E_HIP, "hipStreamWaitEvent failed");
-                ahead = true;
-            }
-            // (a slot that holds any other window is stale -- the host did not come back for it: its copy, if still
-            // running, reads page-locked memory the host may be refilling, so let it finish before the slot is reused)
-            else if (hipEventSynchronize(a.ev) != hipSuccess)
-                return fail(MK_E_HIP, "hipEventSynchronize failed");
-            a.text = nullptr;
-        }
-    }
-    if (!ahead && (rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
-    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
-    if (!ahead && hipMemcpyAsync(m->d_text, text, n_text, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the text failed");
-    dl.mark(1);
-    return extract_text_resident(m, dl, n_text, text[n_text - 1], logging, invert, rec_cap, n_rec_out, rec_start, keep, rows, rows_cap, n_rows, c, counts,
-                                 status);
-    MK_ABI_END
+    mk_window_source S;
+    memset(&S, 0, sizeof(S));
+    S.text = text, S.n_text = n_text, S.ends_at_record = 1, S.rec_start = rec_start;
+    if (!rec_start) rec_cap = 0;
+    return mk_extract_window(m, nullptr, MK_TEXT_FASTQ, 1, &S, logging, invert, rec_cap, n_rec_out, keep, rows, rows_cap, n_rows, c, counts, status);
 }
 
 int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, uint64_t n_head, const uint8_t *bgzf, uint64_t n_bgzf,
@@ -513,125 +855,25 @@ int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, u
         (n_members && (!bgzf || !members)))
         return fail(MK_E_INVALID_ARG, "null argument");
     io->n_text = io->n_used = io->n_tail = io->n_kept_bytes = 0;
-    *n_rec_out = 0;
-    uint8_t *const text = io->text;  // != NULL: the whole window text goes back; NULL: its tail and the kept records only
-    *status = 0;
-    if (n_rows) *n_rows = 0;
-    uint64_t n_text = n_head;
-    for (uint64_t i = 0; i < n_members; ++i) {
-        const mk_bgzf_member &b = members[i];
-        if (b.data_off > n_bgzf || b.data_len > n_bgzf - b.data_off || b.isize > 65536 || b.out_off != n_text - n_head)
-            return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: member %llu lies outside its buffer or its text is not in sequence", (unsigned long long)i);
-        n_text += b.isize;
-    }
-    io->n_text = n_text;
-    if (n_text == 0) return MK_OK;
-    if (n_text >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "a text window must be shorter than 4 GiB (%llu bytes)", (unsigned long long)n_text);
-    if (text && io->text_cap < n_text) return fail(MK_E_CAPACITY, "mk_extract_fastq_bgzf: the window's text takes %llu bytes", (unsigned long long)n_text);
-    if (!text && (!io->tail || (io->kept_cap && !io->kept))) return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: neither a text buffer nor tail / kept buffers");
-    MK_ABI_BEGIN
-    if (codec->device != m->device) return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: the codec and the matcher are on different devices");
-    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
-    DeviceLoop dl(m);
-    hipStream_t st = dl.st;
-    int rc;
-    if ((rc = ensure_device(&m->d_text, &m->d_text_cap, n_text + 64))) return rc;
-    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_text + 64))) return rc;
-    uint32_t total_nl = 0;
-    {
-        // the members' bytes and their table go up (a fifth of the text), the text is inflated behind the head in place
-        std::lock_guard<std::mutex> lock(codec->mu);
-        uint64_t in_lo = n_members ? members[0].data_off : 0, in_hi = in_lo;
-        std::vector<mkz::Member> part(n_members);
-        for (uint64_t i = 0; i < n_members; ++i) {
-            in_lo = std::min<uint64_t>(in_lo, members[i].data_off);
-            in_hi = std::max<uint64_t>(in_hi, members[i].data_off + members[i].data_len);
-        }
-        for (uint64_t i = 0; i < n_members; ++i)
-            part[i] = mkz::Member{members[i].data_off - in_lo, n_head + members[i].out_off, members[i].data_len, members[i].isize, members[i].crc, 0};
-        const uint64_t cn = in_hi - in_lo;
-        if ((rc = ensure_device(&codec->d_in, &codec->in_cap, cn + mkz::kPad)) ||
-            (rc = ensure_device(&codec->d_aux, &codec->aux_cap, (n_members + 1) * sizeof(mkz::Member))) ||
-            (rc = ensure_device(&codec->d_len, &codec->len_cap, (n_members + 1) * 4ull)))
-            return rc;
-        if (n_head && hipMemcpyAsync(m->d_text, head, n_head, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the head failed");
-        if (n_members) {
-            if (hipMemcpyAsync(codec->d_in, bgzf + in_lo, cn, hipMemcpyHostToDevice, st) != hipSuccess ||
-                hipMemsetAsync((uint8_t *)codec->d_in + cn, 0, mkz::kPad, st) != hipSuccess ||
-                hipMemcpyAsync(codec->d_aux, part.data(), n_members * sizeof(mkz::Member), hipMemcpyHostToDevice, st) != hipSuccess)
-                return fail(MK_E_HIP, "upload of the members failed");
-            if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the members failed");
-            dl.mark(1);
-            mkz::launch_inflate((const uint8_t *)codec->d_in, cn, (const mkz::Member *)codec->d_aux, (uint32_t)n_members, (uint8_t *)m->d_text,
-                                (int32_t *)codec->d_len, codec->num_cus, st);
-            mkz::launch_crc_check((const uint8_t *)m->d_text, (const mkz::Member *)codec->d_aux, (uint32_t)n_members, (int32_t *)codec->d_len, st);
-            std::vector<int32_t> st_words(n_members);
-            if (hipGetLastError() != hipSuccess ||
-                hipMemcpyAsync(st_words.data(), codec->d_len, n_members * 4ull, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
-                return fail(MK_E_HIP, "BGZF inflate failed");
-            for (uint64_t i = 0; i < n_members; ++i)
-                if (st_words[i])
-                    return fail(MK_E_CORRUPT, st_words[i] > 0 ? "BGZF member %llu: CRC-32 of the inflated text differs from the trailer's (status %d)"
-                                                               : "BGZF member %llu does not inflate to its ISIZE (decoder status %d)",
-                                (unsigned long long)i, st_words[i]);
-        } else if (hipStreamSynchronize(st) != hipSuccess) {
-            return fail(MK_E_HIP, "upload of the head failed");
-        }
-    }
-    // the text goes to the host as well: record ids, kept records and the unfinished record at its end are read there
-    const uint32_t n_blocks = (uint32_t)((n_text + ingest_block_bytes() - 1) / ingest_block_bytes());
-    if ((rc = ensure_device(&m->d_ing_a, &m->d_ing_a_cap, ((size_t)n_blocks + 8) * 4))) return rc;
-    uint32_t *d_block = (uint32_t *)m->d_ing_a, *d_total = d_block + n_blocks;
-    launch_ingest_count((const uint8_t *)m->d_text, n_text, d_block, d_total, st);
-    // what the host must see: all of the text (mode with io->text), or only its end -- where the last whole record ends
-    // is found there -- and, later, the kept records
-    constexpr uint64_t kTailRegion = 1u << 20;
-    const uint64_t reg0 = text ? 0 : (n_text > kTailRegion ? n_text - kTailRegion : 0);  // host copy = text[reg0, n_text)
-    std::vector<uint8_t> region;
-    if (!text) region.resize(n_text - reg0);
-    uint8_t *const host = text ? text : region.data() - reg0;  // host[i] is valid for reg0 <= i < n_text
-    if (hipMemcpyAsync(&total_nl, d_total, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(host + reg0, (const uint8_t *)m->d_text + reg0, n_text - reg0, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return fail(MK_E_HIP, "download of the text failed");
-    dl.mark(1);
-    // whole records only: the window starts at a record start, a record is four lines
-    uint64_t n_used = n_text;
-    if (last) {
-        const uint64_t lines = (uint64_t)total_nl + (host[n_text - 1] != '\n' ? 1 : 0);
-        if (lines % 4 != 0) {  // an unfinished record at the end of the input: the caller's reader words that error
-            *status = 1;
-            return MK_OK;
-        }
+    if (!io->text && (!io->tail || (io->kept_cap && !io->kept))) return fail(MK_E_INVALID_ARG, "mk_extract_fastq_bgzf: neither a text buffer nor tail / kept buffers");
+    mk_window_source S;
+    memset(&S, 0, sizeof(S));
+    S.head = head, S.n_head = n_head, S.bgzf = bgzf, S.n_bgzf = n_bgzf, S.members = members, S.n_members = n_members;
+    S.ends_at_record = last ? 1 : 0;
+    S.rec_start = rec_start;
+    if (!rec_start) rec_cap = 0;
+    std::vector<uint8_t> dummy(1);
+    if (io->text) {
+        S.all = io->text, S.all_cap = io->text_cap;
     } else {
-        while (n_used > reg0 && host[n_used - 1] != '\n') --n_used;  // the unfinished last line
-        for (uint32_t drop = total_nl % 4; drop > 0 && n_used > reg0; --drop) {
-            --n_used;
-            while (n_used > reg0 && host[n_used - 1] != '\n') --n_used;
-        }
-        if (n_used == reg0 && reg0 > 0) {  // the last record start lies further back than the region that came down
-            *status = 1;
-            return MK_OK;
-        }
+        S.tail = io->tail, S.tail_cap = io->tail_cap;
+        S.kept = io->kept ? io->kept : dummy.data(), S.kept_cap = io->kept_cap;
     }
-    io->n_used = n_used;
-    if (n_used == 0) {  // not one whole record in the window
-        *status = last ? 0u : 1u;
-        return MK_OK;
-    }
-    KeptText kept{io->kept, io->kept_cap, 0};
-    if (!text) {
-        io->n_tail = n_text - n_used;
-        if (io->n_tail > io->tail_cap) return fail(MK_E_CAPACITY, "mk_extract_fastq_bgzf: the unfinished record at the window's end takes %llu bytes", (unsigned long long)io->n_tail);
-        memcpy(io->tail, host + n_used, io->n_tail);
-    }
-    const uint8_t last_byte = n_used > reg0 ? host[n_used - 1] : (uint8_t)'\n';
-    rc = extract_text_resident(m, dl, n_used, last_byte, logging, invert, rec_cap, n_rec_out, rec_start, keep, rows, rows_cap, n_rows, c, counts, status,
-                               text ? nullptr : &kept);
-    io->n_kept_bytes = kept.n_bytes;
+    const int rc = mk_extract_window(m, codec, MK_TEXT_FASTQ, 1, &S, logging, invert, rec_cap, n_rec_out, keep, rows, rows_cap, n_rows, c, counts, status);
+    io->n_text = S.n_window, io->n_used = S.n_used, io->n_tail = io->text ? 0 : S.n_tail, io->n_kept_bytes = S.n_kept_bytes;
+    // (v5 contract: a window without one whole record is the caller's reader's business -- unless nothing follows it)
+    if (rc == MK_OK && !*status && S.n_window && S.n_used == 0) *status = last ? 0u : 1u;
     return rc;
-    MK_ABI_END
 }
 
 // the pair loop with the rows merged on the host (mates of 2 GiB or more under BNDMq: the device pair order keeps

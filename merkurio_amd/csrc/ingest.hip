@@ -140,6 +140,8 @@ __global__ __launch_bounds__(256) void mk_ingest_records_kernel(const uint8_t *_
                                                                uint32_t *__restrict__ seq_len, uint32_t *__restrict__ st) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bad = 0, len = 0;
+    // rec_start[n_rec]: the first byte behind the last whole record (= n when the text ends with that record)
+    if (i == n_rec) rec_start[n_rec] = min(line_start[4 * n_rec], (uint32_t)n);
     bool live = i < n_rec;
     if (live) {
         const uint32_t l0 = line_start[4 * i], l1 = line_start[4 * i + 1], l2 = line_start[4 * i + 2], l3 = line_start[4 * i + 3],
@@ -237,11 +239,12 @@ __global__ __launch_bounds__(256) void mk_ingest_offsets_kernel(const uint32_t *
 // sequence line of record i -> seq[dst, dst + len): 16 lanes per record, bytes
 __global__ __launch_bounds__(256) void mk_ingest_gather_kernel(const uint8_t *__restrict__ text, const uint32_t *__restrict__ seq_start,
                                                               const uint32_t *__restrict__ seq_len, const unsigned long long *__restrict__ off,
-                                                              uint32_t fixed_len, uint64_t n_rec, uint8_t *__restrict__ seq) {
+                                                              uint32_t fixed_len, uint64_t n_rec, uint8_t *__restrict__ seq, uint32_t skip_from) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t sub = threadIdx.x & 15u;
     if (i >= n_rec) return;
     const uint32_t len = seq_len[i];
+    if (len >= skip_from) return;  // (a chromosome-sized record is not a job for 16 lanes: the caller copies those one by one)
     const uint8_t *__restrict__ src = text + seq_start[i];
     uint8_t *__restrict__ dst = seq + (fixed_len ? i * (uint64_t)fixed_len : off[i]);
     for (uint32_t k = sub; k < len; k += 16) dst[k] = src[k];
@@ -255,6 +258,164 @@ __global__ __launch_bounds__(256) void mk_ingest_select_kernel(const uint8_t *__
     if (i >= n_rec) return;
     const uint32_t end = i + 1 < n_rec ? rec_start[i + 1] : n_text;
     sel_len[i] = ((flags[i] != 0) != (invert != 0)) ? end - rec_start[i] : 0u;
+}
+
+// ---- FASTA (r05): '>' header lines, every other line is sequence; record.seq() is the sequence lines without their '\n' and '\r'
+// bytes (needletail strips both; cli/io.cpp: FastxFile::append_seq).  On the device that is a byte compaction of the window's text:
+// a byte is kept iff it lies in a sequence line and is neither '\n' nor '\r'.  Two passes over the text, a thread per 64 bytes:
+// count (kept bytes, header lines) per thread -> per block -> exclusive scan; then the same walk writes the kept bytes to their
+// place in the scan buffer and, at every header line, the record's text offset and sequence offset.  The state "my first byte lies
+// in a header line" comes from the line table (mk_ingest_lines_kernel): the line that holds the thread's first byte starts at
+// line_start[newlines in front of it].  Lines of any length (an unwrapped chromosome is ONE line) cost nothing extra: work is per
+// byte, not per line.
+__device__ __forceinline__ uint32_t eq_mask(uint32_t v, uint32_t c4) {  // 0x80 in every byte of v equal to the byte replicated in c4
+    const uint32_t x = v ^ c4;
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// counts of one thread's 64 bytes: low 32 bits kept bytes, high 32 bits header lines that START in them.  EMIT: the bytes are also
+// written to seq[dst...] and the headers' record entries stored.
+template <bool EMIT>
+__device__ __forceinline__ unsigned long long fa_walk(const uint32_t w[16], uint64_t pos, uint32_t nbytes, bool hdr, bool at_line_start,
+                                                      uint8_t *__restrict__ seq, unsigned long long dst, uint32_t rec, uint32_t *__restrict__ rec_start,
+                                                      unsigned long long *__restrict__ off) {
+    uint32_t kept = 0, heads = 0;
+    bool ls = at_line_start;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t i = 4u * d + b;
+            const uint32_t c = (w[d] >> (8 * b)) & 0xFFu;
+            if (i < nbytes) {
+                if (ls) {
+                    hdr = c == '>';
+                    if (hdr) {
+                        if (EMIT) {
+                            rec_start[rec + heads] = (uint32_t)(pos + i);
+                            off[rec + heads] = dst + kept;
+                        }
+                        ++heads;
+                    }
+                }
+                const bool keep = !hdr && c != '\n' && c != '\r';
+                if (keep) {
+                    if (EMIT) seq[dst + kept] = (uint8_t)c;
+                    ++kept;
+                }
+                ls = c == '\n';
+            }
+        }
+    }
+    return (unsigned long long)heads << 32 | kept;
+}
+
+// newlines in front of this thread's first byte, within its block (exclusive), from the per-thread counts
+__device__ __forceinline__ uint32_t block_excl_u32(uint32_t c, uint32_t *wave_sum) {
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += u;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - c;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) before += wave_sum[wv];
+    __syncthreads();
+    return before;
+}
+__device__ __forceinline__ unsigned long long block_excl_u64(unsigned long long c, unsigned long long *wave_sum, unsigned long long *total) {
+    unsigned long long incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += u;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long before = incl - c;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) before += wave_sum[wv];
+    if (total) *total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    __syncthreads();
+    return before;
+}
+
+// EMIT = false: block_sum[b] = (header lines << 32 | kept bytes) of block b.  EMIT = true: block_sum holds the exclusive scan of
+// those, the kept bytes go to seq and every header line writes rec_start / off of its record; the thread that holds the text's
+// last byte closes the tables: rec_start[records] = n, off[records] = kept bytes.
+template <bool EMIT>
+__global__ __launch_bounds__(kIngestThreads) void mk_ingest_fa_kernel(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ nl_block_off,
+                                                                      const uint32_t *__restrict__ line_start, unsigned long long *__restrict__ block_sum,
+                                                                      uint8_t *__restrict__ seq, uint32_t *__restrict__ rec_start,
+                                                                      unsigned long long *__restrict__ off) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ unsigned long long wave_sum64[4];
+    const uint64_t pos = (uint64_t)blockIdx.x * kIngestBlockBytes + threadIdx.x * kIngestBytesPerThread;
+    uint32_t w[16];
+    uint32_t c = 0, nbytes = 0;
+    if (pos < n) {
+        load64(text, pos, n, w);
+        nbytes = (uint32_t)min((uint64_t)64, n - pos);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c += __popc(nl_mask(w[k]));
+        // (bytes at or beyond n read as 0: never '\n')
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = 0;
+    }
+    const uint32_t line = nl_block_off[blockIdx.x] + block_excl_u32(c, wave_sum);  // the line that holds byte `pos`
+    bool hdr = false, at_ls = false;
+    if (pos < n) {
+        const uint32_t ls = line_start[line];
+        at_ls = ls == (uint32_t)pos;
+        hdr = text[ls] == '>';
+    }
+    const unsigned long long mine = fa_walk<false>(w, pos, nbytes, hdr, at_ls, nullptr, 0, 0, nullptr, nullptr);
+    unsigned long long total = 0;
+    const unsigned long long before = block_excl_u64(mine, wave_sum64, &total);
+    if (!EMIT) {
+        if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+        return;
+    }
+    const unsigned long long base = block_sum[blockIdx.x] + before;
+    if (nbytes) fa_walk<true>(w, pos, nbytes, hdr, at_ls, seq, base & 0xFFFFFFFFull, (uint32_t)(base >> 32), rec_start, off);
+    if (pos < n && pos + 64 >= n) {
+        const unsigned long long end = base + mine;
+        rec_start[end >> 32] = (uint32_t)n;
+        off[end >> 32] = end & 0xFFFFFFFFull;
+    }
+}
+
+// FASTA index + gather of a window whose line table exists (launch_ingest_count + mk_ingest_lines_kernel have run): d_block64 gets the
+// scanned per-block sums, d_block64[n_blocks] the totals (header lines << 32 | sequence bytes); the caller reads them, then
+// launch_ingest_fasta_emit fills seq / rec_start / off (records + 1 entries each)
+void launch_ingest_fasta_count(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl_block_off, const uint32_t *d_line_start,
+                               unsigned long long *d_block64, hipStream_t st) {
+    const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
+    hipLaunchKernelGGL(mk_ingest_fa_kernel<false>, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_nl_block_off, d_line_start, d_block64,
+                       (uint8_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    // exclusive scan in place over n_blocks + 1 entries (the last one, cleared by the caller, receives the total)
+    hipLaunchKernelGGL(mk_ingest_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, d_block64, n_blocks + 1);
+}
+void launch_ingest_fasta_emit(const uint8_t *d_text, uint64_t n, const uint32_t *d_nl_block_off, const uint32_t *d_line_start,
+                              unsigned long long *d_block64, uint8_t *d_seq, uint32_t *d_rec_start, unsigned long long *d_off, hipStream_t st) {
+    const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
+    hipLaunchKernelGGL(mk_ingest_fa_kernel<true>, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_nl_block_off, d_line_start, d_block64, d_seq,
+                       d_rec_start, d_off);
+}
+// the line table alone (FASTA: no record kernel follows it)
+void launch_ingest_lines(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start, hipStream_t st) {
+    const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
+    hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start);
+}
+
+// flags |= other (paired windows: a pair is kept if either mate hits, src/cmd_extract.rs:600-606)
+__global__ __launch_bounds__(256) void mk_ingest_or_flags_kernel(uint8_t *__restrict__ flags, const uint8_t *__restrict__ other, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] |= other[i];
+}
+void launch_ingest_or_flags(uint8_t *d_flags, const uint8_t *d_other, uint64_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(mk_ingest_or_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_flags, d_other, n);
 }
 
 void launch_ingest_select(const uint8_t *d_flags, uint32_t invert, const uint32_t *d_rec_start, uint64_t n_rec, uint32_t n_text, uint32_t *d_sel_len,
@@ -274,9 +435,9 @@ void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_
                            uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status, hipStream_t st) {
     const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
     hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start);
-    if (n_rec)
-        hipLaunchKernelGGL(mk_ingest_records_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, d_text, n, d_line_start, n_rec, d_rec_start,
-                           d_seq_start, d_seq_len, d_status);
+    // (n_rec + 1 lanes: the last one writes the end of the records)
+    hipLaunchKernelGGL(mk_ingest_records_kernel, dim3((unsigned)((n_rec + 1 + 255) / 256)), dim3(256), 0, st, d_text, n, d_line_start, n_rec, d_rec_start,
+                       d_seq_start, d_seq_len, d_status);
 }
 
 void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st) {
@@ -287,10 +448,10 @@ void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned l
 }
 
 void launch_ingest_gather(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off,
-                          uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st) {
+                          uint32_t fixed_len, uint64_t n_rec, uint8_t *d_seq, hipStream_t st, uint32_t skip_from) {
     if (!n_rec) return;
     hipLaunchKernelGGL(mk_ingest_gather_kernel, dim3((unsigned)((n_rec * 16 + 255) / 256)), dim3(256), 0, st, d_text, d_seq_start, d_seq_len, d_off,
-                       fixed_len, n_rec, d_seq);
+                       fixed_len, n_rec, d_seq, skip_from);
 }
 
 uint32_t ingest_block_bytes() { return kIngestBlockBytes; }

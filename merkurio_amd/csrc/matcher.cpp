@@ -527,7 +527,7 @@ void mk_matcher_destroy(mk_matcher *m) {
     for (void *p : {(void *)m->d_bloom, (void *)m->d_table, (void *)m->d_pat_bytes, (void *)m->d_pat_off,
                     (void *)m->d_seq, (void *)m->d_off, (void *)m->d_flags, (void *)m->d_hits, (void *)m->d_nhits,
                     (void *)m->d_stage, (void *)m->d_rec_index, (void *)m->d_flag_list, (void *)m->d_flag_counts, m->d_sort_tmp,
-                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux, m->d_pair, (void *)m->d_short_table, m->d_text, m->d_ing_a, m->d_ing_b, m->ahead[0].d, m->ahead[1].d})
+                    (void *)m->d_pat_rank, (void *)m->d_pat_unrank, (void *)m->d_error, m->d_aux, m->d_pair, (void *)m->d_short_table, m->txt[0].d_text, m->txt[0].d_ing_a, m->txt[0].d_ing_b, m->txt[1].d_text, m->txt[1].d_ing_a, m->txt[1].d_ing_b, m->txt[0].d_fa_seq, m->txt[1].d_fa_seq, (void *)m->d_flags2, m->ahead[0].d, m->ahead[1].d, m->ahead[2].d, m->ahead[3].d})
         if (p) (void)hipFree(p);
     delete m;
 }

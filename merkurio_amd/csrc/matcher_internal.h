@@ -76,10 +76,15 @@ struct mk_matcher {
     void *d_pair = nullptr;  // paired extract: mate 1's tuples while mate 2 is scanned
     size_t d_pair_cap = 0;
     // mk_extract_fastq_text (ingest.hip): the window's raw text, block counts + status words, line / record tables
-    void *d_text = nullptr, *d_ing_a = nullptr, *d_ing_b = nullptr;
-    size_t d_text_cap = 0, d_ing_a_cap = 0, d_ing_b_cap = 0;
-    // mk_upload_text_ahead: text windows copied on a stream of their own while the current window is processed.  Two
-    // slots, so that an upload that arrives before the previous one was consumed cannot overwrite it; the slot
+    // (r05: one slot per input file of a window -- mk_extract_window takes paired inputs)
+    struct TextSlot {
+        void *d_text = nullptr, *d_ing_a = nullptr, *d_ing_b = nullptr, *d_fa_seq = nullptr;  // d_fa_seq: FASTA sequences without line ends
+        size_t d_text_cap = 0, d_ing_a_cap = 0, d_ing_b_cap = 0, d_fa_seq_cap = 0;
+    } txt[2];
+    uint8_t *d_flags2 = nullptr;  // paired windows: mate 1's flags while mate 2 is scanned; the keep flags the kept records are selected by
+    size_t d_flags2_cap = 0;
+    // mk_upload_text_ahead: text windows copied on a stream of their own while the current window is processed.  Four
+    // slots (two windows of two inputs), so that an upload that arrives before the previous one was consumed cannot overwrite it; the slot
     // states are guarded by ahead_mu (the uploader may be another host thread than the one inside the extract call).
     struct AheadSlot {
         void *d = nullptr;
@@ -87,7 +92,7 @@ struct mk_matcher {
         hipEvent_t ev = nullptr;
         const uint8_t *text = nullptr;  // != nullptr: holds (or is receiving) text[0, n), not consumed yet
         uint64_t n = 0;
-    } ahead[2];
+    } ahead[4];
     hipStream_t stream_ahead = nullptr;
     std::mutex ahead_mu;
     // where the last driver-loop call (mk_extract_single / mk_tag_records) spent its time, milliseconds:

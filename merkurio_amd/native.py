@@ -53,7 +53,7 @@ EXPORTS = [
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
-    "mk_codec_times", "mk_codec_set_pass_limits", "mk_extract_fastq_bgzf",
+    "mk_codec_times", "mk_codec_set_pass_limits", "mk_extract_fastq_bgzf", "mk_extract_window",
 ]
 
 
@@ -91,6 +91,18 @@ class WindowText(C.Structure):
     """mk_window_text (include/merkurio_hip.h): what mk_extract_fastq_bgzf hands back of a window's text"""
     _fields_ = [("text", C.c_void_p), ("text_cap", C.c_uint64), ("tail", C.c_void_p), ("tail_cap", C.c_uint64), ("kept", C.c_void_p),
                 ("kept_cap", C.c_uint64), ("n_text", C.c_uint64), ("n_used", C.c_uint64), ("n_tail", C.c_uint64), ("n_kept_bytes", C.c_uint64)]
+
+
+class WindowSource(C.Structure):
+    """mk_window_source (include/merkurio_hip.h, v6): one input file's part of a window handed to mk_extract_window"""
+    _fields_ = [("head", C.c_void_p), ("n_head", C.c_uint64), ("text", C.c_void_p), ("n_text", C.c_uint64), ("bgzf", C.c_void_p),
+                ("n_bgzf", C.c_uint64), ("members", C.c_void_p), ("n_members", C.c_uint64), ("ends_at_record", C.c_uint32),
+                ("reserved", C.c_uint32), ("rec_start", C.c_void_p), ("tail", C.c_void_p), ("tail_cap", C.c_uint64), ("kept", C.c_void_p),
+                ("kept_cap", C.c_uint64), ("all", C.c_void_p), ("all_cap", C.c_uint64), ("n_window", C.c_uint64), ("n_used", C.c_uint64),
+                ("n_tail", C.c_uint64), ("n_kept_bytes", C.c_uint64), ("n_rec_seen", C.c_uint64)]
+
+
+MK_TEXT_FASTQ, MK_TEXT_FASTA = 0, 1
 
 
 class Counters(C.Structure):
@@ -215,6 +227,9 @@ def load(build_if_missing=True):
     L.mk_extract_fastq_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
                                         C.POINTER(WindowText), C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mk_extract_window.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64),
+                                    C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mk_matcher_order_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(Counters), C.c_void_p]
@@ -567,6 +582,91 @@ class Matcher:
         out_rows = [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else []
         out_text = text[:io.n_text].tobytes() if whole_text else (tail[:io.n_tail].tobytes(), text[:io.n_kept_bytes].tobytes())
         return (status.value, out_text, io.n_used, rec_start[:n + 1].tolist(), [bool(k) for k in keep[:n]], out_rows, c2.as_dict(k2))
+
+    def extract_window(self, sources, fmt=MK_TEXT_FASTQ, logging=True, invert=False, codec=None, want=("tail",)):
+        """mk_extract_window.  sources: one dict per input file (one = single, two = paired) with keys
+             head (bytes, default b""), text (bytes) OR blob + members (bgzf_members entries), ends_at_record (bool)
+        want: which texts come back per source, any of "tail", "kept", "all".
+        -> dict(status, n_rec, keep, rows, counters, sources=[dict(n_window, n_used, n_rec_seen, rec_start, tail, kept, all)])"""
+        L = load()
+        n_src = len(sources)
+        arr = (WindowSource * n_src)()
+        hold = []
+        bound = 0
+        for k, sd in enumerate(sources):
+            S = arr[k]
+            head = np.frombuffer(sd.get("head", b""), dtype=np.uint8)
+            hold.append(head)
+            S.head, S.n_head = (head.ctypes.data if head.size else None), head.size
+            n_body = 0
+            if "members" in sd:
+                mem = sd["members"].copy()
+                if len(mem):
+                    mem["out_off"] -= mem["out_off"][0]
+                blob = np.frombuffer(sd["blob"], dtype=np.uint8)
+                hold += [mem, blob]
+                S.bgzf, S.n_bgzf = (blob.ctypes.data if blob.size else None), blob.size
+                S.members, S.n_members = (mem.ctypes.data if len(mem) else None), len(mem)
+                n_body = int(mem["isize"].sum()) if len(mem) else 0
+            else:
+                text = np.frombuffer(sd.get("text", b""), dtype=np.uint8)
+                hold.append(text)
+                S.text, S.n_text = (text.ctypes.data if text.size else None), text.size
+                n_body = text.size
+            S.ends_at_record = int(bool(sd.get("ends_at_record", True)))
+            bound = max(bound, head.size + n_body)
+        cap = max(1, bound // (2 if fmt == MK_TEXT_FASTA else 8) + 2)
+        bufs = []
+        for k in range(n_src):
+            S = arr[k]
+            b = {"rec_start": np.zeros(cap + 1, dtype=np.uint64), "tail": np.zeros(64, dtype=np.uint8), "kept": np.zeros(64, dtype=np.uint8),
+                 "all": np.zeros(max(1, bound), dtype=np.uint8)}
+            bufs.append(b)
+            S.rec_start = b["rec_start"].ctypes.data
+            if "tail" in want:
+                S.tail, S.tail_cap = b["tail"].ctypes.data, b["tail"].size
+            if "kept" in want:
+                S.kept, S.kept_cap = b["kept"].ctypes.data, b["kept"].size
+            if "all" in want:
+                S.all, S.all_cap = b["all"].ctypes.data, b["all"].size
+        n_rec, status, n_rows = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        keep = np.zeros(cap, dtype=np.uint8)
+        rows = np.zeros(4096, dtype=ROW_DTYPE)
+        for _ in range(8):
+            c2, k2 = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+            rc = L.mk_extract_window(self._h, codec._h if codec else None, fmt, n_src, arr, int(logging), int(invert), cap, C.byref(n_rec),
+                                     keep.ctypes.data, rows.ctypes.data, len(rows), C.byref(n_rows), C.byref(c2), k2.ctypes.data, C.byref(status))
+            if rc == MK_E_CAPACITY:  # the call states every need: grow what was too small and ask again
+                grown = False
+                if n_rows.value > len(rows):
+                    rows = np.zeros(n_rows.value, dtype=ROW_DTYPE)
+                    grown = True
+                for k in range(n_src):
+                    S, b = arr[k], bufs[k]
+                    if "tail" in want and S.n_tail > S.tail_cap:
+                        b["tail"] = np.zeros(S.n_tail, dtype=np.uint8)
+                        S.tail, S.tail_cap = b["tail"].ctypes.data, b["tail"].size
+                        grown = True
+                    if "kept" in want and S.n_kept_bytes > S.kept_cap:
+                        b["kept"] = np.zeros(S.n_kept_bytes, dtype=np.uint8)
+                        S.kept, S.kept_cap = b["kept"].ctypes.data, b["kept"].size
+                        grown = True
+                if grown:
+                    continue
+            _check(rc)
+            break
+        n = n_rec.value
+        out = {"status": status.value, "n_rec": n, "keep": [bool(x) for x in keep[:n]],
+               "rows": [(int(r["file"]), int(r["rec"]), int(r["pat"]), int(r["pos"])) for r in rows[:n_rows.value]] if logging else [],
+               "counters": c2.as_dict(k2), "sources": []}
+        for k in range(n_src):
+            S, b = arr[k], bufs[k]
+            out["sources"].append({"n_window": S.n_window, "n_used": S.n_used, "n_rec_seen": S.n_rec_seen,
+                                   "rec_start": b["rec_start"][:n + 1].tolist() if not status.value else [],
+                                   "tail": b["tail"][:S.n_tail].tobytes() if "tail" in want else None,
+                                   "kept": b["kept"][:S.n_kept_bytes].tobytes() if "kept" in want else None,
+                                   "all": b["all"][:S.n_window].tobytes() if "all" in want else None})
+        return out
 
     def extract_paired(self, seqs1, seqs2, logging=True, invert=False):
         d1, o1 = pack_records(seqs1)
