@@ -19,28 +19,12 @@
 
 #include "../../../include/merkurio_hip.h"
 #include "io.hpp"
+#include "extract_common.hpp"
 
 namespace cli {
 
 static const char *kProgram = "merkurio";
 static const char *kVersion = "1.0.0";  // crate version of the reference tree (Cargo.toml:3)
-
-// MERKURIO_TIMING=1: phase wall times on stderr (where does an end-to-end run spend its time)
-struct PhaseTimer {
-    bool on = getenv("MERKURIO_TIMING") != nullptr;
-    double t0 = now();
-    static double now() {
-        struct timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec + ts.tv_nsec * 1e-9;
-    }
-    void mark(const char *what) {
-        if (!on) return;
-        const double t = now();
-        fprintf(stderr, "[timing] %-28s %8.3f s\n", what, t - t0);
-        t0 = t;
-    }
-};
 
 // The handles of a finished command.  The program that is about to end (main.cpp: every output is flushed and closed when
 // run_extract / run_tag return, then the process leaves through _exit) does not free device memory, streams and
@@ -69,16 +53,6 @@ static void report_order_paths(const std::vector<mk_matcher *> &ms) {
         fprintf(stderr, "Note: %llu of %llu emission-order calls fell back to the library merge sort (hit tuples that defeat both binnings)\n",
                 (unsigned long long)tot[3], (unsigned long long)(tot[1] + tot[2] + tot[3]));
 }
-
-static void mk_check(int rc, const char *what) {
-    if (rc != MK_OK) bail(std::string(what) + ": " + mk_last_error());
-}
-
-struct Patterns {
-    std::vector<std::string> list;
-    std::vector<uint8_t> bytes;
-    std::vector<uint32_t> off;
-};
 
 // helpers::parse_pattern_list (src/helpers.rs:76-133) through the library
 static Patterns load_patterns(const CommonArgs &a) {
@@ -125,13 +99,6 @@ static Patterns load_patterns(const CommonArgs &a) {
     return p;
 }
 
-struct Loggers {
-    TextLogger text;
-    JsonLogger json;
-    bool active = false;
-    bool has_json = false;
-};
-
 static void open_loggers(const CommonArgs &a, Loggers &lg) {
     if (a.out_log) {
         lg.text.out.reset(new Sink());
@@ -146,35 +113,6 @@ static void open_loggers(const CommonArgs &a, Loggers &lg) {
         lg.has_json = true;
     }
     lg.active = a.out_log || a.json_log;
-}
-
-// The log rows of a batch (reference emission order), formatted by the host threads -- a batch in which every read
-// hits carries millions of rows, and one thread building them took four times the rest of the run -- and written
-// in order.  id_of(row) -> the record id's bytes; file_of(row) -> the file name to log.
-template <class IdOf, class FileOf>
-static void emit_log_rows(Loggers &lg, const Patterns &pats, const mk_row *rows, uint64_t n_rows, IdOf id_of, FileOf file_of) {
-    if (!lg.active || n_rows == 0) return;
-    const bool text = lg.text.out != nullptr, json = lg.has_json;
-    const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), n_rows / 2048));
-    std::vector<std::string> tb(T), jb(T);
-    const bool first_row_of_log = json && lg.json.first;
-    run_threads(T, [&](size_t t) {
-        const uint64_t lo = n_rows * t / T, hi = n_rows * (t + 1) / T;
-        if (text) tb[t].reserve((hi - lo) * 96);
-        if (json) jb[t].reserve((hi - lo) * 176);
-        for (uint64_t k = lo; k < hi; ++k) {
-            const mk_row &r = rows[k];
-            const std::pair<const char *, size_t> id = id_of(r);
-            const std::string &file = file_of(r);
-            if (text) TextLogger::format(tb[t], file, id.first, id.second, pats.list[r.pat], r.pos);
-            if (json) JsonLogger::format(jb[t], !(first_row_of_log && k == 0), file, id.first, id.second, pats.list[r.pat], r.pos);
-        }
-    });
-    for (size_t t = 0; t < T; ++t) {
-        if (text) lg.text.out->write(tb[t]);
-        if (json) lg.json.out->write(jb[t]);
-    }
-    if (json) lg.json.first = false;
 }
 
 // ---- --gpus N: one matcher handle + one host thread per device, contiguous record ranges ---------
@@ -351,66 +289,25 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     const std::vector<int> devs = device_list(a);
     std::future<std::vector<mk_matcher *>> fm = std::async(std::launch::async, [&] { return make_matchers(a, pats, devs, &use_ac); });
 
-    // The inputs are read a window at a time (--window-mb of text, decompressed if need be): the host holds
+    // Default: everything `extract` reads goes to the device as windows of raw text (extract_windows.cpp: FASTQ or FASTA, one file or
+    // a pair, plain / gzip / bgzip'ed, one GPU or several).  --host-ingest, and inputs that path does not take, are parsed here.
+    WindowExtract wx;
+    bool by_windows = false;
+    // The host reader: the inputs are read a window at a time (--window-mb of text, decompressed if need be): the host holds
     // one window and its record index, like the reference, which streams records.
     FastxStream s1, s2;
     FastxFile &f1 = s1.view, &f2 = s2.view;
     const bool paired = (bool)a.in_fastq_2;
     const uint64_t window_bytes = (uint64_t)a.window_mb << 20;
     bool more1 = false, more2 = false;
-    // Device ingest: a single FASTQ input on one GPU is not parsed here at all -- the raw text of a
-    // window is copied into page-locked memory, uploaded and indexed on the device (mk_extract_fastq_text); the
-    // host reader below stays the fallback for everything the device refuses (and its byte-identical checker).
-    const bool device_ingest = !paired && devs.size() == 1 && !a.host_ingest;
-    // ... and a bgzip'ed FASTQ is not even inflated here: its members go up as they are (mk_extract_fastq_bgzf)
-    bool bgzf_device = false;
-    struct RawBuffer {  // that path's window text: uninitialised memory (no fill pass), first touched while the HIP runtime starts
-        std::unique_ptr<char[]> p;
-        uint64_t cap = 0;
-        void need(uint64_t n) {
-            if (n <= cap) return;
-            p.reset(new char[n]);
-            cap = n;
-        }
-    } bgzf_text;
-    const char *raw_text = nullptr;
-    uint64_t raw_n = 0, raw_resume = 0;
-    bool raw_more = false, raw_refused = false;
-    // (windows of 128 MB: the copy into pinned memory of window k + 1 overlaps upload + scan of window k; page-locking
-    // a buffer costs ~0.1 ms per MB, so the two staging buffers stay small)
-    // (with logs every window also pays the ordering / row / count round trips: fewer, larger windows)
-    const uint64_t raw_window = std::min<uint64_t>(window_bytes, (a.out_log || a.json_log) ? 256ull << 20 : 128ull << 20);
     try {
-        s1.open(a.in_fastx);
-        if (paired) s2.open(*a.in_fastq_2);
-        // (the first window is small and goes up from where it lies: page-locked buffers need the HIP runtime, which
-        // is still starting on the matcher thread; the staging of window 2 then overlaps window 1)
-        bgzf_device = device_ingest && !a.host_codec && s1.raw_is_bgzf();
-        if (device_ingest && !bgzf_device) raw_more = s1.raw_fill(std::min<uint64_t>(raw_window, 32ull << 20), &raw_text, &raw_n, &raw_resume);
-        if (!raw_more && !bgzf_device) more1 = s1.fill(window_bytes);
-        if (bgzf_device && a.invert_match && lg.active) {
-            // (-v with a log: the whole text of a window comes back, see the loop below)
-            // nothing to inflate or parse here; the window's text will come back from the device into this buffer: a copy
-            // into memory that was never touched takes a page fault per 4 KiB (0.15 s per GiB) -- take them now, on all
-            // host threads, while the matcher thread waits for the HIP runtime
-            const WindowSource &ws = s1.source();
-            uint64_t first = 0;
-            const uint64_t target = std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
-            for (size_t i = 0; i < ws.n_bgzf_members() && first < target; ++i) {
-                uint64_t off;
-                uint32_t len, isize, crc;
-                ws.bgzf_member_at(i, &off, &len, &isize, &crc);
-                first += isize;
-            }
-            bgzf_text.need(first + (1u << 20));
-            char *p = bgzf_text.p.get();
-            const uint64_t cap = bgzf_text.cap;
-            const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (size_t)(cap >> 24) + 1));
-            run_threads(T, [&](size_t t) {
-                for (uint64_t q = cap * t / T; q < cap * (t + 1) / T; q += 4096) p[q] = 0;
-            });
+        by_windows = !a.host_ingest && wx.prepare(a, devs);
+        if (!by_windows) {
+            s1.open(a.in_fastx);
+            if (paired) s2.open(*a.in_fastq_2);
+            more1 = s1.fill(window_bytes);
+            if (paired) more2 = s2.fill(window_bytes);
         }
-        if (paired) more2 = s2.fill(window_bytes);
     } catch (...) {
         fm.get();  // a matcher error comes first, as in the serial order of the reference
         throw;
@@ -542,305 +439,17 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             cur ^= 1;
         }
     };
-    // what a device-indexed window leaves to the host: counters, log rows, the kept records written from the window's text
-    std::vector<uint64_t> rec_start;
-    std::vector<uint8_t> keep;
-    std::vector<mk_row> rows(4096);
-    auto accept_window = [&](const char *text, uint64_t n_text, uint64_t n_rec, uint64_t n_rows, const mk_counters &cb,
-                             const std::vector<uint32_t> &cnt_b) {
-        c.nb_records_tot += cb.nb_records_tot; c.nb_bases += cb.nb_bases;
-        c.nb_hits_tot[0] += cb.nb_hits_tot[0]; c.nb_records_hit[0] += cb.nb_records_hit[0];
-        c.nb_records_extracted += cb.nb_records_extracted;
-        for (size_t k = 0; k < counts.size(); ++k) counts[k] += cnt_b[k];
-        tm.mark("window: H2D + index + scan + D2H");
-        // id of a record: its header line without '@' and line end
-        auto id_of = [&](uint64_t r) {
-            const uint64_t b = rec_start[r] + 1;
-            const char *nl = (const char *)memchr(text + b, '\n', (size_t)(rec_start[r + 1] - b));
-            uint64_t e = nl ? (uint64_t)(nl - text) : rec_start[r + 1];
-            if (e > b && text[e - 1] == '\r') --e;
-            return std::pair<const char *, size_t>(text + b, (size_t)(e - b));
-        };
-        emit_log_rows(lg, pats, rows.data(), lg.active ? n_rows : 0, [&](const mk_row &r) { return id_of(r.rec); },
-                      [&](const mk_row &) -> const std::string & { return name1; });
-        if (!a.suppress_output) {
-            // kept records are written by the host reader's own code from the record's four lines
-            FastxFile one;
-            one.fastq = true;
-            one.data = text;
-            one.data_n = n_text;
-            for (uint64_t k = 0; k < n_rec; ++k)
-                if (keep[k]) {
-                    one.recs.clear();
-                    one.parse_span(rec_start[k], rec_start[k + 1]);
-                    // record.write(_, None) re-emits the four lines with a bare '+': a record that is
-                    // stored that way already (and ends in its line end) is written as one piece
-                    const FastxFile::Rec &r = one.recs[0];
-                    const uint64_t b = rec_start[k], e = rec_start[k + 1];
-                    const bool crlf = r.id_e < n_text && text[r.id_e] == '\r';
-                    const uint64_t nl = crlf ? 2 : 1;
-                    if (r.qual_b == r.raw_e + 2 * nl + 1 && r.qual_e + nl == e && text[e - 1] == '\n')
-                        w1.write(text + b, (size_t)(e - b));
-                    else
-                        one.write(0, w1);
-                }
-        }
-        tm.mark("window: rows + records out");
-    };
-    // ---- bgzip'ed FASTQ on one GPU: windows of members -> mk_extract_fastq_bgzf (inflated on the device straight into the
-    // ingest buffer; the text comes back for the record ids and the kept records) -> rows + kept records.  The unfinished
-    // record a window ends with is the next window's head.  A window the device refuses (not plain 4-line FASTQ) sends the
-    // host reader to the place in the member chain where that window's text began; it carries on from there.
-    if (bgzf_device) {
-        const WindowSource &ws = s1.source();
-        mk_codec *codec = nullptr;
-        mk_check(mk_codec_create(devs[0], &codec), "Error setting up the BGZF codec");
-        struct CodecGuard {  // (at the end of the process its gigabytes of device buffers are not freed one by one: 0.07 s)
-            mk_codec *c;
-            ~CodecGuard() {
-                if (!g_process_is_ending) mk_codec_destroy(c);
-            }
-        } guard{codec};
-        RawBuffer &textbuf = bgzf_text;
-        std::vector<char> head;
-        std::vector<mk_bgzf_member> grp;
-        const size_t nm = ws.n_bgzf_members();
-        size_t next = 0, head_member = 0;  // next member to take; the member the head's first byte lies in ...
-        uint64_t head_skip = 0;            // ... and how far into its text
-        // (a launch of the inflate kernel lasts as long as its slowest member whatever it holds: few, large windows)
-        const bool whole_text = a.invert_match && lg.active;
-        // (... and when the text stays on the device -- only the kept records come back -- --window-mb's reason, the host's
-        // memory, does not apply: windows of 3 GiB unless the flag was given)
-        const uint64_t target = (!whole_text && a.window_mb == 1024) ? (3ull << 30) : std::max<uint64_t>(1u << 16, std::min<uint64_t>(window_bytes, 1ull << 30));
-        bool refused = false;
-        RawBuffer tailbuf;
-        uint64_t kept_need = 0;
-        std::vector<uint64_t> packed_start, kept_of;
-        std::vector<uint8_t> packed_keep;
-        while (next < nm || !head.empty()) {
-            grp.clear();
-            uint64_t members_text = 0;
-            size_t g1 = next;
-            while (g1 < nm && (members_text < target || g1 == next)) {
-                mk_bgzf_member e{};
-                ws.bgzf_member_at(g1, &e.data_off, &e.data_len, &e.isize, &e.crc);
-                e.out_off = members_text;
-                members_text += e.isize;
-                grp.push_back(e);
-                ++g1;
-            }
-            const bool last = g1 >= nm;
-            const uint64_t cap_text = head.size() + members_text;
-            // what comes back of the window's text: only the kept records (gathered on the device) and the unfinished record
-            // at its end -- unless the log rows name records that are not kept (-v with a log): then all of it
-            mk_window_text io;
-            memset(&io, 0, sizeof(io));
-            if (whole_text) {
-                textbuf.need(cap_text + 16);
-                io.text = (uint8_t *)textbuf.p.get(), io.text_cap = textbuf.cap;
-            } else {
-                textbuf.need(std::max<uint64_t>(kept_need, std::min<uint64_t>(cap_text, std::max<uint64_t>(64u << 20, cap_text / 8))));
-                tailbuf.need(1u << 20);
-                io.kept = (uint8_t *)textbuf.p.get(), io.kept_cap = textbuf.cap;
-                io.tail = (uint8_t *)tailbuf.p.get(), io.tail_cap = tailbuf.cap;
-            }
-            uint64_t n_rec = 0, n_rows = 0, n_text = 0, n_used = 0;
-            uint32_t status = 0;
-            mk_counters cb;
-            std::vector<uint32_t> cnt_b(counts.size(), 0);
-            uint64_t rec_cap = std::max<uint64_t>(rec_start.size() ? rec_start.size() - 1 : 0, cap_text / 64 + 16);
-            for (;;) {
-                if (rec_start.size() < rec_cap + 1) rec_start.resize(rec_cap + 1);
-                if (keep.size() < rec_cap) keep.resize(rec_cap);
-                memset(&cb, 0, sizeof(cb));
-                std::fill(cnt_b.begin(), cnt_b.end(), 0);
-                const int rc = mk_extract_fastq_bgzf(m, codec, (const uint8_t *)head.data(), head.size(), ws.file_bytes(), ws.file_size(), grp.data(),
-                                                     grp.size(), last, &io, lg.active, a.invert_match, rec_cap, &n_rec, rec_start.data(), keep.data(),
-                                                     rows.data(), rows.size(), &n_rows, &cb, cnt_b.data(), &status);
-                n_text = io.n_text, n_used = io.n_used;
-                if (rc == MK_E_CAPACITY && !whole_text && io.n_kept_bytes > io.kept_cap) {  // (many reads kept: the need is known now)
-                    kept_need = io.n_kept_bytes + (io.n_kept_bytes >> 3);
-                    textbuf.need(kept_need);
-                    io.kept = (uint8_t *)textbuf.p.get(), io.kept_cap = textbuf.cap;
-                    continue;
-                }
-                if (rc == MK_E_CAPACITY && n_rec > rec_cap) {
-                    rec_cap = n_rec;
-                    continue;
-                }
-                if (rc == MK_E_CAPACITY && n_rows > rows.size()) {
-                    rows.resize(n_rows);
-                    continue;
-                }
-                if (rc == MK_E_CORRUPT) bail("Error while decompressing " + a.in_fastx);
-                mk_check(rc, "Error during matching");
-                break;
-            }
-            if (status != 0) {
-                refused = true;
-                break;
-            }
-            if (whole_text) {
-                accept_window(textbuf.p.get(), n_used, n_rec, n_rows, cb, cnt_b);
-            } else {
-                // the kept records lie back to back in what came down: their record table, and the rows' record numbers, in
-                // terms of that text (a row's record is a kept one: no -v here)
-                packed_start.clear();
-                kept_of.clear();
-                uint64_t at = 0;
-                for (uint64_t k = 0; k < n_rec; ++k)
-                    if (keep[k]) {
-                        kept_of.push_back(k);
-                        packed_start.push_back(at);
-                        at += rec_start[k + 1] - rec_start[k];
-                    }
-                packed_start.push_back(at);
-                if (at != io.n_kept_bytes) bail("Error during matching: the kept records' text does not have the size of its record table");
-                for (uint64_t r = 0; r < (lg.active ? n_rows : 0); ++r)
-                    rows[r].rec = (uint64_t)(std::lower_bound(kept_of.begin(), kept_of.end(), rows[r].rec) - kept_of.begin());
-                const uint64_t n_kept = kept_of.size();
-                packed_keep.assign(n_kept, 1);
-                rec_start.swap(packed_start);
-                keep.swap(packed_keep);
-                accept_window(textbuf.p.get(), at, n_kept, n_rows, cb, cnt_b);
-                rec_start.swap(packed_start);
-                keep.swap(packed_keep);
-            }
-            // the next head: text[n_used, n_text), and where it lies in the member chain
-            if (n_used >= n_text) {
-                head_member = g1, head_skip = 0;
-            } else if (n_used < head.size()) {
-                head_skip += n_used;
-            } else {
-                const uint64_t x = n_used - head.size();  // offset in the members' text
-                size_t lo = 0, hi = grp.size();           // the last member whose text starts at or before x
-                while (hi - lo > 1) {
-                    const size_t mid = (lo + hi) / 2;
-                    if (grp[mid].out_off <= x) lo = mid;
-                    else hi = mid;
-                }
-                head_member = next + lo, head_skip = x - grp[lo].out_off;
-            }
-            if (whole_text) head.assign(textbuf.p.get() + n_used, textbuf.p.get() + n_text);
-            else head.assign(tailbuf.p.get(), tailbuf.p.get() + io.n_tail);
-            next = g1;
-            if (last) break;  // (whole records to the end: an unfinished one was a refusal)
-        }
-        if (refused) {
-            s1.seek_bgzf(head_member, head_skip);
-            more1 = s1.fill(window_bytes);
-        }
-    }
-    // ---- device ingest loop: raw text windows -> mk_extract_fastq_text -> rows + kept records --------------------
-    if (raw_more) {
-        struct Pinned {  // (not released at the end of the run: unpinning 2 x 150 MB costs more than the process has left to live)
-            void *p = nullptr;
-            uint64_t cap = 0;
-            void need(uint64_t n) {
-                if (n <= cap) return;
-                mk_host_free(p);
-                p = nullptr;
-                cap = 0;
-                mk_check(mk_host_alloc((size_t)(n + n / 8 + 4096), &p), "Error allocating page-locked memory");
-                cap = n + n / 8 + 4096;
-            }
-        } pin[2];
-        // the window's bytes into pinned memory, on all host threads (page-cache pages cannot be DMA sources).  A plain
-        // file is read with pread() -- the kernel copies from the page cache without a page fault per 4 KiB of a
-        // mapping --, inflated text is copied from the reader's buffer.  file_off: offset of the window in a plain file.
-        const int raw_fd = s1.raw_is_plain() ? open(a.in_fastx.c_str(), O_RDONLY) : -1;
-        auto stage = [&](Pinned &dst, const char *src, uint64_t n, uint64_t file_off) {
-            dst.need(n);
-            const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (size_t)(n >> 22) + 1));
-            run_threads(T, [&](size_t t) {
-                const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
-                uint64_t done = lo;
-                while (raw_fd >= 0 && done < hi) {
-                    const ssize_t got = pread(raw_fd, (char *)dst.p + done, (size_t)(hi - done), (off_t)(file_off + done));
-                    if (got <= 0) break;
-                    done += (uint64_t)got;
-                }
-                if (done < hi) memcpy((char *)dst.p + done, src + done, (size_t)(hi - done));  // (no descriptor, or a short read)
-            });
-        };
-        int cur = 0;
-        bool first = true;
-        while (raw_more) {
-            // kept records and row ids are read from the pinned copy: the file's own mapping has not been touched by
-            // this path (pread), and every first touch of one of its pages is a fault -- 8 ms per window with logs.
-            // (The first window was never staged: it is uploaded from the reader's memory.)
-            const char *text = first ? raw_text : (const char *)pin[cur].p;
-            const uint64_t n_text = raw_n;
-            s1.raw_consume();
-            // the next window: inflate / find its end, copy into the other pinned buffer -- beside the device work
-            const char *nx_text = nullptr;
-            uint64_t nx_n = 0, nx_resume = 0;
-            std::future<bool> next = std::async(std::launch::async, [&] {
-                const bool more = s1.raw_fill(raw_window, &nx_text, &nx_n, &nx_resume);
-                if (more) {
-                    stage(pin[cur ^ 1], nx_text, nx_n, nx_resume - nx_n);
-                    // ... and on its way to the device while this window is still being scanned / written out
-                    mk_check(mk_upload_text_ahead(m, (const uint8_t *)pin[cur ^ 1].p, nx_n), "Error uploading the next window");
-                }
-                return more;
-            });
-            uint64_t n_rec = 0, n_rows = 0;
-            uint32_t status = 0;
-            mk_counters cb;
-            std::vector<uint32_t> cnt_b(counts.size(), 0);
-            bool fell_back = false;
-            try {
-                uint64_t rec_cap = std::max<uint64_t>(rec_start.size() ? rec_start.size() - 1 : 0, n_text / 64 + 16);
-                for (;;) {
-                    if (rec_start.size() < rec_cap + 1) rec_start.resize(rec_cap + 1);
-                    if (keep.size() < rec_cap) keep.resize(rec_cap);
-                    memset(&cb, 0, sizeof(cb));
-                    std::fill(cnt_b.begin(), cnt_b.end(), 0);
-                    int rc = mk_extract_fastq_text(m, (const uint8_t *)text, n_text, lg.active, a.invert_match, rec_cap, &n_rec, rec_start.data(),
-                                                   keep.data(), rows.data(), rows.size(), &n_rows, &cb, cnt_b.data(), &status);
-                    if (rc == MK_E_CAPACITY && n_rec > rec_cap) {
-                        rec_cap = n_rec;
-                        continue;
-                    }
-                    if (rc == MK_E_CAPACITY && n_rows > rows.size()) {
-                        rows.resize(n_rows);
-                        continue;
-                    }
-                    mk_check(rc, "Error during matching");
-                    break;
-                }
-                if (status != 0) {
-                    fell_back = true;  // not plain 4-line FASTQ: the host reader takes over from this window on
-                } else {
-                    accept_window(text, n_text, n_rec, n_rows, cb, cnt_b);
-                }
-            } catch (...) {
-                next.wait();
-                throw;
-            }
-            if (fell_back) {
-                next.get();  // (its window, if any, was not consumed: fill() hands that text out again)
-                raw_refused = true;
-                break;
-            }
-            raw_more = next.get();
-            raw_text = nx_text;
-            raw_n = nx_n;
-            raw_resume = nx_resume;
-            cur ^= 1;
-            first = false;
-        }
-        if (raw_fd >= 0) close(raw_fd);
-        if (raw_refused) {
-            // the host reader parses the refused window (and words any parse error, as the reference would) ...
-            s1.adopt_raw(raw_text, raw_n);
-            more1 = !f1.recs.empty();
-        }
-    }
     // per-device counters of a --gpus N job (summed once, at the end, by RCCL)
     std::vector<mk_counters> dev_c(ms.size());
     std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
     for (auto &x : dev_c) memset(&x, 0, sizeof(x));
+    if (by_windows) {
+        wx.run(a, pats, lg, ms, devs, w1, w2, name1, name2, dev_c, dev_counts, tm);
+        if (ms.size() == 1) {
+            c = dev_c[0];
+            counts = dev_counts[0];
+        }
+    }
     while (more1 || more2) {
         if (paired && !more2)  // src/cmd_extract.rs:465-468: file 2 ends first
             bail("Error during FASTQ record parsing of second file. Do the two input files contain the same number of records?");
@@ -849,14 +458,9 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         // pairs are matched by ordinal: both windows advance by the same number of records
         const size_t n = paired ? std::min(f1.recs.size(), f2.recs.size()) : f1.recs.size();
         // the next window is inflated and indexed while this one is scanned
-        const bool adopted = raw_refused;  // ... this window came from the raw path: the stream resumes behind it afterwards
-        raw_refused = false;
-        if (!adopted) {
-            s1.consume(n);
-            if (paired) s2.consume(n);
-        }
+        s1.consume(n);
+        if (paired) s2.consume(n);
         std::future<void> next_window = std::async(std::launch::async, [&] {
-            if (adopted) return;
             s1.prefetch(window_bytes);
             if (paired) s2.prefetch(window_bytes);
         });
@@ -906,7 +510,6 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
             throw;
         }
         next_window.get();  // a malformed record in the next window is reported now, after this one was written
-        if (adopted) s1.resume_at(raw_resume);
         more1 = s1.fill(window_bytes);
         if (paired) more2 = s2.fill(window_bytes);
         tm.mark("next window");

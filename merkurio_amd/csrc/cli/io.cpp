@@ -191,11 +191,12 @@ static void bgzf_inflate_range(const uint8_t *d, const std::vector<BgzfMember> &
             inflateReset(&z);
             z.next_in = const_cast<Bytef *>(d + b.data_off);
             z.avail_in = (uInt)b.data_len;
-            z.next_out = (Bytef *)out + (b.out_off - base);
+            Bytef none = 0;  // (an empty member -- the end-of-file marker -- into an empty buffer: zlib refuses a NULL next_out)
+            z.next_out = b.isize ? (Bytef *)out + (b.out_off - base) : &none;
             z.avail_out = b.isize;
             const int r = inflate(&z, Z_FINISH);
             if ((r != Z_STREAM_END && !(b.isize == 0 && r == Z_BUF_ERROR)) || z.avail_out != 0 ||
-                (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef *)out + (b.out_off - base), b.isize) != b.crc) {
+                (uint32_t)crc32(crc32(0, nullptr, 0), b.isize ? (const Bytef *)out + (b.out_off - base) : &none, b.isize) != b.crc) {
                 inflateEnd(&z);
                 bail("Error while decompressing " + path);
             }
@@ -649,13 +650,38 @@ bool FastxStream::fill(uint64_t window_bytes) {
 
 // ---- raw windows (device ingest) ------------------------------------------------------------------------------
 // the last record start of d[0, n) at or behind `from` (n if there is none)
-static uint64_t last_record_start(const char *d, uint64_t n, uint64_t from) {
+static uint64_t last_record_start(const char *d, uint64_t n, uint64_t from, bool fastq) {
     uint64_t last = n;
-    for (uint64_t r = next_record_start(d, n, from, true); r < n; r = next_record_start(d, n, r + 1, true)) last = r;
+    for (uint64_t r = next_record_start(d, n, from, fastq); r < n; r = next_record_start(d, n, r + 1, fastq)) last = r;
+    if (last == n && !fastq && from > 0) {
+        // FASTA records can be far longer than the stretch that was searched (a chromosome): walk back to the last '>' at a line start
+        for (uint64_t p = from; p > 0;) {
+            const void *g = memrchr(d, '>', (size_t)p);
+            if (!g) break;
+            p = (uint64_t)((const char *)g - d);
+            if (p == 0 || d[p - 1] == '\n') return p;
+        }
+    }
     return last;
 }
 
 void FastxFile::parse_span(uint64_t b, uint64_t e) { parse_fastx_range(data, data_n, b, e, fastq, recs); }
+uint64_t FastxFile::parse_span_partial(uint64_t b, uint64_t e, bool partial_ok) { return parse_fastx_range(data, data_n, b, e, fastq, recs, partial_ok); }
+
+void inflate_bgzf_members_host(const uint8_t *file, const mk_bgzf_member *members, size_t n, char *out, const std::string &path) {
+    std::vector<BgzfMember> mem(n);
+    for (size_t i = 0; i < n; ++i) mem[i] = BgzfMember{(size_t)members[i].data_off, (size_t)members[i].data_len, (size_t)members[i].out_off, members[i].isize, members[i].crc};
+    if (n == 0) return;
+    const int saved = g_bgzf_device;  // (this is the host's own checker path: never the device codec)
+    g_bgzf_device = -1;
+    try {
+        bgzf_inflate_range(file, mem, 0, n, out + mem[0].out_off, path);
+    } catch (...) {
+        g_bgzf_device = saved;
+        throw;
+    }
+    g_bgzf_device = saved;
+}
 
 void FastxStream::adopt_raw(const char *text, uint64_t n) {
     parse_window(text, n, 0, n, false);
@@ -679,12 +705,18 @@ bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n
         const uint64_t n = src.text_size();
         uint64_t p = cursor;
         while (p < n && (d[p] == '\n' || d[p] == '\r')) ++p;
-        if (p >= n || d[p] != '@') return false;
+        if (p >= n) return false;
+        if (!started) {
+            if (d[p] != '@' && d[p] != '>') return false;
+            fastq = d[p] == '@';
+            started = true;
+        }
+        if (d[p] != (fastq ? '@' : '>')) return false;
         uint64_t end = std::min(n, p + window_bytes);
         if (end < n) {
             const uint64_t a0 = p & ~(uint64_t)4095;
             (void)madvise(const_cast<char *>(d) + a0, (size_t)(std::min(n, end + (1u << 20)) - a0), MADV_WILLNEED);
-            end = next_record_start(d, n, end, true);  // the first record start at or behind the target
+            end = next_record_start(d, n, end, fastq);  // the first record start at or behind the target
         }
         cursor = p;
         raw_next = end;
@@ -711,7 +743,11 @@ bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n
             cursor = nl;
             return false;
         }
-        if (p < nl && nb[p] != '@') {  // not FASTQ: leave everything to fill()
+        if (p < nl && !started && (nb[p] == '@' || nb[p] == '>')) {
+            fastq = nb[p] == '@';
+            started = true;
+        }
+        if (p < nl && (!started || nb[p] != (fastq ? '@' : '>'))) {  // neither FASTQ nor FASTA: leave everything to fill()
             cur ^= 1;
             cursor = 0;
             return false;
@@ -721,7 +757,7 @@ bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n
             break;
         }
         // more text follows: hand out whole records only -- everything in front of the last record start
-        cut = last_record_start(nb.data(), nl, nl > (1u << 20) ? nl - (1u << 20) : 0);
+        cut = last_record_start(nb.data(), nl, nl > (1u << 20) ? nl - (1u << 20) : 0, fastq);
         if (cut < nl && cut > p) break;
         want = std::max<uint64_t>(window_bytes, nl);  // one record larger than the window: take more
     }
@@ -734,6 +770,29 @@ bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n
 }
 
 void FastxStream::raw_consume() { cursor = raw_next; }
+
+bool FastxStream::raw_rest(const char **text, uint64_t *n_out) {
+    if (src.mapped()) {
+        const uint64_t n = src.text_size();
+        if (cursor >= n) return false;
+        *text = src.text() + cursor;
+        *n_out = n - cursor;
+        cursor = n;
+        return true;
+    }
+    std::vector<char> &nb = bufs[cur ^ 1];
+    uint64_t &nl = lens[cur ^ 1];
+    const uint64_t tail = lens[cur] > cursor ? lens[cur] - cursor : 0;
+    if (nb.size() < tail) nb.resize(tail);
+    if (tail) memcpy(nb.data(), bufs[cur].data() + cursor, tail);
+    nl = tail;
+    while (!src.exhausted()) src.more_into(nb, nl, 64u << 20);
+    cur ^= 1;
+    cursor = nl;
+    *text = nb.data();
+    *n_out = nl;
+    return nl > 0;
+}
 
 void FastxStream::seek_bgzf(size_t member, uint64_t skip) {
     src.seek_member(member);

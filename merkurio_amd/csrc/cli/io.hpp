@@ -96,6 +96,9 @@ struct FastxFile {
     void write(size_t i, Sink &w) const;
     // appends the records of data[b, e) (b at a record start) to recs
     void parse_span(uint64_t b, uint64_t e);
+    // the same for text that may end inside a record (partial_ok: more text follows data[0, data_n)): parsing stops in front of a
+    // record that cannot be shown to end in it; returns where it stopped
+    uint64_t parse_span_partial(uint64_t b, uint64_t e, bool partial_ok);
 };
 
 // An input file as a sequence of (decompressed) bytes that is looked at through a sliding window, so that
@@ -168,12 +171,17 @@ struct FastxStream {
     // raw_fill() starts at the same place (a window the device refused is parsed by fill()).  Use before any fill().
     bool raw_fill(uint64_t window_bytes, const char **text, uint64_t *n, uint64_t *resume);
     void raw_consume();
+    // everything that is left of the input, as it is (after raw_fill() returned false: text that does not start like a record);
+    // consumed.  false: nothing is left
+    bool raw_rest(const char **text, uint64_t *n);
     // A raw window the device refused (the caller has already asked for the NEXT one with raw_fill(), as its prefetch
     // thread does, but not consumed it): parsed here into `view`, as fill() would have; the caller then calls
     // resume_at(the refused window's resume) and goes on with fill(), which continues right behind that window.
     void adopt_raw(const char *text, uint64_t n);
     // the raw windows are slices of a plain (memory-mapped) file: window = file[resume - n, resume)
     bool raw_is_plain() const { return src.mapped() && src.is_file_mapping(); }
+    // after the first raw_fill(): the input is FASTQ ('@' records) or FASTA ('>' records)
+    bool raw_fastq() const { return fastq; }
     void resume_at(uint64_t resume);
     // bgzip'ed input whose first windows were inflated and indexed on the device (the caller walked source()'s members
     // itself): the host reader takes over at the text that starts `skip` bytes into member `member`; then fill().
@@ -195,6 +203,13 @@ struct FastxStream {
     uint64_t raw_next = 0;  // raw windows: where the window handed out last ends
     void parse_window(const char *d, uint64_t n, uint64_t from, uint64_t stop, bool partial_ok);
 };
+
+// BGZF members inflated by zlib on the host threads, whatever set_bgzf_device() says: out + member.out_off receives each
+// member's text (the host checker of windows the device refused or could not hold); CRC-32 and ISIZE checked
+}  // namespace cli
+struct mk_bgzf_member;
+namespace cli {
+void inflate_bgzf_members_host(const uint8_t *file, const mk_bgzf_member *members, size_t n, char *out, const std::string &path);
 
 // ---- SAM / BAM ------------------------------------------------------------------------------------
 // A whole SAM or BAM input held as ONE buffer (mmap of the text / inflated BAM); records are
