@@ -564,3 +564,126 @@ def test_bgzip_inputs_the_device_path_hands_back(golden, tmp_path):
     assert (p.returncode, p.stdout) == (q.returncode, q.stdout)
     (tmp_path / "one.fastq.gz").write_bytes(_bgzf(b"@a\nTTACGTTT\n+\nIIIIIIII"))
     assert run(["extract", "-s", "ACGT", "-i", str(tmp_path / "one.fastq.gz")]).stdout == b"@a\nTTACGTTT\n+\nIIIIIIII\n"
+
+
+def test_windows_of_pairs_fasta_and_several_gpus_equal_the_host_reader(golden, tmp_path):
+    """r05: BASELINE's own shapes on the window path (extract_windows.cpp -> mk_extract_window) against --host-ingest, the host
+    reader: paired FASTQ (src/cmd_extract.rs:412-418,463-612) plain / gzip / bgzip'ed with mates of different record sizes (the
+    windows of the two files hold different numbers of records: leftovers carried), CRLF and trimmed mates; FASTA
+    (src/cmd_extract.rs:281-282) wrapped, CRLF, one-line, bgzip'ed, with a record larger than a window; each also dealt to
+    --gpus 2 / 3; pair-count mismatches with the reference's two messages after the common part has been written."""
+    import gzip
+    import random
+    rnd = random.Random(77)
+    kmers = ["".join(rnd.choice("ACGT") for _ in range(31)) for _ in range(40)]
+    (tmp_path / "k.txt").write_text("\n".join(kmers) + "\n")
+
+    def seq(L, i):
+        s = [rnd.choice("ACGT") for _ in range(L)]
+        if L >= 31 and i % 5 == 0:
+            o = rnd.randrange(0, L - 30)
+            s[o:o + 31] = rnd.choice(kmers)
+        return "".join(s)
+
+    def mate(n, tag, lens, eol="\n", id_pad=""):
+        return [f"@p{i}{id_pad}/{tag}{eol}{(s := seq(rnd.choice(lens), i))}{eol}+{eol}{'I' * len(s)}{eol}" for i in range(n)]
+
+    def results(d, paired, ext):
+        outs = [open(d / (f"out_{k}.{ext}" if paired else f"out.{ext}"), "rb").read() for k in ((1, 2) if paired else (0,))]
+        return outs, log_body(d / "log.txt"), json_stable(d / "log.json")[:2]
+
+    def both_ways(tag, args, paired, ext, extra_sets=((), ("--gpus", "2"), ("--gpus", "3"))):
+        res = {}
+        for mode in ("host",) + tuple("dev" + "".join(x) for x in extra_sets):
+            d = tmp_path / f"{tag}.{mode}"
+            d.mkdir()
+            extra = ["--host-ingest"] if mode == "host" else list(extra_sets[[("dev" + "".join(x)) for x in extra_sets].index(mode)])
+            run(["extract", *args, "-f", str(tmp_path / "k.txt"), "-o", str(d / "out"), "-l", str(d / "log.txt"), "-j", str(d / "log.json"),
+                 "--window-mb", "1", *extra])
+            res[mode] = results(d, paired, ext)
+        for mode in res:
+            assert res[mode] == res["host"], (tag, mode)
+        return res["host"]
+
+    # ---- pairs: mate 1 with long ids (fewer records per 1 MB window than mate 2), trimmed mate 2
+    r1, r2 = mate(9000, 1, (150,), id_pad=" a longer description than its mate carries"), mate(9000, 2, (50, 100, 150))
+    (tmp_path / "a_1.fastq").write_text("".join(r1))
+    (tmp_path / "a_2.fastq").write_text("".join(r2))
+    base = both_ways("pair", ["-i", str(tmp_path / "a_1.fastq"), "-2", str(tmp_path / "a_2.fastq")], True, "fastq")
+    assert base[0][0].count(b"\n@p") > 1500
+    (tmp_path / "g_1.fastq.gz").write_bytes(gzip.compress("".join(r1).encode(), 1))
+    (tmp_path / "g_2.fastq.gz").write_bytes(gzip.compress("".join(r2).encode(), 1))
+    gz = both_ways("pair-gz", ["-i", str(tmp_path / "g_1.fastq.gz"), "-2", str(tmp_path / "g_2.fastq.gz")], True, "fastq", ((), ("--gpus", "2")))
+    assert gz[0] == base[0]
+    (tmp_path / "b_1.fastq.gz").write_bytes(_bgzf("".join(r1).encode(), 20000))
+    (tmp_path / "b_2.fastq.gz").write_bytes(_bgzf("".join(r2).encode(), 65280))
+    bz = both_ways("pair-bgzf", ["-i", str(tmp_path / "b_1.fastq.gz"), "-2", str(tmp_path / "b_2.fastq.gz")], True, "fastq", ((), ("--gpus", "2")))
+    assert bz[0] == base[0]
+    # one plain, one bgzip'ed; -v; no logging at all
+    d = tmp_path / "mixed"
+    d.mkdir()
+    run(["extract", "-i", str(tmp_path / "a_1.fastq"), "-2", str(tmp_path / "b_2.fastq.gz"), "-f", str(tmp_path / "k.txt"), "-o", str(d / "out"), "--window-mb", "1"])
+    assert [open(d / f"out_{k}.fastq", "rb").read() for k in (1, 2)] == base[0]
+    for extra in ([], ["--host-ingest"]):
+        dd = tmp_path / ("inv" + "".join(extra))
+        dd.mkdir()
+        run(["extract", "-i", str(tmp_path / "b_1.fastq.gz"), "-2", str(tmp_path / "b_2.fastq.gz"), "-f", str(tmp_path / "k.txt"), "-v", "-o", str(dd / "out"),
+             "-l", str(dd / "log.txt"), "--window-mb", "1", *extra])
+    assert [open(tmp_path / "inv" / f"out_{k}.fastq", "rb").read() for k in (1, 2)] == \
+        [open(tmp_path / "inv--host-ingest" / f"out_{k}.fastq", "rb").read() for k in (1, 2)]
+    assert log_body(tmp_path / "inv" / "log.txt") == log_body(tmp_path / "inv--host-ingest" / "log.txt")
+    # CRLF mates
+    c1, c2 = mate(3000, 1, (150,), eol="\r\n"), mate(3000, 2, (75, 150), eol="\r\n")
+    (tmp_path / "c_1.fastq").write_text("".join(c1), newline="")
+    (tmp_path / "c_2.fastq").write_text("".join(c2), newline="")
+    both_ways("pair-crlf", ["-i", str(tmp_path / "c_1.fastq"), "-2", str(tmp_path / "c_2.fastq")], True, "fastq", ((),))
+    # pair-count mismatches: the common part is written, then the reference's message (both file orders, plain and bgzip'ed)
+    (tmp_path / "short_2.fastq").write_text("".join(r2[:-2]))
+    (tmp_path / "short_2.fastq.gz").write_bytes(_bgzf("".join(r2[:-2]).encode(), 30000))
+    for second in ("short_2.fastq", "short_2.fastq.gz"):
+        outs = []
+        for extra in ([], ["--host-ingest"], ["--gpus", "2"]):
+            dd = tmp_path / ("mm" + second + "".join(extra))
+            dd.mkdir()
+            p = run(["extract", "-i", str(tmp_path / "a_1.fastq"), "-2", str(tmp_path / second), "-f", str(tmp_path / "k.txt"), "-o", str(dd / "o"),
+                     "--window-mb", "1", *extra], check=False)
+            assert p.returncode == 1 and b"Error during FASTQ record parsing of second file" in p.stderr, (second, extra)
+            outs.append([open(dd / f"o_{k}.fastq", "rb").read() for k in (1, 2)])
+        assert outs[0] == outs[1] == outs[2] and outs[0][0].count(b"\n@p") > 1400
+    (tmp_path / "short_1.fastq").write_text("".join(r1[:-3]))
+    for extra in ([], ["--host-ingest"]):
+        p = run(["extract", "-i", str(tmp_path / "short_1.fastq"), "-2", str(tmp_path / "a_2.fastq"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "m2"),
+                 "--window-mb", "1", *extra], check=False)
+        assert p.returncode == 1 and b"different number of records" in p.stderr
+
+    # ---- FASTA: wrapped at 70, CRLF, one line per sequence, a 3 Mbp record (three windows of 1 MB), empty sequences
+    def fasta(n, width, eol="\n"):
+        out = []
+        for i in range(n):
+            s = seq(rnd.choice((0, 40, 69, 70, 71, 500, 5000)), i)
+            lines = [s[k:k + width] for k in range(0, len(s), width)] if width else [s]
+            out.append(f">c{i} len={len(s)}{eol}" + "".join(ln + eol for ln in lines))
+        return "".join(out)
+
+    big = ">big one\n" + "\n".join("".join(rnd.choice("ACGT") for _ in range(60)) for _ in range(50000)) + "\n" + kmers[3][:20] + "\n" + kmers[3][20:] + "\n"
+    texts = {"w70.fasta": fasta(2500, 70), "crlf.fasta": fasta(800, 60, "\r\n"), "oneline.fa": fasta(1500, 0) + big + fasta(200, 70)}
+    for name, text in texts.items():
+        (tmp_path / name).write_text(text, newline="")
+        ext = name.rsplit(".", 1)[1]
+        r = both_ways(name, ["-i", str(tmp_path / name)], False, ext, ((), ("--gpus", "2")))
+        assert r[0][0].count(b">c") > 100
+        (tmp_path / (name + ".gz")).write_bytes(_bgzf(text.encode(), 30000))
+        rz = both_ways(name + ".bgzf", ["-i", str(tmp_path / (name + ".gz"))], False, ext, ((),))
+        assert rz[0] == r[0]
+    assert b">big one" in both_ways("big", ["-i", str(tmp_path / "oneline.fa"), "-r"], False, "fa", ((),))[0][0]
+    # the reference's own FASTA fixtures with 1 MB windows and two devices
+    fx = os.path.join(golden, "fixtures")
+    for name, kmer, flags, gold in (("simple.fasta", "ACG", ["-r"], "simple"), ("fixed-width.faa", "DKAT", [], "fixed-width")):
+        dd = tmp_path / ("fx" + gold)
+        dd.mkdir()
+        ext = name.rsplit(".", 1)[1]
+        run(["extract", "-i", os.path.join(fx, "input", name), "-s", kmer, *flags, "-o", str(dd / "out"), "-l", str(dd / "x.log"), "-j", str(dd / "x.json"),
+             "--gpus", "2", "--window-mb", "1"])
+        assert open(dd / f"out.{ext}", "rb").read() == open(os.path.join(fx, "extract", f"{gold}.extracted.{ext}"), "rb").read()
+        assert log_body(dd / "x.log") == log_body(os.path.join(fx, "extract", f"{gold}.log"))
+        check_json(dd / "x.json", os.path.join(fx, "extract", f"{gold}.json"))
