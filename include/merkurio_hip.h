@@ -393,6 +393,10 @@ int mk_synth_reads_device_range(mk_matcher *m, uint64_t seed, uint64_t rec0, uin
  * ---------------------------------------------------------------------------------- */
 #define MK_COMM_ID_BYTES 128
 int mk_reduce_counters(mk_matcher *const *per_gpu, int n, void *const *d_counters, size_t len, uint64_t *host_sum);
+/* (v6) creates the communicators mk_reduce_counters will use for these handles' devices and keeps them -- RCCL's set-up takes
+ * seconds, the reduction itself microseconds: call it from a thread of its own when the job starts.  Nothing is synchronised,
+ * nothing reduced; mk_reduce_counters works without it. */
+int mk_reduce_prepare(mk_matcher *const *per_gpu, int n);
 /* MK_OK if librccl could be bound in this process (ranks other than 0 can check before the collective init) */
 int mk_comm_available(void);
 int mk_comm_unique_id(uint8_t id[MK_COMM_ID_BYTES]);

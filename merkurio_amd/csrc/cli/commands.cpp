@@ -315,6 +315,9 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
     tm.mark("open + first window");
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
+    // --gpus N: RCCL's communicators for the final counter reduction are set up beside the job (seconds, against a job of one)
+    std::future<void> comm_ready;
+    if (ms.size() > 1) comm_ready = std::async(std::launch::async, [&ms] { (void)mk_reduce_prepare(ms.data(), (int)ms.size()); });
     // from here on (the HIP runtime is up) the members of a bgzip'ed input are inflated by the device codec (mk_bgzf_inflate)
     if (!a.host_codec) set_bgzf_device(devs[0], a.device_codec_always);
     tm.mark("matcher create (HIP init), remainder");
@@ -515,8 +518,10 @@ int run_extract(const ExtractArgs &a, const std::vector<std::string> &argv) {
         tm.mark("next window");
     }
     if (ms.size() > 1) {
+        tm.mark("records done");
+        comm_ready.get();
         reduce_device_counters(ms, devs, dev_c, dev_counts, c, counts);
-        tm.mark("counter reduction");
+        tm.mark("counter reduction (RCCL set-up began with the job)");
     }
     w1.flush();
     w2.flush();
@@ -608,6 +613,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     tm.mark("open + header");
     const std::vector<mk_matcher *> ms = fm.get();
     mk_matcher *m = ms[0];
+    std::future<void> comm_ready;  // (--gpus N: RCCL's set-up beside the job, as in extract)
+    if (ms.size() > 1) comm_ready = std::async(std::launch::async, [&ms] { (void)mk_reduce_prepare(ms.data(), (int)ms.size()); });
     // from here on (the HIP runtime is up) the BGZF members of a BAM window are inflated by the device codec (mk_bgzf_inflate)
     if (!a.host_codec) set_bgzf_device(devs[0], a.device_codec_always);
     tm.mark("matcher (HIP init), remainder");
@@ -831,6 +838,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         more_windows = sam.fill(window_bytes);
     }
     if (ms.size() > 1) {
+        comm_ready.get();
         reduce_device_counters(ms, devs, dev_c, dev_counts, c, counts);
         tm.mark("counter reduction");
     }

@@ -22,6 +22,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -38,7 +39,7 @@ namespace cli {
 
 namespace {
 
-constexpr uint64_t kFirstWindow = 32ull << 20;  // (page-locked staging needs the HIP runtime, which is still starting: a small first window)
+constexpr uint64_t kFirstWindow = 8ull << 20;  // (page-locked staging needs the HIP runtime, which is still starting: a small first window)
 
 struct Pinned {
     void *p = nullptr;
@@ -108,6 +109,7 @@ struct WindowExtract::Impl {
     bool fastq = true;
     bool chained = false;
     uint64_t plain_target = 128ull << 20, bgzf_target = 1ull << 30;
+    const bool timing = getenv("MERKURIO_TIMING") != nullptr;
     bool whole_text = false;  // -v with a log: the rows name records that are not kept -- BGZF windows hand their whole text back
 
     // ---- set by run()
@@ -129,6 +131,7 @@ struct WindowExtract::Impl {
     std::string failure;
     bool failed = false;
     uint64_t last_head[2] = {0, 0};
+    std::atomic<uint64_t> rec_cap_seen{0};
 
     void fail_all(const std::string &msg) {
         std::lock_guard<std::mutex> lk(mu);
@@ -217,9 +220,11 @@ struct WindowExtract::Impl {
             pin = I.free_pins.front();
             I.free_pins.pop_front();
         }
+        const double t_stage = PhaseTimer::now();
         stage(I, I.pins[pin], text, n, resume - n);
         S.pin = pin, S.body = (const char *)I.pins[pin].p, S.n_body = n;
         if (m_ahead) mk_check(mk_upload_text_ahead(m_ahead, (const uint8_t *)S.body, n), "Error uploading the next window");
+        if (timing) fprintf(stderr, "[timing]   reader: input %d, %.0f MB staged + sent ahead in %.1f ms\n", i, n / 1e6, (PhaseTimer::now() - t_stage) * 1e3);
     }
 
     void reader_loop() {
@@ -415,7 +420,8 @@ struct WindowExtract::Impl {
             }
         }
         if (cap_text >= 0xFFFFFFF0ull) return host_window(W, m);  // (a FASTA record of 4 GiB or more: the host path's own limits apply)
-        uint64_t rec_cap = cap_text / (fastq ? 64 : 256) + 16;
+        // (a guess the call corrects: MK_E_CAPACITY comes back before anything is scanned)
+        uint64_t rec_cap = std::max<uint64_t>(rec_cap_seen.load(), cap_text / (fastq ? 192 : 1024) + 16);
         W.rows.resize(std::max<size_t>(W.rows.size(), 4096));
         W.cnt.assign(pats->list.size(), 0);
         uint32_t status = 0;
@@ -432,7 +438,7 @@ struct WindowExtract::Impl {
                                              W.cnt.data(), &status);
             if (rc == MK_E_CAPACITY && attempt < 8) {  // the call states every need: grow what was too small, once more
                 bool grown = false;
-                if (W.n_rec > rec_cap) rec_cap = W.n_rec, grown = true;
+                if (W.n_rec > rec_cap) rec_cap = W.n_rec + W.n_rec / 16, grown = true, rec_cap_seen = std::max<uint64_t>(rec_cap_seen.load(), rec_cap);
                 if (W.n_rows > W.rows.size()) W.rows.resize(W.n_rows), grown = true;
                 for (int i = 0; i < n_in; ++i) {
                     Side &S = W.side[i];
@@ -477,8 +483,45 @@ struct WindowExtract::Impl {
                 if (S.n_used < nh) S.tail.insert(S.tail.end(), S.head.begin() + (ptrdiff_t)S.n_used, S.head.end());
                 const uint64_t from = S.n_used > nh ? S.n_used - nh : 0;
                 if (from < S.n_body) S.tail.insert(S.tail.end(), S.body + from, S.body + S.n_body);
+                // ... and what the writer will need of it -- the kept records (all of it when the rows name records that are not
+                // kept) -- is copied out here, so that the page-locked buffer goes back to the reader now, not after the write-out
+                pack_host_text(W, S);
             }
         }
+    }
+
+    // S.text = the kept records of a host-held window back to back (layout PACKED_KEPT), or its whole text (WHOLE)
+    void pack_host_text(const Win &W, Side &S) {
+        const uint64_t nh = S.head.size();
+        auto piece = [&](uint64_t b, uint64_t e, char *dst) {  // text[b, e) of head ++ body
+            if (b < nh) {
+                const uint64_t k = std::min(e, nh) - b;
+                memcpy(dst, S.head.data() + b, (size_t)k);
+                dst += k, b += k;
+            }
+            if (b < e) memcpy(dst, S.body + (b - nh), (size_t)(e - b));
+        };
+        if (whole_text) {
+            S.text.resize(S.n_used);
+            const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (size_t)(S.n_used >> 22) + 1));
+            run_threads(T, [&](size_t t) { piece(S.n_used * t / T, S.n_used * (t + 1) / T, S.text.data() + S.n_used * t / T); });
+            S.layout = Side::WHOLE;
+            return;
+        }
+        std::vector<uint64_t> kept, at;
+        uint64_t total = 0;
+        for (uint64_t r = 0; r < W.n_rec; ++r)
+            if (W.keep[r]) {
+                kept.push_back(r);
+                at.push_back(total);
+                total += S.rec_start[r + 1] - S.rec_start[r];
+            }
+        S.text.resize(total);
+        const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), (size_t)(total >> 22) + 1));
+        run_threads(T, [&](size_t t) {
+            for (size_t q = kept.size() * t / T; q < kept.size() * (t + 1) / T; ++q) piece(S.rec_start[kept[q]], S.rec_start[kept[q] + 1], S.text.data() + at[q]);
+        });
+        S.layout = Side::PACKED_KEPT;
     }
 
     void device_loop(size_t d) {
@@ -493,6 +536,7 @@ struct WindowExtract::Impl {
                 W = std::move(queue[d].front());
                 queue[d].pop_front();
             }
+            const double t_call = PhaseTimer::now();
             if (W->error.empty() && !W->by_host) {
                 // an error of this window (a malformed record, a damaged member) is raised when the writer reaches the window: the
                 // reference has written everything in front of it by then
@@ -503,7 +547,20 @@ struct WindowExtract::Impl {
                     for (int i = 0; i < n_in; ++i) W->side[i].tail.clear();
                 }
             }
+            if (timing) {
+                float ms4[4] = {0, 0, 0, 0};
+                (void)mk_matcher_batch_times(m, ms4);
+                fprintf(stderr, "[timing]   device %zu, window %llu: call %.1f ms (upload %.1f, device %.1f, download %.1f, host %.1f)%s\n", d,
+                        (unsigned long long)W->k, (PhaseTimer::now() - t_call) * 1e3, ms4[0], ms4[1], ms4[2], ms4[3], W->by_host ? " [host parser]" : "");
+            }
             std::lock_guard<std::mutex> lk(mu);
+            for (int i = 0; i < n_in; ++i) {  // (the text the writer needs has been copied out of the staging buffers: device and host windows alike)
+                Side &S = W->side[i];
+                if (S.pin >= 0) in[i].free_pins.push_back(S.pin);
+                S.pin = -1, S.body = nullptr, S.n_body = 0;
+                std::vector<char>().swap(S.own);
+                if (!chained) std::vector<char>().swap(S.head);
+            }
             if (chained) {
                 std::vector<std::vector<char>> t(2);
                 for (int i = 0; i < n_in; ++i) t[i] = W->side[i].tail;  // (a copy: the window itself goes to the writer)
@@ -522,11 +579,8 @@ struct WindowExtract::Impl {
         uint64_t n, b, e;
     };
     static Span span_of(const Side &S, uint64_t b, uint64_t e) {
-        if (S.layout != Side::HEAD_BODY) return Span{S.text.data(), S.text.size(), b, e};
-        const uint64_t nh = S.head.size();
-        if (e <= nh) return Span{S.head.data(), nh, b, e};
-        if (b < nh) bail("Error during matching: a record lies across a window's head and body");
-        return Span{S.body, S.n_body, b - nh, e - nh};
+        if (S.layout == Side::HEAD_BODY) bail("Error during matching: a window reached the writer without its text");
+        return Span{S.text.data(), S.text.size(), b, e};
     }
 
     void write_window(Win &W, Sink &w1, Sink &w2, const std::string &name1, const std::string &name2, PhaseTimer &tm) {
@@ -589,29 +643,49 @@ struct WindowExtract::Impl {
         emit_log_rows(*lg, *pats, W.rows.data(), lg->active ? W.n_rows : 0, id_of, [&](const mk_row &r) -> const std::string & { return *names[r.file]; });
         tm.mark("window: log rows");
         if (!a.suppress_output) {
-            // kept records are written by the host reader's own code from the record's lines
-            FastxFile one;
-            one.fastq = fastq;
-            for (uint64_t r = 0; r < n; ++r) {
-                if (!W.keep[r]) continue;
-                for (int i = 0; i < n_in; ++i) {
-                    const Span sp = record_span(i, r);
-                    one.data = sp.p;
-                    one.data_n = sp.n;
-                    one.recs.clear();
-                    one.parse_span(sp.b, sp.e);
-                    if (one.recs.size() != 1) bail("Error during matching: the device's record table and the host parser disagree");
-                    const FastxFile::Rec &rec = one.recs[0];
-                    // record.write(_, None) re-emits the lines (FASTQ: with a bare '+'): a record that is stored that way already (and
-                    // ends in its line end) is written as one piece
-                    const bool crlf = rec.id_e < sp.n && sp.p[rec.id_e] == '\r';
-                    const uint64_t nl = crlf ? 2 : 1;
-                    const bool verbatim = sp.p[sp.e - 1] == '\n' && (fastq ? (rec.qual_b == rec.raw_e + 2 * nl + 1 && rec.qual_e + nl == sp.e)
-                                                                           : (rec.raw_e + nl == sp.e && rec.raw_b == rec.id_e + nl));
-                    if (verbatim) w[i]->write(sp.p + sp.b, (size_t)(sp.e - sp.b));
-                    else one.write(0, *w[i]);
+            // kept records are written by the host reader's own code from the record's lines -- formatted by the host threads into
+            // one buffer per thread and input, written in order (a window of 2 x 128 MB holds ~8 000 kept records at the usual 1 %,
+            // a window of extracted reads 800 000)
+            std::vector<uint64_t> kept;
+            for (uint64_t r = 0; r < n; ++r)
+                if (W.keep[r]) kept.push_back(r);
+            const size_t T = std::max<size_t>(1, std::min<size_t>(io_threads(), kept.size() / 1024));
+            std::vector<std::string> out[2];
+            out[0].resize(T), out[1].resize(T);
+            run_threads(T, [&](size_t t) {
+                FastxFile one;
+                one.fastq = fastq;
+                std::string line;
+                for (size_t q = kept.size() * t / T; q < kept.size() * (t + 1) / T; ++q) {
+                    const uint64_t r = kept[q];
+                    for (int i = 0; i < n_in; ++i) {
+                        const Span sp = record_span(i, r);
+                        one.data = sp.p;
+                        one.data_n = sp.n;
+                        one.recs.clear();
+                        one.parse_span(sp.b, sp.e);
+                        if (one.recs.size() != 1) bail("Error during matching: the device's record table and the host parser disagree");
+                        const FastxFile::Rec &rec = one.recs[0];
+                        // record.write(_, None) re-emits the lines (FASTQ: with a bare '+'): a record that is stored that way already
+                        // (and ends in its line end) is written as one piece
+                        const bool crlf = rec.id_e < sp.n && sp.p[rec.id_e] == '\r';
+                        const uint64_t nl = crlf ? 2 : 1;
+                        const bool verbatim = sp.p[sp.e - 1] == '\n' && (fastq ? (rec.qual_b == rec.raw_e + 2 * nl + 1 && rec.qual_e + nl == sp.e)
+                                                                               : (rec.raw_e + nl == sp.e && rec.raw_b == rec.id_e + nl));
+                        std::string &o = out[i][t];
+                        if (verbatim) {
+                            o.append(sp.p + sp.b, (size_t)(sp.e - sp.b));
+                        } else {  // (FastxFile::write, into the buffer)
+                            const char *eol = crlf ? "\r\n" : "\n";
+                            o.append(fastq ? "@" : ">", 1).append(sp.p + rec.id_b, (size_t)(rec.id_e - rec.id_b)).append(eol, nl);
+                            o.append(sp.p + rec.raw_b, (size_t)(rec.raw_e - rec.raw_b)).append(eol, nl);
+                            if (fastq) o.append("+", 1).append(eol, nl).append(sp.p + rec.qual_b, (size_t)(rec.qual_e - rec.qual_b)).append(eol, nl);
+                        }
+                    }
                 }
-            }
+            });
+            for (size_t t = 0; t < T; ++t)
+                for (int i = 0; i < n_in; ++i) w[i]->write(out[i][t]);
         }
         tm.mark("window: records out");
     }
@@ -711,8 +785,27 @@ void WindowExtract::run(const ExtractArgs &a, const Patterns &pats, Loggers &lg,
     for (int i = 0; i < J.n_in; ++i) {
         Input &I = J.in[i];
         if (I.bgzf_dev) continue;
-        I.pins.resize(N + 2);
-        for (size_t q = 0; q < I.pins.size(); ++q) I.free_pins.push_back((int)q);
+        I.pins.resize(N + 1);
+    }
+    // (page-locking costs ~0.2 ms per MB: the buffers are made on threads of their own, one per input, beside the first window --
+    // which goes up from where it lies --, and handed to the reader as they appear)
+    std::vector<std::thread> pin_threads;
+    for (int i = 0; i < J.n_in; ++i) {
+        if (J.in[i].bgzf_dev) continue;
+        pin_threads.emplace_back([&J, i] {
+            Input &I = J.in[i];
+            for (size_t q = 0; q < I.pins.size(); ++q) {
+                try {
+                    I.pins[q].need(J.plain_target + (1u << 20));
+                } catch (const Error &e) {
+                    J.fail_all(e.what());
+                    return;
+                }
+                std::lock_guard<std::mutex> lk(J.mu);
+                I.free_pins.push_back((int)q);
+                J.cv.notify_all();
+            }
+        });
     }
     std::vector<std::thread> th;
     auto guarded = [&](auto fn) {
@@ -751,8 +844,6 @@ void WindowExtract::run(const ExtractArgs &a, const Patterns &pats, Loggers &lg,
             J.write_window(*W, w1, w2, name1, name2, tm);
             {
                 std::lock_guard<std::mutex> lk(J.mu);
-                for (int i = 0; i < J.n_in; ++i)
-                    if (W->side[i].pin >= 0) J.in[i].free_pins.push_back(W->side[i].pin);
                 J.written = k + 1;
                 J.cv.notify_all();
             }
@@ -762,6 +853,7 @@ void WindowExtract::run(const ExtractArgs &a, const Patterns &pats, Loggers &lg,
         J.fail_all(writer_error);
     }
     for (auto &t : th) t.join();
+    for (auto &t : pin_threads) t.join();
     if (!writer_error.empty()) bail(writer_error);
     if (J.failed) bail(J.failure);
 }

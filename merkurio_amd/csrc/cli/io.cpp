@@ -683,20 +683,6 @@ void inflate_bgzf_members_host(const uint8_t *file, const mk_bgzf_member *member
     g_bgzf_device = saved;
 }
 
-void FastxStream::adopt_raw(const char *text, uint64_t n) {
-    parse_window(text, n, 0, n, false);
-    view.recs.swap(spare_recs);
-    spare_recs.clear();
-    view.data = text;
-    view.data_n = n;
-    view.fastq = fastq;
-    have_spare = false;
-}
-
-void FastxStream::resume_at(uint64_t resume) {
-    if (src.mapped()) cursor = resume;  // (compressed: the unconsumed text is already the current buffer)
-}
-
 bool FastxStream::raw_fill(uint64_t window_bytes, const char **text, uint64_t *n_out, uint64_t *resume) {
     *resume = 0;
     if (window_bytes < (1u << 16)) window_bytes = 1u << 16;
@@ -792,15 +778,6 @@ bool FastxStream::raw_rest(const char **text, uint64_t *n_out) {
     *text = nb.data();
     *n_out = nl;
     return nl > 0;
-}
-
-void FastxStream::seek_bgzf(size_t member, uint64_t skip) {
-    src.seek_member(member);
-    have_spare = false;
-    lens[0] = lens[1] = 0;
-    cur = 0;
-    while (lens[cur] <= skip && !src.exhausted()) src.more_into(bufs[cur], lens[cur], skip + (1u << 16) - lens[cur]);
-    cursor = std::min<uint64_t>(skip, lens[cur]);  // (fill() starts with the unconsumed tail of the current buffer)
 }
 
 void FastxStream::consume(size_t n) { cursor = n < view.recs.size() ? view.recs[n].id_b - 1 : cur_end; }

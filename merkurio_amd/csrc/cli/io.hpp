@@ -164,30 +164,23 @@ struct FastxStream {
     // Parses the window behind the consumed records into a spare index (and, for compressed input, a second
     // buffer); may run on another thread while `view` is being used.  Call after consume().
     void prefetch(uint64_t window_bytes);
-    // RAW windows (extract's device path: the window's text goes to the GPU as it is and is indexed there,
-    // mk_extract_fastq_text): the next ~window_bytes of text, from a record start to a record start, NOT parsed.
-    // false: no text is left, or the input is not FASTQ (nothing consumed: fill() then takes over).  The text stays
-    // valid until the raw_fill() after next; raw_consume() accepts the window, without it the next fill() /
-    // raw_fill() starts at the same place (a window the device refused is parsed by fill()).  Use before any fill().
+    // RAW windows (extract_windows.cpp: a window's text goes to the GPU as it is and is indexed there, mk_extract_window): the
+    // next ~window_bytes of text, from a record start to a record start, NOT parsed; FASTQ ('@' records) or FASTA ('>' records),
+    // whichever the first record is.  false: no text is left, or it does not start like a record (nothing consumed).  The text
+    // stays valid until the raw_fill() after next; raw_consume() accepts the window, without it the next fill() / raw_fill()
+    // starts at the same place.  Use before any fill().
     bool raw_fill(uint64_t window_bytes, const char **text, uint64_t *n, uint64_t *resume);
     void raw_consume();
     // everything that is left of the input, as it is (after raw_fill() returned false: text that does not start like a record);
     // consumed.  false: nothing is left
     bool raw_rest(const char **text, uint64_t *n);
-    // A raw window the device refused (the caller has already asked for the NEXT one with raw_fill(), as its prefetch
-    // thread does, but not consumed it): parsed here into `view`, as fill() would have; the caller then calls
-    // resume_at(the refused window's resume) and goes on with fill(), which continues right behind that window.
-    void adopt_raw(const char *text, uint64_t n);
     // the raw windows are slices of a plain (memory-mapped) file: window = file[resume - n, resume)
     bool raw_is_plain() const { return src.mapped() && src.is_file_mapping(); }
     // after the first raw_fill(): the input is FASTQ ('@' records) or FASTA ('>' records)
     bool raw_fastq() const { return fastq; }
-    void resume_at(uint64_t resume);
-    // bgzip'ed input whose first windows were inflated and indexed on the device (the caller walked source()'s members
-    // itself): the host reader takes over at the text that starts `skip` bytes into member `member`; then fill().
+    // bgzip'ed input: the caller walks source()'s members itself and sends them to the device as they are
     bool raw_is_bgzf() const { return src.is_bgzf(); }
     const WindowSource &source() const { return src; }
-    void seek_bgzf(size_t member, uint64_t skip);
 
    private:
     WindowSource src;

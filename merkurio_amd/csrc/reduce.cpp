@@ -145,6 +145,27 @@ static_assert(MK_COMM_ID_BYTES == sizeof(ncclUniqueId), "id size");
 
 extern "C" {
 
+// Setting up RCCL's communicators takes seconds (ncclCommInitAll: 5.7 s for a 2-handle job on the round's box) -- as long as a whole
+// 6 GB extract job: a host that knows it will reduce at the end starts this on a thread of its own at the beginning, beside the job.
+int mk_reduce_prepare(mk_matcher *const *per_gpu, int n) {
+    if (!per_gpu || n <= 0) return fail(MK_E_INVALID_ARG, "null argument");
+    MK_ABI_BEGIN
+    Rccl *R = rccl();
+    if (!R) return fail(MK_E_RCCL, "%s", g_rccl.why);
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) {
+        if (!per_gpu[i]) return fail(MK_E_INVALID_ARG, "null handle (%d)", i);
+        if (std::find(devs.begin(), devs.end(), per_gpu[i]->device) == devs.end()) devs.push_back(per_gpu[i]->device);
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_comm_sets.count(devs)) return MK_OK;
+    std::vector<ncclComm_t> c(devs.size(), nullptr);
+    MK_NCCL(R, R->CommInitAll(c.data(), (int)devs.size(), devs.data()));
+    g_comm_sets.emplace(devs, std::move(c));
+    return MK_OK;
+    MK_ABI_END
+}
+
 int mk_reduce_counters(mk_matcher *const *per_gpu, int n, void *const *d_counters, size_t len, uint64_t *host_sum) {
     if (!per_gpu || !d_counters || n <= 0) return fail(MK_E_INVALID_ARG, "null argument");
     for (int i = 0; i < n; ++i)

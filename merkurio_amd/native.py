@@ -50,7 +50,7 @@ EXPORTS = [
     "mk_matcher_filter_info", "mk_matcher_class_info", "mk_matcher_filter_mode", "mk_scan_batch", "mk_scan_device", "mk_order_hits", "mk_order_hits_device", "mk_matcher_order_info", "mk_matcher_order_stats", "mk_matcher_kernel_name",
     "mk_matcher_launch_info", "mk_matcher_enable_timing", "mk_matcher_kernel_times", "mk_matcher_hint_hit_density", "mk_matcher_hint_record_lengths", "mk_matcher_set_fixed_record_length", "mk_matcher_check_device",
     "mk_extract_single", "mk_extract_fastq_text", "mk_upload_text_ahead", "mk_host_alloc", "mk_host_free", "mk_extract_paired", "mk_tag_records", "mk_tag_value", "mk_matcher_batch_times", "mk_synth_reads_device",
-    "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
+    "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_reduce_prepare", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
     "mk_codec_times", "mk_codec_set_pass_limits", "mk_extract_fastq_bgzf", "mk_extract_window",
@@ -176,6 +176,7 @@ def load(build_if_missing=True):
     L.mk_synth_reads_device_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
     L.mk_reduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]
+    L.mk_reduce_prepare.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.mk_comm_unique_id.argtypes = [C.c_void_p]
     L.mk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.mk_comm_reduce_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

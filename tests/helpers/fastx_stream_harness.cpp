@@ -1,9 +1,9 @@
 // test harness: reads a FASTA/FASTQ file through the CLI's windowed reader (FastxStream,
 // merkurio_amd/csrc/cli/io.cpp) and prints one line per record -- id, sequence (line breaks squeezed
 // out), quality -- plus the number of windows; tests/test_cli_cpu.py compares with a Python parse.
-// usage: harness <file> <window bytes> [consume at most N records per window (0 = all)] [digest | raw | raw:K]
+// usage: harness <file> <window bytes> [consume at most N records per window (0 = all)] [digest | raw]
 // digest: one line per record with id, sequence length and FNV-1a hash instead of the text
-// raw / raw:K: through raw_fill() (the windows extract uploads unparsed), window K refused and adopted by the host reader
+// raw: through raw_fill() / raw_rest() (the windows extract hands to the GPU unparsed)
 #include <cstdio>
 #include <cstdlib>
 
@@ -24,44 +24,39 @@ int main(int argc, char **argv) {
             printf("%s\t%.*s\t%.*s\n", f.id(i).c_str(), (int)seq.size(), (const char *)seq.data(), (int)(r.qual_e - r.qual_b), f.data + r.qual_b);
         };
         if (argc > 4 && argv[4][0] == 'r') {
-            // raw windows (extract's device path): "raw" = every window accepted (its records printed by the host
-            // parser, the checker of the device's index); "raw:K" = window K is refused -- adopted by the host reader,
-            // which then carries on with fill() from right behind it
-            const long refuse = argv[4][3] == ':' ? atol(argv[4] + 4) : -1;
+            // raw windows (extract's text windows: FASTQ or FASTA, handed to the GPU unparsed): every window starts at a record start
+            // and holds whole records; its records are printed by the host parser, the checker of the device's index.  What
+            // raw_fill() does not take (text that does not start like a record) comes out of raw_rest() as one last piece.
             const char *text = nullptr;
             uint64_t n = 0, resume = 0;
             bool more = s.raw_fill(w, &text, &n, &resume);
-            while (more) {
-                std::vector<char> copy(text, text + n);  // (the CLI works on its pinned copy while the stream moves on)
-                const uint64_t this_resume = resume;
-                s.raw_consume();
-                // the next window is fetched before the fate of this one is known, as the CLI's prefetch thread does
-                more = s.raw_fill(w, &text, &n, &resume);
-                ++windows;
-                if ((long)windows - 1 == refuse) {  // refused: the host reader parses it and carries on behind it
-                    s.adopt_raw(copy.data(), copy.size());
-                    for (size_t i = 0; i < s.view.recs.size(); ++i) print(s.view, i);
-                    total += s.view.recs.size();
-                    s.resume_at(this_resume);
-                    break;
-                }
+            auto parse_and_print = [&](const std::vector<char> &copy) {
                 FastxFile f;
-                f.fastq = true;
+                f.fastq = s.raw_fastq();
                 f.data = copy.data();
                 f.data_n = copy.size();
-                if (!copy.empty() && copy[0] != '@') {
+                if (!copy.empty() && copy[0] != (f.fastq ? '@' : '>')) {
                     printf("#error raw window does not start at a record\n");
-                    return 0;
+                    exit(0);
                 }
                 f.parse_span(0, copy.size());
                 for (size_t i = 0; i < f.recs.size(); ++i) print(f, i);
                 total += f.recs.size();
-            }
-            while (s.fill(w)) {  // (also: inputs raw_fill does not take at all, e.g. FASTA)
+            };
+            while (more) {
+                std::vector<char> copy(text, text + n);  // (the CLI works on its pinned copy while the stream moves on)
+                s.raw_consume();
+                // the next window is fetched while this one is in use, as the CLI's reader thread does
+                more = s.raw_fill(w, &text, &n, &resume);
                 ++windows;
-                for (size_t i = 0; i < s.view.recs.size(); ++i) print(s.view, i);
-                total += s.view.recs.size();
-                s.consume(s.view.recs.size());
+                parse_and_print(copy);
+            }
+            if (s.raw_rest(&text, &n) && n) {
+                std::vector<char> copy(text, text + n);
+                size_t p = 0;
+                while (p < copy.size() && (copy[p] == '\n' || copy[p] == '\r')) ++p;
+                copy.erase(copy.begin(), copy.begin() + (ptrdiff_t)p);
+                if (!copy.empty()) ++windows, parse_and_print(copy);
             }
             printf("#windows %zu records %zu\n", windows, total);
             return 0;
