@@ -743,24 +743,64 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
     return res
 
 
-def codec_configs(mk, megabytes=1024, reps=3):
-    """The BGZF codec either side of `tag` (include/merkurio_hip.h v5, merkurio_amd/csrc/codec/): 1 GiB of BAM-shaped
-    records (tests/textio.py: bam_like, 4-bin qualities) deflated into 65 280-byte members and inflated again through
-    the C ABI, host buffers in and out.  `kernel_ms` = the device part of a call (hipEvents around its kernels:
-    CRC + parse + codes + bit packing + pack, or inflate + CRC check), best of `reps`; `ms_per_call` the whole call with
-    its PCIe copies from / to pageable memory.  Neither kernel is bound by HBM or MFMA: both are latency-bound serial
-    decoders / parsers, one wave (deflate) or one lane (inflate) per member, so `frac` against the HBM peak is reported
-    for scale only.  The round trip is checked in the run."""
+def _fastq_binned(n, L=150, seed=11):
+    """FASTQ text with Illumina-style binned qualities in runs (a position keeps its predecessor's bin with p = 0.92, the lower
+    bins open up along the read): what a sequencer's bgzip'ed output looks like to a DEFLATE coder, unlike constant qualities"""
     import numpy as np
+    rng = np.random.default_rng(seed)
+    bins = np.frombuffer(b"FFF:,#", dtype=np.uint8)
+    q = np.empty((n, L), dtype=np.uint8)
+    cur = rng.integers(0, 2, size=n).astype(np.uint8)
+    for j in range(L):
+        change = rng.random(n) < 0.08
+        nxt = rng.integers(0, 3 + (3 * j) // L, size=n).astype(np.uint8)
+        cur = np.where(change, nxt, cur)
+        q[:, j] = bins[cur]
+    H = 13
+    rec = np.empty((n, H + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, :H] = np.array([f"@r{i:010d}\n" for i in range(n)], dtype="S13").view(np.uint8).reshape(n, H)
+    rec[:, H:H + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))]
+    rec[:, H + L:H + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, H + L + 3:H + 2 * L + 3] = q
+    rec[:, -1] = ord("\n")
+    return rec.tobytes()
+
+
+def _zlib_bgzf(raw, level=6):
+    """BGZF members as htslib / bgzip write them: zlib at `level`, 65 280 bytes of text each (16 host threads: zlib releases the GIL)"""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def member(b):
+        chunk = raw[b:b + 0xff00]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        c = co.compress(chunk) + co.flush()
+        return (bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + (len(c) + 25).to_bytes(2, "little") + c +
+                zlib.crc32(chunk).to_bytes(4, "little") + len(chunk).to_bytes(4, "little"))
+    with ThreadPoolExecutor(16) as ex:
+        return b"".join(ex.map(member, range(0, len(raw), 0xff00)))
+
+
+def codec_configs(mk, megabytes=1024, reps=3):
+    """The BGZF codec either side of `tag` and in front of `extract` (include/merkurio_hip.h, merkurio_amd/csrc/codec/), through the C
+    ABI with host buffers in and out.  r05: the inflater is measured on members a REAL writer made -- zlib level 6, what htslib and
+    bgzip produce -- of 1 GiB of BAM-shaped records (tests/textio.py: bam_like, 4-bin qualities) and of 1 GiB of FASTQ with binned
+    qualities in runs, and on 64 MB of the same (a small call: the wave-per-member kernel); the members the device's own deflate
+    writes (longer matches, fewer tokens) stay beside them, labelled.  `kernel_ms` = the device part of a call (hipEvents around its
+    kernels), best of `reps`; `ms_per_call` = the C call alone, from pageable host memory into a fresh, untouched output buffer
+    (upload_ms / download_ms: its two host <-> device legs through the handle's page-locked staging buffers).  Neither direction is
+    bound by HBM or MFMA -- latency-bound serial decoders / parsers per member -- so `frac` against the HBM peak is for scale only.
+    Every round trip is checked in the run."""
+    import zlib
     from textio import bam_like
-    unit = bam_like(200000, seed=21)
-    data = unit * max(1, megabytes * (1 << 20) // len(unit))
     codec = mk.Codec()
     out = []
+    n_bytes = megabytes << 20
+    unit = bam_like(200000, seed=21)
+    bam = (unit * (n_bytes // len(unit) + 1))[:n_bytes]
     # what the reference runs on its reader / writer threads, on one host core, on a 16 MB sample of the same text (zlib: the
     # checker of the codec tests; the reference's flate2 backend is of the same class)
-    import zlib
-    sample = data[:256 * 65280]
+    sample = bam[:256 * 65280]
     t0 = time.perf_counter()
     zs = []
     for i in range(0, len(sample), 65280):
@@ -772,42 +812,63 @@ def codec_configs(mk, megabytes=1024, reps=3):
         zlib.decompress(z, -15)
     z_inf = len(sample) / (time.perf_counter() - t0) / 1e6
     z_ratio = len(sample) / (sum(map(len, zs)) + 26 * len(zs))
+
+    def timed(fn):
+        best = None
+        for _ in range(reps):
+            res = fn()
+            up, dev_ms, down = codec.times()
+            if best is None or dev_ms < best[1]:
+                best = (codec.last_call_s, dev_ms, up, down)
+        return res, best
+
+    def entry(workload, kernel, n_text, n_blob, best, bound, extra):
+        e = {"workload": workload, "kernel": kernel, "kernel_ms": round(best[1], 2), "ms_per_call": round(best[0] * 1e3, 1),
+             "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1), "legs_share_of_call": round((best[1] + best[2] + best[3]) / (best[0] * 1e3), 3),
+             "text_gb_per_s_kernels": round(n_text / best[1] / 1e6, 1), "text_gb_per_s_call": round(n_text / best[0] / 1e9, 2), "bound": bound,
+             "frac": round((n_text + n_blob) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+             "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"}
+        e.update(extra)
+        out.append(e)
+
     try:
-        best = None
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            blob = codec.deflate(data)
-            dt = time.perf_counter() - t0
-            up, dev_ms, down = codec.times()
-            if best is None or dev_ms < best[1]:
-                best = (dt, dev_ms, up, down)
-        out.append({"workload": f"BGZF deflate (tag's BAM output): {len(data) / 1e6:.0f} MB of BAM-shaped records -> {(len(data) + 65279) // 65280} members",
-                    "kernel": "mk_bgzf_crc_kernel + mk_bgzf_deflate_kernel + mk_bgzf_pack_kernel", "kernel_ms": round(best[1], 2),
-                    "ms_per_call": round(best[0] * 1e3, 1), "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1),
-                    "text_gb_per_s_kernels": round(len(data) / best[1] / 1e6, 1), "compression_ratio": round(len(data) / len(blob), 2),
-                    "cpu_baseline": {"value": round(z_def / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib level 6, 65 280-byte members",
-                                     "compression_ratio": round(z_ratio, 2), "sample": "the first 16.7 MB of the same text"},
-                    "bound": "latency (serial parse per member; not HBM, not MFMA)",
-                    "frac": round((len(data) + len(blob)) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                    "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
-        best = None
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            text = codec.inflate(blob)
-            dt = time.perf_counter() - t0
-            up, dev_ms, down = codec.times()
-            if best is None or dev_ms < best[1]:
-                best = (dt, dev_ms, up, down)
-        out.append({"workload": f"BGZF inflate (tag's BAM input): the {(len(data) + 65279) // 65280} members above -> {len(data) / 1e6:.0f} MB, CRC-32 checked",
-                    "kernel": "mk_bgzf_inflate_kernel + mk_bgzf_crc_check_kernel", "kernel_ms": round(best[1], 2), "ms_per_call": round(best[0] * 1e3, 1),
-                    "upload_ms": round(best[2], 1), "download_ms": round(best[3], 1), "text_gb_per_s_kernels": round(len(data) / best[1] / 1e6, 1),
-                    "cpu_baseline": {"value": round(z_inf / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib inflate of its own level 6 members",
-                                     "sample": "the first 16.7 MB of the same text"},
-                    "round_trip_equal": bool(text == data), "bound": "latency (one lane per member, 64 serial decoders per wave; not HBM, not MFMA)",
-                    "frac": round((len(data) + len(blob)) / (best[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                    "traffic_source": "not an HBM-bound kernel: no PMC traffic profile"})
-        if text != data:
+        blob, best = timed(lambda: codec.deflate(bam))
+        entry(f"BGZF deflate (tag's BAM output): {len(bam) / 1e6:.0f} MB of BAM-shaped records -> {(len(bam) + 65279) // 65280} members",
+              "mk_bgzf_crc_kernel + mk_bgzf_deflate_kernel + mk_bgzf_pack_kernel", len(bam), len(blob), best,
+              "latency (serial parse per member; not HBM, not MFMA)",
+              {"compression_ratio": round(len(bam) / len(blob), 2),
+               "cpu_baseline": {"value": round(z_def / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib level 6, 65 280-byte members",
+                                "compression_ratio": round(z_ratio, 2), "sample": "the first 16.7 MB of the same text"}})
+        inflate_kernels = "mk_bgzf_inflate_kernel (a lane per member) or mk_bgzf_inflate_wave_kernel (a wave per member, small calls) + mk_bgzf_crc_check_kernel"
+        cpu_inf = {"value": round(z_inf / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib inflate of its own level 6 members",
+                   "sample": "the first 16.7 MB of the BAM text"}
+        text, best = timed(lambda: codec.inflate(blob))
+        entry(f"BGZF inflate, members the DEVICE wrote (long matches, few tokens): {(len(bam) + 65279) // 65280} members -> {len(bam) / 1e6:.0f} MB of BAM "
+              "records, CRC-32 checked", inflate_kernels, len(bam), len(blob), best, "latency (serial decode per member; not HBM, not MFMA)",
+              {"round_trip_equal": bool(text == bam), "cpu_baseline": cpu_inf})
+        if text != bam:
             raise RuntimeError("BGZF round trip on the device does not reproduce its input")
+        del text, blob
+        fq = _fastq_binned(n_bytes // 317 + 1)[:n_bytes]
+        for label, raw in (("BAM records, 4-bin qualities", bam), ("FASTQ, binned qualities in runs", fq)):
+            zb = _zlib_bgzf(raw)
+            for size_mb in (megabytes, 64):
+                tab, _, _ = mk.bgzf_members(zb)
+                import numpy as np
+                cum = np.cumsum(tab["isize"].astype(np.int64))
+                k = min(len(tab), int(np.searchsorted(cum, size_mb << 20)) + 1)
+                end = int(tab["data_off"][k - 1]) + int(tab["data_len"][k - 1]) + 8
+                part, want = zb[:end], raw[:int(cum[k - 1])]
+                text, best = timed(lambda: codec.inflate(part))
+                ok = text == want
+                entry(f"BGZF inflate, zlib LEVEL-6 members (what htslib / bgzip write) of {label}: {k} members -> {len(want) / 1e6:.0f} MB, CRC-32 checked",
+                      inflate_kernels, len(want), len(part), best, "latency (serial decode per member; not HBM, not MFMA)",
+                      {"compression_ratio": round(len(want) / len(part), 2), "round_trip_equal": bool(ok), "cpu_baseline": cpu_inf})
+                if not ok:
+                    raise RuntimeError("the device does not inflate zlib's members to their text")
+                del text
+            del zb
+        del fq, bam
         out.append(bgzf_window_config(mk, codec, reps))
     finally:
         codec.close()

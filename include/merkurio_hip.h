@@ -536,6 +536,10 @@ const uint8_t *mk_bgzf_eof(void);
 /* Tuning / test hook: a call is cut into device passes of at most `deflate_members` members (default 49 152 = 3.2 GB of
  * text) / `inflate_text_bytes` of text (default 3 GiB); 0 keeps the default.  Results do not depend on it. */
 int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inflate_text_bytes);
+/* (v6) Tuning / test hook: which inflate kernel the handle's calls use -- 0 (default) by the number of members in the call,
+ * 1 one lane per member (many members in flight, each slow), 2 one wave per member with the member's recent text in LDS (few in
+ * flight, each fast).  Results do not depend on it. */
+int mk_codec_set_inflate_kernel(mk_codec *c, int which);
 /* milliseconds of the handle's last call: [0] upload, [1] kernels, [2] download */
 int mk_codec_times(const mk_codec *c, float ms[3]);
 

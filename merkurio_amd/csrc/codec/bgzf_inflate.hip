@@ -42,9 +42,18 @@ uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
     return lanes;
 }
 
+// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in ~2 ms and holds four members per
+// CU: its time grows with the members per CU.  A lane per member takes 15-25 ms for its slowest lane whatever the call holds and
+// stays there up to tens of thousands of members.  They cross at ~4 members per CU-slot (64 MB: 6-10 ms against 14-22; 256 MB: 16-26 against 16-24) (profiles/r05_codec_inflate_kernels.txt).
+constexpr uint32_t kWaveRounds = 3;
+
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
-                    hipStream_t s) {
+                    hipStream_t s, int which) {
     if (!n_members) return;
+    if (which == 2 || (which == 0 && n_members <= (uint32_t)num_cus * 4u * kWaveRounds)) {
+        launch_inflate_wave(in, n_in, members, n_members, out, status, s);
+        return;
+    }
     const uint32_t lanes = inflate_lanes(n_members, num_cus);
     hipLaunchKernelGGL(mk_bgzf_inflate_kernel, dim3((n_members + lanes - 1) / lanes), dim3(lanes), lanes * (kLaneTableU16 / 2) * 4, s, in, n_in, members,
                        n_members, out, status);

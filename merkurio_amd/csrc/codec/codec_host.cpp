@@ -7,7 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../host_common.h"
@@ -37,6 +39,95 @@ constexpr uint64_t kInflateChunkText = 3ull << 30;
 float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0;
     return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
+}
+
+// ---- host buffers <-> device through the handle's two page-locked staging buffers (r05) -------------------------------------
+// A caller's plain (pageable) buffer cannot be a DMA source or target: the runtime stages it through a bounce buffer on ONE thread,
+// and a freshly allocated output buffer additionally takes a page fault per 4 KiB inside that copy -- mk_bgzf_inflate of 1 GB spent
+// 335 of its 376 ms there (kernels 41 ms; tools/codec_real.py before this change).  Here the host threads copy piece k + 1 into /
+// out of one staging buffer (first touch of the caller's pages included, on all of them) while the DMA engine moves piece k through
+// the other.  Buffers that are page-locked already (mk_host_alloc) and small ones go the direct way.
+constexpr uint64_t kStageBytes = 32ull << 20, kStageFrom = 4ull << 20;
+
+unsigned copy_threads() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hc ? hc : 4u));
+}
+void parallel_copy(uint8_t *dst, const uint8_t *src, uint64_t n) {
+    const unsigned T = (unsigned)std::min<uint64_t>(copy_threads(), n / (1u << 20) + 1);
+    if (T <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([=] { memcpy(dst + n * t / T, src + n * t / T, (size_t)(n * (t + 1) / T - n * t / T)); });
+    memcpy(dst, src, (size_t)(n / T));
+    for (auto &x : th) x.join();
+}
+bool is_page_locked(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to this query: not an error of ours)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+int stage_buffers(mk_codec *c) {
+    for (int k = 0; k < 2; ++k) {
+        if (!c->h_stage[k]) MKC_HIP(hipHostMalloc(&c->h_stage[k], kStageBytes, hipHostMallocDefault), "hipHostMalloc of a staging buffer");
+        if (!c->ev_stage[k]) MKC_HIP(hipEventCreateWithFlags(&c->ev_stage[k], hipEventDisableTiming), "hipEventCreate");
+    }
+    return MK_OK;
+}
+// src[0, n) -> d_dst, enqueued on the handle's stream; the host side of it is done when this returns
+int upload(mk_codec *c, void *d_dst, const uint8_t *src, uint64_t n) {
+    if (n < kStageFrom || is_page_locked(src)) {
+        MKC_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, c->stream), "upload");
+        return MK_OK;
+    }
+    int rc = stage_buffers(c);
+    if (rc) return rc;
+    int k = 0;
+    for (uint64_t at = 0; at < n; at += kStageBytes, k ^= 1) {
+        const uint64_t m = std::min<uint64_t>(kStageBytes, n - at);
+        if (at >= 2 * kStageBytes) MKC_HIP(hipEventSynchronize(c->ev_stage[k]), "hipEventSynchronize");  // its previous piece has left
+        parallel_copy((uint8_t *)c->h_stage[k], src + at, m);
+        MKC_HIP(hipMemcpyAsync((uint8_t *)d_dst + at, c->h_stage[k], m, hipMemcpyHostToDevice, c->stream), "upload");
+        MKC_HIP(hipEventRecord(c->ev_stage[k], c->stream), "hipEventRecord");
+    }
+    // the staging buffers are reused by the next transfer of the call: wait until both have been read
+    MKC_HIP(hipEventSynchronize(c->ev_stage[0]), "hipEventSynchronize");
+    MKC_HIP(hipEventSynchronize(c->ev_stage[1]), "hipEventSynchronize");
+    return MK_OK;
+}
+// d_src[0, n) -> dst; waits for the stream (everything enqueued before it included)
+int download(mk_codec *c, uint8_t *dst, const void *d_src, uint64_t n) {
+    if (n < kStageFrom || is_page_locked(dst)) {
+        if (n) MKC_HIP(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, c->stream), "download");
+        MKC_HIP(hipStreamSynchronize(c->stream), "download");
+        return MK_OK;
+    }
+    int rc = stage_buffers(c);
+    if (rc) return rc;
+    // piece j travels into buffer j & 1 while the host threads copy piece j - 1 out of the other
+    const uint64_t pieces = (n + kStageBytes - 1) / kStageBytes;
+    for (uint64_t j = 0; j <= pieces; ++j) {
+        if (j < pieces) {
+            const uint64_t at = j * kStageBytes, m = std::min<uint64_t>(kStageBytes, n - at);
+            MKC_HIP(hipMemcpyAsync(c->h_stage[j & 1], (const uint8_t *)d_src + at, m, hipMemcpyDeviceToHost, c->stream), "download");
+            MKC_HIP(hipEventRecord(c->ev_stage[j & 1], c->stream), "hipEventRecord");
+        }
+        if (j > 0) {
+            const uint64_t at = (j - 1) * kStageBytes, m = std::min<uint64_t>(kStageBytes, n - at);
+            MKC_HIP(hipEventSynchronize(c->ev_stage[(j - 1) & 1]), "hipEventSynchronize");
+            parallel_copy(dst + at, (const uint8_t *)c->h_stage[(j - 1) & 1], m);
+        }
+    }
+    return MK_OK;
+}
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 const uint8_t kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -76,6 +167,10 @@ void mk_codec_destroy(mk_codec *c) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) {
+        if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+        if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -93,6 +188,13 @@ int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inf
     std::lock_guard<std::mutex> lock(c->mu);
     c->deflate_pass_blocks = deflate_members;
     c->inflate_pass_text = inflate_text_bytes;
+    return MK_OK;
+}
+
+int mk_codec_set_inflate_kernel(mk_codec *c, int which) {
+    if (!c || which < 0 || which > 2) return mk::fail(MK_E_INVALID_ARG, "mk_codec_set_inflate_kernel: handle / selector");
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->inflate_kernel = which;
     return MK_OK;
 }
 
@@ -138,14 +240,16 @@ int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint
             (rc = mk::ensure_device(&c->d_out, &c->out_cap, mk_bgzf_deflate_bound(cn, bb))))
             return rc;
         uint64_t *d_total = (uint64_t *)c->d_off + blocks;
-        MKC_HIP(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
+        const double t_up = now_ms();
         for (uint64_t done = 0; done < cn;) {  // the pieces land back to back: the concatenation exists on the device only
             while (piece_at == sizes[piece]) ++piece, piece_at = 0;
             const uint64_t k = std::min<uint64_t>(cn - done, sizes[piece] - piece_at);
-            MKC_HIP(hipMemcpyAsync((uint8_t *)c->d_in + done, pieces[piece] + piece_at, k, hipMemcpyHostToDevice, c->stream), "upload of the text");
+            if ((rc = upload(c, (uint8_t *)c->d_in + done, pieces[piece] + piece_at, k))) return rc;
             done += k, piece_at += k;
         }
         MKC_HIP(hipMemsetAsync((uint8_t *)c->d_in + cn, 0, mkz::kPad, c->stream), "hipMemsetAsync");
+        MKC_HIP(hipStreamSynchronize(c->stream), "upload of the text");
+        c->ms[0] += (float)(now_ms() - t_up);
         MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
         mkz::launch_crc((const uint8_t *)c->d_in, cn, bb, blocks, (uint32_t *)c->d_crc, c->stream);
         mkz::launch_deflate((const uint8_t *)c->d_in, cn, bb, blocks, (const uint32_t *)c->d_crc, (uint32_t *)c->d_tokens, (uint8_t *)c->d_slots,
@@ -157,10 +261,9 @@ int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *const *pieces, const uint
         MKC_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream), "download of the size");
         MKC_HIP(hipStreamSynchronize(c->stream), "BGZF deflate");
         if (total > out_cap - written) return mk::fail(MK_E_CAPACITY, "mk_bgzf_deflate: members exceed the bound (internal error)");
-        MKC_HIP(hipMemcpyAsync(out + written, c->d_out, total, hipMemcpyDeviceToHost, c->stream), "download of the members");
-        MKC_HIP(hipEventRecord(c->ev[3], c->stream), "hipEventRecord");
-        MKC_HIP(hipStreamSynchronize(c->stream), "BGZF deflate");
-        c->ms[0] += elapsed(c->ev[0], c->ev[1]), c->ms[1] += elapsed(c->ev[1], c->ev[2]), c->ms[2] += elapsed(c->ev[2], c->ev[3]);
+        const double t_down = now_ms();
+        if ((rc = download(c, out + written, c->d_out, total))) return rc;
+        c->ms[1] += elapsed(c->ev[1], c->ev[2]), c->ms[2] += (float)(now_ms() - t_down);
         written += total;
     }
     *out_len = written;
@@ -260,21 +363,27 @@ int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf
         if ((rc = mk::ensure_device(&c->d_in, &c->in_cap, cn + mkz::kPad)) || (rc = mk::ensure_device(&c->d_aux, &c->aux_cap, cnt * sizeof(mkz::Member))) ||
             (rc = mk::ensure_device(&c->d_out, &c->out_cap, tn + 16)) || (rc = mk::ensure_device(&c->d_len, &c->len_cap, cnt * 4ull)))
             return rc;
-        MKC_HIP(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
-        MKC_HIP(hipMemcpyAsync(c->d_in, in + in_lo, cn, hipMemcpyHostToDevice, c->stream), "upload of the members");
+        const double t_up = now_ms();
+        if ((rc = upload(c, c->d_in, in + in_lo, cn))) return rc;
         MKC_HIP(hipMemsetAsync((uint8_t *)c->d_in + cn, 0, mkz::kPad, c->stream), "hipMemsetAsync");
         MKC_HIP(hipMemcpyAsync(c->d_aux, part.data(), cnt * sizeof(mkz::Member), hipMemcpyHostToDevice, c->stream), "upload of the member table");
+        MKC_HIP(hipStreamSynchronize(c->stream), "upload of the members");
+        c->ms[0] += (float)(now_ms() - t_up);
         MKC_HIP(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
-        mkz::launch_inflate((const uint8_t *)c->d_in, cn, (const mkz::Member *)c->d_aux, cnt, (uint8_t *)c->d_out, (int32_t *)c->d_len, c->num_cus, c->stream);
+        mkz::launch_inflate((const uint8_t *)c->d_in, cn, (const mkz::Member *)c->d_aux, cnt, (uint8_t *)c->d_out, (int32_t *)c->d_len, c->num_cus, c->stream,
+                            c->inflate_kernel);
         mkz::launch_crc_check((const uint8_t *)c->d_out, (const mkz::Member *)c->d_aux, cnt, (int32_t *)c->d_len, c->stream);
         MKC_HIP(hipGetLastError(), "BGZF inflate kernels");
         MKC_HIP(hipEventRecord(c->ev[2], c->stream), "hipEventRecord");
         status.resize(cnt);
         MKC_HIP(hipMemcpyAsync(status.data(), c->d_len, cnt * 4ull, hipMemcpyDeviceToHost, c->stream), "download of the status words");
-        if (tn) MKC_HIP(hipMemcpyAsync(out + out_lo, c->d_out, tn, hipMemcpyDeviceToHost, c->stream), "download of the text");
-        MKC_HIP(hipEventRecord(c->ev[3], c->stream), "hipEventRecord");
         MKC_HIP(hipStreamSynchronize(c->stream), "BGZF inflate");
-        c->ms[0] += elapsed(c->ev[0], c->ev[1]), c->ms[1] += elapsed(c->ev[1], c->ev[2]), c->ms[2] += elapsed(c->ev[2], c->ev[3]);
+        // (a damaged member's text is not handed out: the status words first)
+        bool all_ok = true;
+        for (uint32_t k = 0; k < cnt && all_ok; ++k) all_ok = status[k] == 0;
+        const double t_down = now_ms();
+        if (all_ok && tn && (rc = download(c, out + out_lo, c->d_out, tn))) return rc;
+        c->ms[1] += elapsed(c->ev[1], c->ev[2]), c->ms[2] += (float)(now_ms() - t_down);
         for (uint32_t k = 0; k < cnt; ++k)
             if (status[k]) {
                 if (bad_member) *bad_member = m0 + k;

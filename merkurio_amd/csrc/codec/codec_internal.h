@@ -17,6 +17,10 @@ struct mk_codec {
     void *d_in = nullptr, *d_crc = nullptr, *d_tokens = nullptr, *d_slots = nullptr, *d_len = nullptr, *d_off = nullptr, *d_out = nullptr,
          *d_aux = nullptr;
     size_t in_cap = 0, crc_cap = 0, tokens_cap = 0, slots_cap = 0, len_cap = 0, off_cap = 0, out_cap = 0, aux_cap = 0;
+    // host buffers travel through two page-locked staging buffers, filled / emptied by the host threads beside the DMA (codec_host.cpp)
+    void *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    int inflate_kernel = 0;  // mk_codec_set_inflate_kernel: 0 = chosen per call, 1 = a lane per member, 2 = a wave per member
     float ms[3] = {0, 0, 0};
     uint64_t deflate_pass_blocks = 0, inflate_pass_text = 0;  // mk_codec_set_pass_limits; 0 = the defaults below
 };

@@ -407,7 +407,7 @@ int window_assemble(mk_matcher *m, mk_codec *codec, mk_window_source &S, WindowS
         if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the members failed");
         dl.mark(1);
         mkz::launch_inflate((const uint8_t *)codec->d_in, cn, (const mkz::Member *)codec->d_aux, (uint32_t)S.n_members, (uint8_t *)T.d_text,
-                            (int32_t *)codec->d_len, codec->num_cus, st);
+                            (int32_t *)codec->d_len, codec->num_cus, st, codec->inflate_kernel);
         mkz::launch_crc_check((const uint8_t *)T.d_text, (const mkz::Member *)codec->d_aux, (uint32_t)S.n_members, (int32_t *)codec->d_len, st);
         std::vector<int32_t> st_words(S.n_members);
         if (hipGetLastError() != hipSuccess ||

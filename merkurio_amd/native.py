@@ -12,6 +12,7 @@ Everything that searches text runs in the gfx950 kernels; there is no CPU fallba
 the library or a GPU is missing, construction raises.
 """
 import ctypes as C
+import time
 import importlib.util
 import os
 
@@ -53,7 +54,7 @@ EXPORTS = [
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_reduce_prepare", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
-    "mk_codec_times", "mk_codec_set_pass_limits", "mk_extract_fastq_bgzf", "mk_extract_window",
+    "mk_codec_times", "mk_codec_set_pass_limits", "mk_codec_set_inflate_kernel", "mk_extract_fastq_bgzf", "mk_extract_window",
 ]
 
 
@@ -225,6 +226,7 @@ def load(build_if_missing=True):
     L.mk_bgzf_eof.restype = C.POINTER(C.c_uint8 * 28)
     L.mk_codec_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mk_codec_set_pass_limits.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.mk_codec_set_inflate_kernel.argtypes = [C.c_void_p, C.c_int]
     L.mk_extract_fastq_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
                                         C.POINTER(WindowText), C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
@@ -815,8 +817,11 @@ class Codec:
         src = np.frombuffer(data, dtype=np.uint8)
         out = np.empty(self._L.mk_bgzf_deflate_bound(src.size, block_bytes), dtype=np.uint8)
         n = C.c_uint64(0)
-        _check(self._L.mk_bgzf_deflate(self._h, src.ctypes.data if src.size else None, src.size, block_bytes,
-                                       out.ctypes.data if out.size else None, out.size, C.byref(n)))
+        t0 = time.perf_counter()
+        rc = self._L.mk_bgzf_deflate(self._h, src.ctypes.data if src.size else None, src.size, block_bytes,
+                                     out.ctypes.data if out.size else None, out.size, C.byref(n))
+        self.last_call_s = time.perf_counter() - t0  # (the C call alone: not this wrapper's buffer and bytes-object copies)
+        _check(rc)
         return out[:n.value].tobytes()
 
     def deflate_pieces(self, pieces, block_bytes=0):
@@ -839,9 +844,16 @@ class Codec:
         src = np.frombuffer(data, dtype=np.uint8)
         out = np.empty(text_bytes, dtype=np.uint8)
         bad = C.c_uint64(0)
-        _check(self._L.mk_bgzf_inflate(self._h, src.ctypes.data if src.size else None, src.size, members.ctypes.data if members.size else None,
-                                       members.size, out.ctypes.data if out.size else None, out.size, C.byref(bad)))
+        t0 = time.perf_counter()
+        rc = self._L.mk_bgzf_inflate(self._h, src.ctypes.data if src.size else None, src.size, members.ctypes.data if members.size else None,
+                                     members.size, out.ctypes.data if out.size else None, out.size, C.byref(bad))
+        self.last_call_s = time.perf_counter() - t0  # (the C call alone, first touch of the fresh output buffer included)
+        _check(rc)
         return out.tobytes()
+
+    def set_inflate_kernel(self, which=0):
+        """0 = chosen per call, 1 = a lane per member, 2 = a wave per member (mk_codec_set_inflate_kernel)"""
+        _check(self._L.mk_codec_set_inflate_kernel(self._h, which))
 
     def set_pass_limits(self, deflate_members=0, inflate_text_bytes=0):
         _check(self._L.mk_codec_set_pass_limits(self._h, deflate_members, inflate_text_bytes))

@@ -74,19 +74,24 @@ for label, make in (("BAM records, 4-bin qualities", lambda mb: bam_like(mb * (1
             else:
                 reps = mb // unit_mb
                 blob, want = blob_unit * reps, None
-            best = None
-            for r in range(3):
-                t1 = time.time()
-                text = codec.inflate(blob)
-                dt = time.time() - t1
-                up, dev, down = codec.times()
-                if best is None or dev < best[1]:
-                    best = (dt, dev, up, down)
-            if want is not None:
-                assert text == want
-            else:
-                assert len(text) == len(unit) * reps and text[:1 << 20] == unit[:1 << 20] and text[-(1 << 20):] == unit[-(1 << 20):]
-            n_text = len(text)
-            del text
-            print(f"  {mb:5d} MB, {kind:24s}: kernels {best[1]:7.2f} ms = {n_text / best[1] / 1e6:6.1f} GB/s of text; call {best[0] * 1e3:6.0f} ms "
-                  f"(upload {best[2]:.0f}, download {best[3]:.0f})", flush=True)
+            for which, kname in ((0, "chosen by size"), (1, "lane per member"), (2, "wave per member")):
+                if which == 2 and mb > 1024:
+                    continue
+                codec.set_inflate_kernel(which)
+                best = None
+                for r in range(3):
+                    t1 = time.time()
+                    text = codec.inflate(blob)
+                    dt = codec.last_call_s  # (the C call alone)
+                    up, dev, down = codec.times()
+                    if best is None or dev < best[1]:
+                        best = (dt, dev, up, down)
+                if want is not None:
+                    assert text == want
+                else:
+                    assert len(text) == len(unit) * reps and text[:1 << 20] == unit[:1 << 20] and text[-(1 << 20):] == unit[-(1 << 20):]
+                n_text = len(text)
+                del text
+                print(f"  {mb:5d} MB, {kind:24s}, {kname:16s}: kernels {best[1]:7.2f} ms = {n_text / best[1] / 1e6:6.1f} GB/s of text; call {best[0] * 1e3:6.0f} ms "
+                      f"(upload {best[2]:.0f}, download {best[3]:.0f})", flush=True)
+            codec.set_inflate_kernel(0)
