@@ -20,7 +20,7 @@ namespace mkz {
 static_assert(kPad >= kStreamPad, "input buffers carry the decoder's padding");
 
 // blockDim.x = the lanes of a wave that hold a member (1, 2, 4 ... 64): LDS is sized for them at launch
-__global__ __launch_bounds__(64) void mk_bgzf_inflate_kernel(const uint8_t *__restrict__ in, uint64_t n_in, const Member *__restrict__ members,
+__global__ __launch_bounds__(64, 4) void mk_bgzf_inflate_kernel(const uint8_t *__restrict__ in, uint64_t n_in, const Member *__restrict__ members,
                                                              uint32_t n_members, uint8_t *__restrict__ out, int32_t *__restrict__ status) {
     extern __shared__ uint32_t lanes[];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

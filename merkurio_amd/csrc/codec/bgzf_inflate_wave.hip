@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Canonical tables of one code from lens[0, n) (n <= 320, in LDS), by the whole wave: sorted[] = symbols in (length, symbol)
-// order, limit[l] / base[l] as build_decode_tables (inflate_serial.hpp) defines them.  Returns 0 / 1 over-subscribed /
+// order, limit[l] / base[l] as inflate_serial.hpp defines them.  Returns 0 / 1 over-subscribed /
 // 2 incomplete and not one of the shapes zlib accepts.
 __device__ int wave_build_tables(const uint8_t *lens, uint32_t n, uint16_t *sorted, uint16_t *limit, uint16_t *base, bool allow_single) {
     const uint32_t lane = lane_id();

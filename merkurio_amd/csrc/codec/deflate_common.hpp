@@ -134,8 +134,10 @@ MKZ_HD void code_lengths_from_sorted(const uint32_t *skey, int m, int maxbits, u
 
 // canonical codewords (§3.2.2) of lens[0..n), stored bit-reversed: DEFLATE packs Huffman codes starting with
 // their most significant bit into a stream that is otherwise filled from the least significant bit
-MKZ_HD void canonical_codes(const uint8_t *lens, int n, uint16_t *codes) {
-    uint32_t count[kMaxBits + 1], next[kMaxBits + 2];
+// (count[] and next[] -- indexed by a code length -- live in the caller's HuffScratch, LDS on the device: a local array indexed by
+// a run-time value would be private memory)
+MKZ_HD void canonical_codes(const uint8_t *lens, int n, uint16_t *codes, HuffScratch &s) {
+    uint32_t *const count = s.count, *const next = s.weight;  // (weight[]: free once the lengths are known)
     for (int l = 0; l <= kMaxBits; ++l) count[l] = 0;
     for (int i = 0; i < n; ++i) count[lens[i]]++;
     count[0] = 0;
@@ -175,8 +177,8 @@ MKZ_HD void block_codes_from_sorted(const uint32_t *ll_key, int ll_m, const uint
     for (int i = 0; i < 32; ++i) c.d_len[i] = 0;
     code_lengths_from_sorted(ll_key, ll_m, kMaxBits, c.ll_len, s);
     code_lengths_from_sorted(d_key, d_m, kMaxBits, c.d_len, s);
-    canonical_codes(c.ll_len, kLitLen, c.ll_code);
-    canonical_codes(c.d_len, kDist, c.d_code);
+    canonical_codes(c.ll_len, kLitLen, c.ll_code, s);
+    canonical_codes(c.d_len, kDist, c.d_code, s);
 }
 
 // ---- bit stream, filled from the least significant bit of 32-bit words (words zeroed by the caller) ----
@@ -200,12 +202,17 @@ struct HeaderScratch {
     uint8_t cl_len[kCl];
     uint16_t cl_code[kCl];
     uint32_t hlit, hdist, hclen;
+    uint32_t cl_key[kCl + 2];  // the code-length code's (frequency << 9 | symbol) keys, sorted
     HuffScratch huff;
 };
 
-MKZ_HD void cl_order(uint8_t o[kCl]) {
-    const uint8_t t[kCl] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    for (int i = 0; i < kCl; ++i) o[i] = t[i];
+// the order in which the lengths of the code-length code are sent (3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 -- 5 bits
+// each in two constants, so that position i needs a shift, not an array
+MKZ_HD uint32_t cl_order_at(uint32_t i) {
+    const uint64_t lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 |
+                        11ull << 50 | 4ull << 55;
+    const uint64_t hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    return (uint32_t)((i < 12 ? lo >> (5 * i) : hi >> (5 * (i - 12))) & 31u);
 }
 
 // Builds the run-length form and the code-length code; returns the header's size in bits (BFINAL/BTYPE included).
@@ -239,7 +246,7 @@ MKZ_HD uint32_t plan_dynamic_header(const uint8_t *ll_len, const uint8_t *d_len,
     }
     h.n_rle = n;
     // code-length code: <= 19 symbols, insertion sort of their keys
-    uint32_t key[kCl + 2];
+    uint32_t *const key = h.cl_key;
     int m = 0;
     for (int s = 0; s < kCl; ++s)
         if (h.cl_freq[s]) {
@@ -255,11 +262,9 @@ MKZ_HD uint32_t plan_dynamic_header(const uint8_t *ll_len, const uint8_t *d_len,
         m = 2;
     }
     code_lengths_from_sorted(key, m, kMaxClBits, h.cl_len, h.huff);
-    canonical_codes(h.cl_len, kCl, h.cl_code);
-    uint8_t order[kCl];
-    cl_order(order);
+    canonical_codes(h.cl_len, kCl, h.cl_code, h.huff);
     uint32_t hclen = kCl;
-    while (hclen > 4 && h.cl_len[order[hclen - 1]] == 0) --hclen;
+    while (hclen > 4 && h.cl_len[cl_order_at(hclen - 1)] == 0) --hclen;
     h.hclen = hclen;
     uint32_t bits = 3 + 5 + 5 + 4 + 3 * hclen;
     for (uint32_t k = 0; k < n; ++k) {
@@ -275,9 +280,7 @@ MKZ_HD void write_dynamic_header(BitSink &b, const HeaderScratch &h, bool final_
     put_bits(b, h.hlit - 257, 5);
     put_bits(b, h.hdist - 1, 5);
     put_bits(b, h.hclen - 4, 4);
-    uint8_t order[kCl];
-    cl_order(order);
-    for (uint32_t i = 0; i < h.hclen; ++i) put_bits(b, h.cl_len[order[i]], 3);
+    for (uint32_t i = 0; i < h.hclen; ++i) put_bits(b, h.cl_len[cl_order_at(i)], 3);
     for (uint32_t k = 0; k < h.n_rle; ++k) {
         const uint32_t s = h.rle[k] & 255u, x = h.rle[k] >> 8;
         put_bits(b, h.cl_code[s], h.cl_len[s]);

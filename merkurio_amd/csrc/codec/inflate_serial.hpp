@@ -20,7 +20,7 @@
 //     per token turn, and a round's loads are issued one turn before its stores: the L2 round trip runs beside the
 //     next decode.  A long match occupies its own lane for several turns instead of stalling all 64.
 // 836 bytes of LDS per lane (an odd number of dwords: the lanes' blocks start in different banks), 52 KiB per wave.
-// Only the code lengths while a block header is read sit in private memory (once per block).
+// Nothing sits in private memory (r05: a block header is decoded twice instead of keeping its code lengths in an array).
 #pragma once
 #include "deflate_common.hpp"
 
@@ -51,37 +51,11 @@ MKZ_HD uint32_t load_le32(const uint8_t *p) {
     return v;
 }
 
-// Tables of one code from lens[0..n): sorted[] (symbols in (length, symbol) order), limit[l] = the first left-aligned
-// 15-bit value behind the codewords of length l (ascending in l), base[l] = (rank of the first symbol of length l) -
-// (its codeword), mod 2^16.  Returns 0 / 1 over-subscribed / 2 incomplete (usable only as zlib's inflate_table
-// accepts it: no codeword at all, or -- allow_single: literal / length and distance codes -- exactly one codeword of
-// length 1).
-MKZ_HD int build_decode_tables(const uint8_t *lens, int n, uint16_t *sorted, uint16_t *limit, uint16_t *base, bool allow_single) {
-    uint32_t count[kMaxBits + 1], offs[kMaxBits + 2];
-    for (int l = 0; l <= kMaxBits; ++l) count[l] = 0;
-    for (int i = 0; i < n; ++i) count[lens[i]]++;
-    const int used = n - (int)count[0];
-    count[0] = 0;
-    int left = 1;
-    for (int l = 1; l <= kMaxBits; ++l) {
-        left <<= 1;
-        left -= (int)count[l];
-        if (left < 0) return 1;
-    }
-    uint32_t code = 0;
-    offs[1] = 0;
-    limit[0] = 0, base[0] = 0;
-    for (int l = 1; l <= kMaxBits; ++l) {
-        code = (code + count[l - 1]) << 1;
-        offs[l + 1] = offs[l] + count[l];
-        limit[l] = (uint16_t)((code + count[l]) << (kMaxBits - l));
-        base[l] = (uint16_t)(offs[l] - code);
-    }
-    for (int i = 0; i < n; ++i)
-        if (lens[i]) sorted[offs[lens[i]]++] = (uint16_t)i;
-    if (left > 0 && !(used == 0 || (allow_single && used == 1 && count[1] == 1))) return 2;
-    return 0;
-}
+// The canonical description of a prefix code, as the decoders use it: sorted[] = the symbols in (length, symbol) order; limit[l] =
+// the first left-aligned 15-bit value behind the codewords of length l (ascending in l); base[l] = (rank of the first symbol of
+// length l) - (its first codeword), mod 2^16.  Built by tables_from_counts below (one lane, no arrays) and by wave_build_tables
+// (bgzf_inflate_wave.hip: a whole wave).  A code is refused when it is over-subscribed, or incomplete and not one of the two shapes
+// zlib's inflate_table accepts: no codeword at all, or -- literal / length and distance codes -- exactly one codeword of length 1.
 
 MKZ_HD uint32_t bit_reverse32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -106,6 +80,116 @@ MKZ_HD uint32_t decode_codeword(uint32_t bits, const uint16_t *sorted, const uin
     if (w >= limit[l]) return 0;
     const uint32_t idx = (base[l] + (w >> (kMaxBits - l))) & 0xffffu;
     return (uint32_t)sorted[idx] << 4 | l;
+}
+
+// ---- a block header without a code-length array (r05) -----------------------------------------------------------------------
+// The 288 + 32 code lengths of a dynamic block used to sit in a per-lane array: 336 bytes of private (scratch) memory, the only
+// ones of the kernel.  They are not needed as an array: the header is decoded TWICE.  Pass 1 only counts the codewords of each
+// length (fifteen 10-bit counters in three 64-bit registers per alphabet); from the counts follow the limits, the bases and the rank
+// of the first symbol of every length; the bit reader goes back to where the lengths began and pass 2 drops each symbol into its
+// place in sorted[].  The code-length code itself (19 symbols of at most 7 bits) lives in four 64-bit registers.  No array is
+// indexed by a run-time value anywhere in the header any more: 0 bytes of scratch.
+// (three separate scalars, not an array and not a struct whose members a select could pick between by address: what a run-time
+// value selects here is a VALUE, so nothing has to live in memory)
+// ("Pack15": fifteen 10-bit fields, l = 1..15: 1..6 in a, 7..12 in b, 13..15 in c)
+MKZ_HD uint32_t p15_get(uint64_t a, uint64_t b, uint64_t c, uint32_t l) {
+    const uint32_t k = l - 1;
+    const uint32_t f = k < 6 ? k : k < 12 ? k - 6 : k - 12;
+    const uint64_t w = (k < 6 ? a : 0ull) | ((k >= 6 && k < 12) ? b : 0ull) | (k >= 12 ? c : 0ull);
+    return (uint32_t)(w >> (10 * f)) & 1023u;
+}
+MKZ_HD void p15_add(uint64_t &a, uint64_t &b, uint64_t &c, uint32_t l, uint32_t v) {
+    const uint32_t k = l - 1;
+    const uint32_t f = k < 6 ? k : k < 12 ? k - 6 : k - 12;
+    const uint64_t inc = (uint64_t)v << (10 * f);
+    a += k < 6 ? inc : 0ull;
+    b += (k >= 6 && k < 12) ? inc : 0ull;
+    c += k >= 12 ? inc : 0ull;
+}
+MKZ_HD void p15_set(uint64_t &a, uint64_t &b, uint64_t &c, uint32_t l, uint32_t v) {
+    const uint32_t k = l - 1;
+    const uint32_t f = k < 6 ? k : k < 12 ? k - 6 : k - 12;
+    const uint64_t m = ~(1023ull << (10 * f)), x = (uint64_t)v << (10 * f);
+    a = k < 6 ? (a & m) | x : a;
+    b = (k >= 6 && k < 12) ? (b & m) | x : b;
+    c = k >= 12 ? (c & m) | x : c;
+}
+// limit[] / base[] (as defined above) and offs = rank of the first symbol of every length, from the counts per
+// length; `used` = codewords in all.  Returns 0 / 1 over-subscribed / 2 incomplete and not a shape zlib's inflate_table accepts.
+// (in place: `p` holds the counts on entry and the ranks on return -- the two are never needed together)
+MKZ_HD int tables_from_counts(uint64_t &pa, uint64_t &pb, uint64_t &pc, uint32_t used, uint16_t *limit, uint16_t *base, bool allow_single) {
+    int left = 1;
+    uint32_t code = 0, off = 0, prev = 0;
+    limit[0] = 0, base[0] = 0;
+    const uint32_t c1 = p15_get(pa, pb, pc, 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (uint32_t l = 1; l <= (uint32_t)kMaxBits; ++l) {
+        const uint32_t c = p15_get(pa, pb, pc, l);
+        left = (left << 1) - (int)c;
+        if (left < 0) return 1;
+        code = (code + prev) << 1;
+        limit[l] = (uint16_t)((code + c) << (kMaxBits - l));
+        base[l] = (uint16_t)(off - code);
+        p15_set(pa, pb, pc, l, off);  // count -> rank of the first symbol of this length
+        off += c;
+        prev = c;
+    }
+    if (left > 0 && !(used == 0 || (allow_single && used == 1 && c1 == 1))) return 2;
+    return 0;
+}
+
+// the code-length code in registers: limit / base of the lengths 1..7 (8 bits each, field l), the symbols in (length, symbol)
+// order (5 bits each: ranks 0..11 in sorted_lo, 12..18 in sorted_hi)
+struct ClCode {
+    uint64_t limit, base, sorted_lo, sorted_hi;
+};
+// cl = the 19 lengths, 3 bits each, indexed by symbol.  Returns 0 or 1 (over-subscribed, or incomplete with any codeword at all)
+MKZ_HD int cl_build(uint64_t cl, ClCode &t) {
+    uint64_t cnt = 0;  // eight 5-bit counters
+    uint32_t used = 0;
+    for (int s = 0; s < kCl; ++s) {
+        const uint32_t len = (uint32_t)(cl >> (3 * s)) & 7u;
+        cnt += len ? 1ull << (5 * len) : 0ull;
+        used += len != 0;
+    }
+    int left = 1;
+    uint32_t code = 0, off = 0, prev = 0;
+    uint64_t offs = 0;
+    t.limit = t.base = t.sorted_lo = t.sorted_hi = 0;
+    for (uint32_t l = 1; l <= (uint32_t)kMaxClBits; ++l) {
+        const uint32_t c = (uint32_t)(cnt >> (5 * l)) & 31u;
+        left = (left << 1) - (int)c;
+        if (left < 0) return 1;
+        code = (code + prev) << 1;
+        t.limit |= (uint64_t)(((code + c) << (kMaxClBits - l)) & 0xffu) << (8 * l);
+        t.base |= (uint64_t)((off - code) & 0xffu) << (8 * l);
+        offs |= (uint64_t)off << (5 * l);
+        off += c;
+        prev = c;
+    }
+    if (left > 0 && used != 0) return 1;
+    for (int s = 0; s < kCl; ++s) {
+        const uint32_t len = (uint32_t)(cl >> (3 * s)) & 7u;
+        if (!len) continue;
+        const uint32_t pos = (uint32_t)(offs >> (5 * len)) & 31u;
+        offs += 1ull << (5 * len);
+        if (pos < 12) t.sorted_lo |= (uint64_t)s << (5 * pos);
+        else t.sorted_hi |= (uint64_t)s << (5 * (pos - 12));
+    }
+    return 0;
+}
+// the code-length codeword at the low end of `bits`: symbol << 4 | length, or 0 (decode_codeword's rule on 7 bits)
+MKZ_HD uint32_t cl_decode(uint32_t bits, const ClCode &t) {
+    const uint32_t w = bit_reverse32(bits) >> (32 - kMaxClBits);
+    uint32_t l = 1;
+    for (int k = 1; k < kMaxClBits; ++k) l += w >= ((uint32_t)(t.limit >> (8 * k)) & 0xffu);  // (a limit of 128 is never reached: w < 128)
+    // limit[l] == 128 means "every 7-bit value is in front of it"; as an 8-bit field 128 survives, as the general code's 2^15 does in 16 bits
+    if (w >= ((uint32_t)(t.limit >> (8 * l)) & 0xffu)) return 0;
+    const uint32_t idx = ((uint32_t)(t.base >> (8 * l)) + (w >> (kMaxClBits - l))) & 0xffu;
+    const uint32_t sym = idx < 12 ? (uint32_t)(t.sorted_lo >> (5 * idx)) & 31u : (uint32_t)(t.sorted_hi >> (5 * (idx - 12))) & 31u;
+    return sym << 4 | l;
 }
 
 // in[0, n_in): the raw DEFLATE stream (readable up to in + n_in + kStreamPad); out[0, n_out): exactly what it must
@@ -168,63 +252,106 @@ MKZ_HD int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32
             continue;
         }
         if (type == 3) return kInfBadBlockType;
-        {
-            uint8_t lens[288 + 32];
-            if (type == 1) {
-                fixed_code_lengths(lens, lens + 288);
-            } else {
-                const uint32_t hlit = ((uint32_t)bitbuf & 31u) + 257, hdist = ((uint32_t)(bitbuf >> 5) & 31u) + 1,
-                               hclen = ((uint32_t)(bitbuf >> 10) & 15u) + 4;
-                MKZ_TAKE(14);
-                if (hlit > 286 || hdist > 30) return kInfBadLengths;
-                uint8_t order[kCl], cl_len[kCl];
-                cl_order(order);
-                for (int i = 0; i < kCl; ++i) cl_len[i] = 0;
+        if (type == 1) {
+            // the fixed code of RFC 1951 3.2.6: lengths 7 (256..279), 8 (0..143, 280..287), 9 (144..255); 32 distance codewords of
+            // 5 bits (symbols 30 and 31 complete the code and are refused when met)
+            uint64_t ca = 0, cb = 0, cc = 0;
+            p15_add(ca, cb, cc, 7, 24), p15_add(ca, cb, cc, 8, 152), p15_add(ca, cb, cc, 9, 112);
+            (void)tables_from_counts(ca, cb, cc, 288, ll_limit, ll_base, true);
+            // rank k -> symbol: 256..279, then 0..143, then 280..287, then 144..255
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+            for (uint32_t k = 0; k < 288; ++k) ll_sorted[k] = (uint16_t)(k < 24 ? 256 + k : k < 168 ? k - 24 : k < 176 ? k + 112 : k - 32);
+            ca = cb = cc = 0;
+            p15_add(ca, cb, cc, 5, 32);
+            (void)tables_from_counts(ca, cb, cc, 32, d_limit, d_base, true);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+            for (uint32_t k = 0; k < 32; ++k) d_sorted[k] = (uint16_t)k;
+        } else {
+            const uint32_t hlit = ((uint32_t)bitbuf & 31u) + 257, hdist = ((uint32_t)(bitbuf >> 5) & 31u) + 1,
+                           hclen = ((uint32_t)(bitbuf >> 10) & 15u) + 4;
+            MKZ_TAKE(14);
+            if (hlit > 286 || hdist > 30) return kInfBadLengths;
+            // the code-length code: 19 lengths of 3 bits, sent in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+            uint64_t cl = 0;
+            {
+                const uint64_t order_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                                          5ull << 45 | 11ull << 50 | 4ull << 55;
+                const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
                 for (uint32_t i = 0; i < hclen; ++i) {
                     MKZ_NEED32();
-                    cl_len[order[i]] = (uint8_t)((uint32_t)bitbuf & 7u);
+                    const uint32_t sym = (uint32_t)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31u);
+                    cl |= (uint64_t)((uint32_t)bitbuf & 7u) << (3 * sym);
                     MKZ_TAKE(3);
                 }
-                // the code-length code borrows the literal tables
-                if (build_decode_tables(cl_len, kCl, ll_sorted, ll_limit, ll_base, false)) return kInfBadLengths;
-                uint32_t i = 0;
+            }
+            ClCode clc;
+            if (cl_build(cl, clc)) return kInfBadLengths;
+            // where the code lengths begin, in bits of the stream: pass 2 starts here again
+            const uint64_t lens_at = (uint64_t)MKZ_TAKEN() * 8 - bitcnt;
+            uint64_t la = 0, lb = 0, lc = 0, da = 0, db = 0, dc = 0;  // (Pack15 each) pass 1: codewords per length; pass 2: the next free rank of every length
+            uint32_t ll_used = 0, d_used = 0;
+            bool has_eob = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) {
+                    if (!has_eob) return kInfBadLengths;  // no end-of-block codeword
+                    if (tables_from_counts(la, lb, lc, ll_used, ll_limit, ll_base, true)) return kInfBadLengths;
+                    if (tables_from_counts(da, db, dc, d_used, d_limit, d_base, true)) return kInfBadLengths;
+                    // back to the first code length
+                    const uint32_t byte = (uint32_t)(lens_at >> 3);
+                    bitbuf = 0, bitcnt = 0, wpos = byte, wr = 0, rd = 0;
+                    MKZ_NEED32();
+                    MKZ_TAKE((uint32_t)lens_at & 7u);
+                }
+                uint32_t i = 0, prev = 0;
                 while (i < hlit + hdist) {
                     MKZ_NEED32();
                     if (MKZ_RAN_OUT()) return kInfTruncated;
-                    const uint32_t e = decode_codeword((uint32_t)bitbuf, ll_sorted, ll_limit, ll_base);
-                    if (e == 0 || (e & 15u) > (uint32_t)kMaxClBits) return kInfBadLengths;
+                    const uint32_t e = cl_decode((uint32_t)bitbuf, clc);
+                    if (e == 0) return kInfBadLengths;
                     MKZ_TAKE(e & 15u);
                     const uint32_t sym = e >> 4;
-                    if (sym < 16) {
-                        lens[i++] = (uint8_t)sym;
-                        continue;
-                    }
-                    uint32_t rep, val = 0;
+                    uint32_t rep = 1, val = sym;
                     if (sym == 16) {
                         if (i == 0) return kInfBadLengths;
-                        val = lens[i - 1];
+                        val = prev;
                         rep = 3 + ((uint32_t)bitbuf & 3u);
                         MKZ_TAKE(2);
                     } else if (sym == 17) {
+                        val = 0;
                         rep = 3 + ((uint32_t)bitbuf & 7u);
                         MKZ_TAKE(3);
-                    } else {
+                    } else if (sym == 18) {
+                        val = 0;
                         rep = 11 + ((uint32_t)bitbuf & 127u);
                         MKZ_TAKE(7);
                     }
                     if (i + rep > hlit + hdist) return kInfBadLengths;
-                    for (; rep; --rep) lens[i++] = (uint8_t)val;
+                    if (val) {  // (rep <= 6 here: runs of a non-zero length come from symbol 16 or are single)
+                        for (uint32_t j = i; j < i + rep; ++j) {
+                            const bool lit = j < hlit;
+                            const uint32_t symbol = lit ? j : j - hlit;
+                            if (pass == 0) {
+                                if (lit) ++ll_used, has_eob = has_eob || symbol == 256;
+                                else ++d_used;
+                            } else if (lit) {
+                                ll_sorted[p15_get(la, lb, lc, val)] = (uint16_t)symbol;
+                            } else {
+                                d_sorted[p15_get(da, db, dc, val)] = (uint16_t)symbol;
+                            }
+                            if (lit) p15_add(la, lb, lc, val, 1);  // (pass 1 counts, pass 2 moves on to the next rank: the same step)
+                            else p15_add(da, db, dc, val, 1);
+                        }
+                    }
+                    prev = val, i += rep;
                 }
-                if (lens[256] == 0) return kInfBadLengths;  // no end-of-block codeword
-                // distance lengths behind the literal ones, each alphabet padded with zeros to its full size
-                uint8_t *const dl = lens + 288;
-                for (int k = (int)hdist - 1; k >= 0; --k) dl[k] = lens[hlit + (uint32_t)k];
-                for (uint32_t k = hdist; k < 32; ++k) dl[k] = 0;
-                for (uint32_t k = hlit; k < 288; ++k) lens[k] = 0;
             }
-            if (build_decode_tables(lens, 288, ll_sorted, ll_limit, ll_base, true)) return kInfBadLengths;
-            // (the fixed distance code is 32 codewords of 5 bits: symbols 30 and 31 complete it and are refused when met)
-            if (build_decode_tables(lens + 288, type == 1 ? 32 : 30, d_sorted, d_limit, d_base, true)) return kInfBadLengths;
         }
         // Symbols of this block.  One token per turn of the loop, and a turn never waits for memory it has just asked
         // for (the 64 lanes of a wave turn together: whatever one of them waits for, all wait for):
