@@ -526,6 +526,28 @@ int mk_extract_window(mk_matcher *m, mk_codec *codec, uint32_t format, uint32_t 
                       uint64_t rec_cap, uint64_t *n_rec, uint8_t *keep, mk_row *rows, uint64_t rows_cap, uint64_t *n_rows, mk_counters *counters,
                       uint32_t *pattern_hit_counts, uint32_t *status);
 
+/* -------------------------------------------------------------------------------------
+ * One gzip member inflated in parallel on the device (v6) -- a .fastq.gz / .fasta.gz as plain gzip (or pigz, or zlib) writes it: ONE
+ * DEFLATE stream of thousands of blocks, which zlib can only walk from the front.  Replaces needletail's gzip reader under
+ * `merkurio extract` (src/cmd_extract.rs:281-282) for such files.  The stream is cut where block starts can be FOUND (a dynamic
+ * block's header is a pattern almost no bit position satisfies; a candidate is confirmed by decoding its block and meeting another
+ * header behind it), the pieces are decoded side by side into 16-bit symbols -- bytes, or place-holders for the text in front of the
+ * piece that a match reached into --, the place-holders are resolved piece by piece, and the text is checked against the member's
+ * CRC-32 and ISIZE (merkurio_amd/csrc/codec/gzip_segments.hpp).
+ * gz[0, n) = the whole member.  *taken = 1: the text lies on the codec's device, *text_bytes long, until the next call or
+ * mk_gzip_text_release; read it with mk_gzip_text_read (host copy of a range) or hand windows of it to mk_extract_window
+ * (mk_window_source::device_text).  *taken = 0: not a file for this path -- several members, a stream without findable block starts
+ * where they are needed, a piece that does not meet its neighbour, an unusually compressible stream the buffers do not hold, a
+ * CRC-32 / ISIZE that does not match --: nothing is reported as an error, the caller inflates the file with zlib (which then also
+ * words what is wrong with a damaged one).
+ * --------------------------------------------------------------------------------------- */
+int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t *text_bytes, uint32_t *taken);
+int mk_gzip_text_read(mk_codec *c, uint64_t offset, uint8_t *out, uint64_t len);
+const void *mk_gzip_text_device(const mk_codec *c, uint64_t *text_bytes);
+int mk_gzip_text_release(mk_codec *c);
+/* pieces of the last mk_gzip_inflate_device and its phases in milliseconds: upload, block search, pieces, resolution, CRC-32 */
+int mk_gzip_info(const mk_codec *c, uint32_t *segments, float ms[5]);
+
 /* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,
  * *consumed = bytes of whole members, *text_bytes = sum of ISIZE.  MK_E_CORRUPT where a header is not BGZF; a trailing
  * partial member is not an error (*consumed < n).  Host code, no device. */

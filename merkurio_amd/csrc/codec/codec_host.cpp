@@ -15,6 +15,7 @@
 #include "../host_common.h"
 #include "codec_internal.h"
 #include "codec_kernels.h"
+#include "gzip_segments.hpp"
 
 namespace mk {
 int hip_fail(hipError_t e, const char *what);
@@ -163,7 +164,7 @@ void mk_codec_destroy(mk_codec *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void *p : {c->d_in, c->d_crc, c->d_tokens, c->d_slots, c->d_len, c->d_off, c->d_out, c->d_aux})
+    for (void *p : {c->d_in, c->d_crc, c->d_tokens, c->d_slots, c->d_len, c->d_off, c->d_out, c->d_aux, c->d_gz_in, c->d_gz_sym, c->d_gz_tab, c->d_gz_ctx, c->d_gz_text})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -318,6 +319,184 @@ int mk_bgzf_members(const uint8_t *in, uint64_t n, mk_bgzf_member *members, uint
     *n_members = k;
     if (consumed) *consumed = at;
     if (text_bytes) *text_bytes = text;
+    return MK_OK;
+}
+
+// ---- one gzip member in parallel pieces (gzip_segments.hpp says how; kernels: gzip_inflate.hip) ---------------------------------
+int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t *text_bytes, uint32_t *taken) {
+    MK_ABI_BEGIN
+    if (!c || !text_bytes || !taken || (n && !gz)) return mk::fail(MK_E_INVALID_ARG, "mk_gzip_inflate_device: NULL argument");
+    *text_bytes = 0, *taken = 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->gz_text_bytes = 0, c->gz_segments = 0;
+    for (float &x : c->gz_ms) x = 0;
+    // RFC 1952: the member's header, then the DEFLATE stream up to the 8 trailer bytes.  One member is what is taken; whether the
+    // stream really ends where the file does shows when the last segment meets its final block there.
+    if (n < 18 + 2 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xE0)) return MK_OK;  // (not gzip / reserved flags: not taken)
+    uint64_t p = 10;
+    if (gz[3] & 4) {
+        if (p + 2 > n) return MK_OK;
+        p += 2 + (gz[p] | (uint64_t)gz[p + 1] << 8);
+    }
+    for (int bit = 3; bit <= 4; ++bit)
+        if (gz[3] & (1 << bit)) {
+            const void *z = p < n ? memchr(gz + p, 0, (size_t)(n - p)) : nullptr;
+            if (!z) return MK_OK;
+            p = (uint64_t)((const uint8_t *)z - gz) + 1;
+        }
+    if (gz[3] & 2) p += 2;
+    if (p + 8 + 2 > n) return MK_OK;
+    const uint64_t n_in = n - 8 - p;
+    uint32_t want_crc, want_isize;
+    memcpy(&want_crc, gz + n - 8, 4), memcpy(&want_isize, gz + n - 4, 4);
+    MKC_HIP(hipSetDevice(c->device), "hipSetDevice");
+    int rc;
+    // nominal chunks of 64 KiB of compressed bytes (a block of zlib's is 15-40 KiB of them): the segments that come out hold one to
+    // a few blocks each.  At most 32 768 chunks (the prefix kernel's grid; a stream of more than 2 GiB gets larger chunks).
+    uint64_t chunk = 64u << 10;
+    while (n_in / chunk > 32768) chunk *= 2;
+    const uint32_t n_chunks = (uint32_t)std::max<uint64_t>(1, n_in / chunk);
+    if ((rc = mk::ensure_device(&c->d_gz_in, &c->gz_in_cap, n_in + mkz::kPad + 16))) return rc;
+    // tables, all 64-bit: starts[n_chunks] | seg_bits[J + 1] | seg_off[J] | seg_cap[J] | n_out[J] | text_off[J] | status (i32) [J] | bad
+    const size_t tab_words = (size_t)n_chunks * 7 + 16;
+    if ((rc = mk::ensure_device(&c->d_gz_tab, &c->gz_tab_cap, tab_words * 8))) return rc;
+    unsigned long long *d_starts = (unsigned long long *)c->d_gz_tab;
+    double t0 = now_ms();
+    if ((rc = upload(c, c->d_gz_in, gz + p, n_in))) return rc;
+    MKC_HIP(hipMemsetAsync((uint8_t *)c->d_gz_in + n_in, 0, mkz::kPad + 16, c->stream), "hipMemsetAsync");
+    MKC_HIP(hipStreamSynchronize(c->stream), "upload of the stream");
+    c->gz_ms[0] = (float)(now_ms() - t0);
+    // ---- block starts
+    t0 = now_ms();
+    std::vector<unsigned long long> starts(n_chunks, ~0ull);
+    mkz::launch_gzip_find((const uint8_t *)c->d_gz_in, n_in, chunk, n_chunks, 3 * chunk, d_starts, c->stream);
+    MKC_HIP(hipGetLastError(), "gzip block search");
+    if (n_chunks > 1) MKC_HIP(hipMemcpyAsync(starts.data() + 1, d_starts + 1, (n_chunks - 1) * 8ull, hipMemcpyDeviceToHost, c->stream), "download of the block starts");
+    MKC_HIP(hipStreamSynchronize(c->stream), "gzip block search");
+    c->gz_ms[1] = (float)(now_ms() - t0);
+    std::vector<unsigned long long> seg_bits{0ull};
+    for (uint32_t k = 1; k < n_chunks; ++k)
+        if (starts[k] != ~0ull && starts[k] > seg_bits.back()) seg_bits.push_back(starts[k]);
+    const uint32_t J = (uint32_t)seg_bits.size();
+    seg_bits.push_back(~0ull);
+    c->gz_segments = J;
+    // ---- segments -> symbols.  Room per segment: 12 x its compressed bytes (FASTQ / FASTA / text: 3-6 x), then 48 x once more
+    std::vector<unsigned long long> seg_off(J), seg_cap(J), n_out(J), text_off(J);
+    std::vector<int32_t> status(J);
+    unsigned long long *d_bits = d_starts + n_chunks, *d_off = d_bits + (J + 1), *d_cap = d_off + J, *d_nout = d_cap + J, *d_toff = d_nout + J;
+    int32_t *d_status = (int32_t *)(d_toff + J);
+    uint32_t *d_bad = (uint32_t *)(d_status + J + (J & 1));
+    uint64_t total = 0;
+    bool done = false;
+    t0 = now_ms();
+    for (uint64_t ratio : {12ull, 48ull}) {
+        uint64_t elems = 0;
+        for (uint32_t j = 0; j < J; ++j) {
+            const uint64_t b0 = seg_bits[j] >> 3, b1 = j + 1 < J ? seg_bits[j + 1] >> 3 : n_in;
+            seg_cap[j] = 65536 + ratio * (b1 - b0 + 1);
+            seg_off[j] = elems;
+            elems += mkz::kSegPrefix + seg_cap[j] + mkz::kSegSlack;
+            elems = (elems + 7) & ~7ull;  // (16-byte aligned buffers)
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && elems * 2 > c->gz_sym_cap && elems * 2 - c->gz_sym_cap > free_b / 2) return MK_OK;  // not taken: too large for this device
+        if ((rc = mk::ensure_device(&c->d_gz_sym, &c->gz_sym_cap, elems * 2 + 64))) return rc;
+        MKC_HIP(hipMemcpyAsync(d_bits, seg_bits.data(), (J + 1) * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the segment table");
+        MKC_HIP(hipMemcpyAsync(d_off, seg_off.data(), J * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the segment table");
+        MKC_HIP(hipMemcpyAsync(d_cap, seg_cap.data(), J * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the segment table");
+        mkz::launch_gzip_segments((const uint8_t *)c->d_gz_in, n_in, d_bits, d_off, d_cap, J, (uint16_t *)c->d_gz_sym, d_nout, d_status, c->num_cus, c->stream);
+        MKC_HIP(hipGetLastError(), "gzip segment decode");
+        MKC_HIP(hipMemcpyAsync(n_out.data(), d_nout, J * 8ull, hipMemcpyDeviceToHost, c->stream), "download");
+        MKC_HIP(hipMemcpyAsync(status.data(), d_status, J * 4ull, hipMemcpyDeviceToHost, c->stream), "download");
+        MKC_HIP(hipStreamSynchronize(c->stream), "gzip segment decode");
+        bool overflow = false, failed = false;
+        for (uint32_t j = 0; j < J; ++j) {
+            overflow = overflow || status[j] == mkz::kSegOverflow;
+            failed = failed || (status[j] != 0 && status[j] != mkz::kSegOverflow);
+        }
+        if (failed) return MK_OK;  // (a segment that does not decode or does not meet its neighbour: zlib will say what this file is)
+        if (!overflow) {
+            done = true;
+            break;
+        }
+    }
+    c->gz_ms[2] = (float)(now_ms() - t0);
+    if (!done) return MK_OK;
+    for (uint32_t j = 0; j < J; ++j) text_off[j] = total, total += n_out[j];
+    if ((uint32_t)total != want_isize) return MK_OK;
+    // ---- contexts, text, CRC-32
+    t0 = now_ms();
+    if ((rc = mk::ensure_device(&c->d_gz_ctx, &c->gz_ctx_cap, (size_t)J * mkz::kSegPrefix + 16))) return rc;
+    if ((rc = mk::ensure_device(&c->d_gz_text, &c->gz_text_cap, total + 64))) return rc;
+    MKC_HIP(hipMemcpyAsync(d_toff, text_off.data(), J * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the text offsets");
+    MKC_HIP(hipMemsetAsync(d_bad, 0, 4, c->stream), "hipMemsetAsync");
+    mkz::launch_gzip_resolve((const uint16_t *)c->d_gz_sym, d_off, d_nout, d_toff, J, (uint8_t *)c->d_gz_ctx, (uint8_t *)c->d_gz_text, d_bad, c->stream);
+    MKC_HIP(hipGetLastError(), "gzip resolution");
+    uint32_t bad = 0;
+    MKC_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream), "download");
+    MKC_HIP(hipStreamSynchronize(c->stream), "gzip resolution");
+    c->gz_ms[3] = (float)(now_ms() - t0);
+    if (bad) return MK_OK;
+    t0 = now_ms();
+    {
+        // CRC-32 of the text: per 65 280-byte block on the device (the BGZF writer's kernel), folded here:
+        // crc(A ++ B) = crc(A) * x^(8 |B|) mod P  ^  crc(B)
+        const uint32_t bb = mkz::kMaxBlockBytes;
+        const uint32_t blocks = (uint32_t)((total + bb - 1) / bb);
+        if ((rc = mk::ensure_device(&c->d_crc, &c->crc_cap, blocks * 4ull + 16))) return rc;
+        mkz::launch_crc((const uint8_t *)c->d_gz_text, total, bb, blocks, (uint32_t *)c->d_crc, c->stream);
+        std::vector<uint32_t> crcs(blocks);
+        MKC_HIP(hipGetLastError(), "CRC kernel");
+        if (blocks) MKC_HIP(hipMemcpyAsync(crcs.data(), c->d_crc, blocks * 4ull, hipMemcpyDeviceToHost, c->stream), "download of the CRCs");
+        MKC_HIP(hipStreamSynchronize(c->stream), "CRC kernel");
+        const uint32_t shift_full = mkz::crc_x_pow_bytes(bb);
+        uint32_t crc = 0;
+        for (uint32_t b = 0; b < blocks; ++b) {
+            const uint64_t len = b + 1 < blocks ? bb : total - (uint64_t)b * bb;
+            crc = mkz::crc_mulmod(crc, len == bb ? shift_full : mkz::crc_x_pow_bytes(len)) ^ crcs[b];
+        }
+        if (crc != want_crc) return MK_OK;
+    }
+    c->gz_ms[4] = (float)(now_ms() - t0);
+    c->gz_text_bytes = total;
+    *text_bytes = total, *taken = 1;
+    return MK_OK;
+    MK_ABI_END
+}
+
+int mk_gzip_text_read(mk_codec *c, uint64_t offset, uint8_t *out, uint64_t len) {
+    MK_ABI_BEGIN
+    if (!c || (len && !out)) return mk::fail(MK_E_INVALID_ARG, "mk_gzip_text_read: NULL argument");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (offset > c->gz_text_bytes || len > c->gz_text_bytes - offset) return mk::fail(MK_E_INVALID_ARG, "mk_gzip_text_read: [%llu, +%llu) is outside the text", (unsigned long long)offset, (unsigned long long)len);
+    MKC_HIP(hipSetDevice(c->device), "hipSetDevice");
+    return download(c, out, (const uint8_t *)c->d_gz_text + offset, len);
+    MK_ABI_END
+}
+
+const void *mk_gzip_text_device(const mk_codec *c, uint64_t *text_bytes) {
+    if (text_bytes) *text_bytes = c ? c->gz_text_bytes : 0;
+    return c && c->gz_text_bytes ? c->d_gz_text : nullptr;
+}
+
+int mk_gzip_text_release(mk_codec *c) {
+    if (!c) return mk::fail(MK_E_INVALID_ARG, "mk_gzip_text_release: NULL handle");
+    std::lock_guard<std::mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    for (void **p : {&c->d_gz_in, &c->d_gz_sym, &c->d_gz_tab, &c->d_gz_ctx, &c->d_gz_text}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->gz_in_cap = c->gz_sym_cap = c->gz_tab_cap = c->gz_ctx_cap = c->gz_text_cap = 0;
+    c->gz_text_bytes = 0;
+    return MK_OK;
+}
+
+int mk_gzip_info(const mk_codec *c, uint32_t *segments, float ms[5]) {
+    if (!c) return mk::fail(MK_E_INVALID_ARG, "mk_gzip_info: NULL handle");
+    if (segments) *segments = c->gz_segments;
+    if (ms)
+        for (int k = 0; k < 5; ++k) ms[k] = c->gz_ms[k];
     return MK_OK;
 }
 

@@ -20,6 +20,13 @@ struct mk_codec {
     // host buffers travel through two page-locked staging buffers, filled / emptied by the host threads beside the DMA (codec_host.cpp)
     void *h_stage[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    // mk_gzip_inflate_device: the compressed stream, the segments' symbols, segment tables, contexts, and the text, which stays
+    // here until the next such call or mk_gzip_text_release
+    void *d_gz_in = nullptr, *d_gz_sym = nullptr, *d_gz_tab = nullptr, *d_gz_ctx = nullptr, *d_gz_text = nullptr;
+    size_t gz_in_cap = 0, gz_sym_cap = 0, gz_tab_cap = 0, gz_ctx_cap = 0, gz_text_cap = 0;
+    uint64_t gz_text_bytes = 0;
+    uint32_t gz_segments = 0;  // of the last call (diagnostic)
+    float gz_ms[5] = {0, 0, 0, 0, 0};  // upload, block search, segments, resolve + translate, CRC
     int inflate_kernel = 0;  // mk_codec_set_inflate_kernel: 0 = chosen per call, 1 = a lane per member, 2 = a wave per member
     float ms[3] = {0, 0, 0};
     uint64_t deflate_pass_blocks = 0, inflate_pass_text = 0;  // mk_codec_set_pass_limits; 0 = the defaults below

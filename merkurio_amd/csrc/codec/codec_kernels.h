@@ -50,4 +50,18 @@ void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uin
                     hipStream_t s, int which = 0);
 void launch_inflate_wave(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s);
 
+// ---- one gzip member inflated in parallel pieces (gzip_inflate.hip, gzip_segments.hpp) ----
+// starts[c] (c = 1 .. n_chunks - 1) = bit position of the first confirmed block start at or behind byte c * chunk_bytes, searched
+// over search_bytes; ~0 = none
+void launch_gzip_find(const uint8_t *in, uint64_t n_in, uint64_t chunk_bytes, uint32_t n_chunks, uint64_t search_bytes, unsigned long long *starts,
+                      hipStream_t s);
+// segment j = bits [seg_bits[j], seg_bits[j + 1]) (the last entry ~0: to the final block) -> 16-bit symbols in sym[seg_off[j] + 32768 ...],
+// at most seg_cap[j] of them; n_out[j], status[j]
+void launch_gzip_segments(const uint8_t *in, uint64_t n_in, const unsigned long long *seg_bits, const unsigned long long *seg_off,
+                          const unsigned long long *seg_cap, uint32_t n_seg, uint16_t *sym, unsigned long long *n_out, int32_t *status, int num_cus,
+                          hipStream_t s);
+// contexts (n_seg x 32 KiB) and the text: text[text_off[j] ...] = segment j's bytes; *bad != 0: a symbol that is neither
+void launch_gzip_resolve(const uint16_t *sym, const unsigned long long *seg_off, const unsigned long long *n_out, const unsigned long long *text_off,
+                         uint32_t n_seg, uint8_t *ctx, uint8_t *text, uint32_t *bad, hipStream_t s);
+
 }  // namespace mkz

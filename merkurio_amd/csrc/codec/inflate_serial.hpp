@@ -71,7 +71,10 @@ MKZ_HD uint32_t bit_reverse32(uint32_t v) {
 // the codeword at the low end of `bits`: symbol << 4 | length, or 0 if no codeword matches
 MKZ_HD uint32_t decode_codeword(uint32_t bits, const uint16_t *sorted, const uint16_t *limit, const uint16_t *base) {
     const uint32_t w = bit_reverse32(bits) >> (32 - kMaxBits);  // the next 15 stream bits, first bit on top
-    const uint32_t *lw = reinterpret_cast<const uint32_t *>(limit);
+    // (the limits are written as 16-bit values and read here two at a time: a type that may alias them, or the compiler is free to
+    // move these loads across the stores that built the table -- which it did once both sat in one function, r05's block search)
+    typedef uint32_t __attribute__((may_alias)) pair_u16;
+    const pair_u16 *lw = reinterpret_cast<const pair_u16 *>(limit);
     uint32_t l = 1;
     for (int k = 0; k < 8; ++k) {  // limits ascend with the length: count those w has reached (limit[0] = 0 stands for the start of l, limit[15] is left out)
         const uint32_t pair = lw[k];

@@ -54,7 +54,7 @@ EXPORTS = [
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_reduce_prepare", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
-    "mk_codec_times", "mk_codec_set_pass_limits", "mk_codec_set_inflate_kernel", "mk_extract_fastq_bgzf", "mk_extract_window",
+    "mk_codec_times", "mk_codec_set_pass_limits", "mk_codec_set_inflate_kernel", "mk_gzip_inflate_device", "mk_gzip_text_read", "mk_gzip_text_device", "mk_gzip_text_release", "mk_gzip_info", "mk_extract_fastq_bgzf", "mk_extract_window",
 ]
 
 
@@ -227,6 +227,12 @@ def load(build_if_missing=True):
     L.mk_codec_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mk_codec_set_pass_limits.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.mk_codec_set_inflate_kernel.argtypes = [C.c_void_p, C.c_int]
+    L.mk_gzip_inflate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.mk_gzip_text_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    L.mk_gzip_text_device.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mk_gzip_text_device.restype = C.c_void_p
+    L.mk_gzip_text_release.argtypes = [C.c_void_p]
+    L.mk_gzip_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     L.mk_extract_fastq_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
                                         C.POINTER(WindowText), C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
@@ -849,6 +855,25 @@ class Codec:
                                      members.size, out.ctypes.data if out.size else None, out.size, C.byref(bad))
         self.last_call_s = time.perf_counter() - t0  # (the C call alone, first touch of the fresh output buffer included)
         _check(rc)
+        return out.tobytes()
+
+    def gunzip(self, gz):
+        """mk_gzip_inflate_device + mk_gzip_text_read: one gzip member inflated in parallel pieces -> bytes, or None when the device
+        did not take the file (the caller's zlib does then).  self.gzip_info = (pieces, ms of upload / search / pieces / resolution / CRC)"""
+        src = np.frombuffer(gz, dtype=np.uint8)
+        n, taken = C.c_uint64(0), C.c_uint32(0)
+        t0 = time.perf_counter()
+        _check(self._L.mk_gzip_inflate_device(self._h, src.ctypes.data if src.size else None, src.size, C.byref(n), C.byref(taken)))
+        self.last_call_s = time.perf_counter() - t0
+        seg, ms = C.c_uint32(0), (C.c_float * 5)()
+        _check(self._L.mk_gzip_info(self._h, C.byref(seg), ms))
+        self.gzip_info = (seg.value, tuple(round(x, 2) for x in ms))
+        if not taken.value:
+            return None
+        out = np.empty(n.value, dtype=np.uint8)
+        t0 = time.perf_counter()
+        _check(self._L.mk_gzip_text_read(self._h, 0, out.ctypes.data if out.size else None, out.size))
+        self.last_read_s = time.perf_counter() - t0
         return out.tobytes()
 
     def set_inflate_kernel(self, which=0):

@@ -310,3 +310,81 @@ def test_reference_gzip_fixture_through_the_device_inflater(codec):
         assert codec.inflate(m) == text
     with pytest.raises(mk.MerkurioError):
         mk.bgzf_members(bytes([0x1f, 0x8b, 8, 4 | 0x20]) + m[4:])
+
+
+# ---- one gzip member inflated in parallel pieces (r05: mk_gzip_inflate_device, codec/gzip_segments.hpp) -----------------------------
+def _fastq_text(n, seed=3):
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        s = "".join(rnd.choice("ACGT") for _ in range(150))
+        q = "".join(rnd.choice("FFFF:,#") for _ in range(150))
+        out.append(f"@read{i} lane={i % 8}\n{s}\n+\n{q}\n")
+    return "".join(out).encode()
+
+
+def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(codec):
+    """tests/data/sample.fasta.gz (the reference's own: one small member, a single piece) and 30 MB of FASTQ as gzip -1 / -6 / -9 wrote
+    it (hundreds of pieces: block starts found on the device, pieces decoded side by side, place-holders resolved): the text zlib gives"""
+    blob = open(os.path.join(GOLDEN, "data/sample.fasta.gz"), "rb").read()
+    assert codec.gunzip(blob) == open(os.path.join(GOLDEN, "data/sample.fasta"), "rb").read()
+    assert codec.gzip_info[0] == 1
+    data = _fastq_text(90_000)
+    for level in (1, 6, 9):
+        gz = gzip.compress(data, level)
+        text = codec.gunzip(gz)
+        assert text is not None, ("not taken", level, codec.gzip_info)
+        assert text == data, level
+        assert codec.gzip_info[0] > 20, codec.gzip_info  # pieces: this is the parallel path, not one lane walking the stream
+    # the text stays on the device: ranges of it
+    n, L = len(data), codec._L
+    for off, ln in ((0, 1), (n - 7, 7), (12345, 1 << 20), (n, 0)):
+        out = np.zeros(max(1, ln), dtype=np.uint8)
+        mk._check(L.mk_gzip_text_read(codec._h, off, out.ctypes.data, ln))
+        assert out[:ln].tobytes() == data[off:off + ln]
+    assert L.mk_gzip_text_read(codec._h, n - 3, out.ctypes.data, 4) == mk.MK_E_INVALID_ARG
+
+
+def test_gunzip_shapes_the_device_takes_or_hands_back(codec):
+    """streams of every block type and of many flush points; what is not for this path comes back as 'not taken' (None) and never as a
+    wrong text: several members, a damaged stream, a stream the buffers do not hold"""
+    rnd = random.Random(8)
+    base = _fastq_text(8000, seed=5)
+    taken = 0
+    for case in range(24):
+        level = rnd.choice([0, 1, 1, 6, 6, 9])
+        strategy = rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 9 if case % 2 else 6, strategy)
+        data = base[:rnd.randrange(200_000, len(base))]
+        parts, at = [], 0
+        while at < len(data):  # flush points: blocks of every size, empty stored blocks between them
+            step = rnd.choice([500, 5000, 70_000, 300_000])
+            parts.append(co.compress(data[at:at + step]))
+            if rnd.random() < 0.4:
+                parts.append(co.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
+            at += step
+        parts.append(co.flush())
+        gz = b"".join(parts)
+        assert zlib.decompress(gz, 31) == data
+        text = codec.gunzip(gz)
+        assert text is None or text == data, (case, level, strategy)
+        taken += text is not None
+    assert taken >= 16, taken  # (most of them: zlib-written streams are what the path is for)
+    data = base[:1_500_000]
+    gz = gzip.compress(data, 6)
+    assert codec.gunzip(gz) == data
+    assert codec.gunzip(gz + gzip.compress(b"second member\n")) is None          # several members: zlib's business
+    for k in range(12):                                                         # damage: never a wrong text
+        bad = bytearray(gz)
+        pos = rnd.randrange(20, len(bad) - 8)
+        bad[pos] ^= 1 << rnd.randrange(8)
+        t = codec.gunzip(bytes(bad))
+        assert t is None, (k, pos)
+    bad = bytearray(gz)
+    bad[-2] ^= 0x10                                                             # ISIZE
+    assert codec.gunzip(bytes(bad)) is None
+    assert codec.gunzip(gz[:len(gz) // 2]) is None                               # truncated
+    assert codec.gunzip(b"not gzip at all, just text\n" * 10) is None
+    zeros = gzip.compress(bytes(50_000_000), 6)                                  # ratio 1000: more than a piece's buffer holds
+    t = codec.gunzip(zeros)
+    assert t is None or t == bytes(50_000_000)
