@@ -479,7 +479,8 @@ int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, u
  *
  * A source's window text = head[0, n_head) ++ body, the body being text[0, n_text) (uploaded; fastest from mk_host_alloc memory;
  * mk_upload_text_ahead of the same pointer and size beforehand overlaps the copy with the previous window) or the text of
- * members[0, n_members) of bgzf[0, n_bgzf) (inflated on the device, never uploaded; needs `codec` on the matcher's device).  The
+ * members[0, n_members) of bgzf[0, n_bgzf) (inflated on the device, never uploaded; needs `codec` on the matcher's device), or
+ * device_text[0, n_device_text) (text that is on the device already: a gzip file inflated there by mk_gzip_inflate_device).  The
  * window starts at a record start.  ends_at_record != 0: its end is a record end (the end of the input, or a place the caller
  * chose); == 0: it may end anywhere -- the unfinished record stays behind as the tail.  The head is how a caller hands the
  * previous window's tail back in.
@@ -510,6 +511,8 @@ typedef struct mk_window_source {
     uint64_t n_bgzf;
     const mk_bgzf_member *members; /* out_off = running sum of ISIZE from 0 */
     uint64_t n_members;
+    const void *device_text; /* body that already lies on the matcher's device (a range of mk_gzip_text_device's text), or NULL */
+    uint64_t n_device_text;
     uint32_t ends_at_record;
     uint32_t reserved;
     uint64_t *rec_start; /* room for rec_cap + 1, or NULL */

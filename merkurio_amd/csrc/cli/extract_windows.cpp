@@ -59,6 +59,13 @@ struct Input {
     std::string path;
     FastxStream s;
     bool bgzf_dev = false;  // its members go to the device as they are
+    // a plain gzip file whose ONE member the device has inflated in parallel pieces (mk_gzip_inflate_device): the text lies there,
+    // windows are ranges of it
+    bool gz_dev = false;
+    mk_codec *gz_codec = nullptr;
+    const uint8_t *gz_text = nullptr;
+    uint64_t gz_bytes = 0, gz_next = 0;
+    bool dev_text() const { return bgzf_dev || gz_dev; }  // the host never holds this input's text: tails / kept records come back
     int fd = -1;            // plain file: windows are staged with pread()
     size_t next_member = 0;
     bool exhausted = false;
@@ -76,6 +83,8 @@ struct Side {  // one input's part of a window
     int pin = -1;                 // ... in this page-locked buffer of its input (-1: where the reader left it)
     std::vector<char> own;        // (first window of a compressed input: a copy of its own)
     std::vector<mk_bgzf_member> grp;  // ... or BGZF members
+    const uint8_t *dev_body = nullptr;  // ... or a range of text that lies on the device
+    uint64_t n_dev_body = 0, dev_off = 0;
     bool ends = true;             // the body ends at a record end
     // results
     std::vector<uint64_t> rec_start;
@@ -162,8 +171,16 @@ struct WindowExtract::Impl {
     // the next body of input i into S; first: the window prepare() has read.  staged: page-locked staging + upload ahead are possible
     void next_body(int i, Side &S, uint64_t target, bool staged, mk_matcher *m_ahead) {
         Input &I = in[i];
-        S.body = nullptr, S.n_body = 0, S.pin = -1, S.grp.clear(), S.ends = true;
+        S.body = nullptr, S.n_body = 0, S.pin = -1, S.grp.clear(), S.ends = true, S.dev_body = nullptr, S.n_dev_body = 0;
         if (I.exhausted) return;
+        if (I.gz_dev) {
+            const uint64_t n = std::min<uint64_t>(target, I.gz_bytes - I.gz_next);
+            S.dev_body = I.gz_text + I.gz_next, S.n_dev_body = n, S.dev_off = I.gz_next;
+            I.gz_next += n;
+            I.exhausted = I.gz_next >= I.gz_bytes;
+            S.ends = I.exhausted;
+            return;
+        }
         if (I.bgzf_dev) {
             const WindowSource &ws = I.s.source();
             const size_t nm = ws.n_bgzf_members();
@@ -234,11 +251,11 @@ struct WindowExtract::Impl {
             W->k = k, W->dev = (int)(k % N);
             bool any_body = false;
             for (int i = 0; i < n_in; ++i) {
-                const uint64_t full = in[i].bgzf_dev ? bgzf_target : (k == 0 ? std::min(plain_target, kFirstWindow) : plain_target);
+                const uint64_t full = in[i].dev_text() ? bgzf_target : (k == 0 ? std::min(plain_target, kFirstWindow) : plain_target);
                 // (the previous window's leftovers count against this one: the two files of a pair then advance at the same rate)
                 const uint64_t target = std::max<uint64_t>(1u << 16, full > last_head[i] ? full - last_head[i] : 0);
                 next_body(i, W->side[i], target, k > 0, ms.empty() ? nullptr : ms[W->dev]);
-                any_body = any_body || W->side[i].n_body || !W->side[i].grp.empty();
+                any_body = any_body || W->side[i].n_body || !W->side[i].grp.empty() || W->side[i].n_dev_body;
             }
             bool any_head = false;
             if (chained && k > 0) {  // the tails of window k - 1 are this window's heads
@@ -269,13 +286,13 @@ struct WindowExtract::Impl {
                 // one file has nothing left while the other still holds records: the reference notices at this point, after the common
                 // part (src/cmd_extract.rs:465-468 file 2 ends first; :608-612 file 2 still has records)
                 bool none[2];
-                for (int i = 0; i < 2; ++i) none[i] = W->side[i].head.empty() && !W->side[i].n_body && W->side[i].grp.empty();
+                for (int i = 0; i < 2; ++i) none[i] = W->side[i].head.empty() && !W->side[i].n_body && W->side[i].grp.empty() && !W->side[i].n_dev_body;
                 if (none[0] != none[1]) {
                     W->error = none[1] ? "Error during FASTQ record parsing of second file. Do the two input files contain the same number of records?"
                                        : "The two input files have a different number of records. Please provide valid paired-end read files.";
                     // (what the other file still holds may be nothing but blank lines at its end: the host parser says)
                     Side &S = W->side[none[0] ? 1 : 0];
-                    bool only_blank = S.grp.empty();
+                    bool only_blank = S.grp.empty() && !S.n_dev_body;
                     for (char ch : S.head) only_blank = only_blank && (ch == '\n' || ch == '\r');
                     for (uint64_t q = 0; q < S.n_body && only_blank; ++q) only_blank = S.body[q] == '\n' || S.body[q] == '\r';
                     if (only_blank) W->error.clear(), W->by_host = true;  // an empty window: nothing to do, the job goes on to its end
@@ -300,11 +317,13 @@ struct WindowExtract::Impl {
     // ---- device side -----------------------------------------------------------------------------------------------------------
     // contiguous text of a side on the host: head ++ body (BGZF members inflated by zlib)
     void side_text(int i, Side &S, std::vector<char> &out) {
-        uint64_t body = S.n_body;
+        uint64_t body = S.n_body + S.n_dev_body;
         for (auto &e : S.grp) body += e.isize;
         out.resize(S.head.size() + body);
         if (!S.head.empty()) memcpy(out.data(), S.head.data(), S.head.size());
         if (S.n_body) memcpy(out.data() + S.head.size(), S.body, S.n_body);
+        if (S.n_dev_body)
+            mk_check(mk_gzip_text_read(in[i].gz_codec, S.dev_off, (uint8_t *)out.data() + S.head.size(), S.n_dev_body), "Error reading the inflated text back");
         if (!S.grp.empty())
             inflate_bgzf_members_host(in[i].s.source().file_bytes(), S.grp.data(), S.grp.size(), out.data() + S.head.size(), in[i].path);
     }
@@ -400,12 +419,15 @@ struct WindowExtract::Impl {
                 Q.members = S.grp.data(), Q.n_members = S.grp.size();
                 for (auto &e : S.grp) body += e.isize;
                 any_bgzf = true;
+            } else if (S.n_dev_body) {
+                Q.device_text = S.dev_body, Q.n_device_text = S.n_dev_body;
+                body += S.n_dev_body;
             } else {
                 Q.text = (const uint8_t *)S.body, Q.n_text = S.n_body;
             }
             Q.ends_at_record = S.ends ? 1 : 0;
             cap_text = std::max(cap_text, S.head.size() + body);
-            if (in[i].bgzf_dev) {  // the host never sees this text: what it needs of it comes back
+            if (in[i].dev_text()) {  // the host never sees this text: what it needs of it comes back
                 if (whole_text) {
                     S.text.resize(S.head.size() + body + 16);
                     Q.all = (uint8_t *)S.text.data(), Q.all_cap = S.text.size();
@@ -473,7 +495,7 @@ struct WindowExtract::Impl {
             Side &S = W.side[i];
             S.n_window = src[i].n_window, S.n_used = src[i].n_used;
             S.rec_start.resize(W.n_rec + 1);
-            if (in[i].bgzf_dev) {
+            if (in[i].dev_text()) {
                 S.tail.resize(src[i].n_tail);
                 if (S.layout == Side::PACKED_KEPT) S.text.resize(src[i].n_kept_bytes);
                 if (S.layout == Side::WHOLE) S.text.resize(src[i].n_window);
@@ -699,6 +721,8 @@ WindowExtract::~WindowExtract() {
     if (!g_process_is_ending) {
         for (mk_codec *c : impl->codecs) mk_codec_destroy(c);
         for (int i = 0; i < 2; ++i)
+            if (impl->in[i].gz_codec) mk_codec_destroy(impl->in[i].gz_codec);
+        for (int i = 0; i < 2; ++i)
             for (Pinned &p : impl->in[i].pins) mk_host_free(p.p);
     }
     delete impl;
@@ -756,7 +780,8 @@ bool WindowExtract::prepare(const ExtractArgs &a, const std::vector<int> &devs) 
         if (kind[i] != '@' && kind[i] != '>') return false;  // empty, or not FASTA / FASTQ: the host reader words what it is
     if (J.n_in == 2 && kind[0] != kind[1]) return false;
     J.fastq = kind[0] == '@';
-    J.chained = J.n_in == 2 || J.in[0].bgzf_dev;
+    // (a plain gzip input may become device text once the HIP runtime is up, run(): its windows then end anywhere too)
+    J.chained = J.n_in == 2 || J.in[0].bgzf_dev || (!a.host_codec && J.in[0].s.raw_is_gzip());
     return true;
 }
 
@@ -781,17 +806,54 @@ void WindowExtract::run(const ExtractArgs &a, const Patterns &pats, Loggers &lg,
         if (hipSetDevice(devs[0]) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
             J.bgzf_target = std::min<uint64_t>(J.bgzf_target, std::max<uint64_t>(64ull << 20, (uint64_t)free_b / (6 * (uint64_t)J.n_in)));
     }
+    // a plain gzip input: ONE DEFLATE stream, which zlib walks from the front at 0.5 GB/s -- the device inflates it in parallel
+    // pieces (mk_gzip_inflate_device) and keeps the text; what it does not take (several members, no findable block starts, a
+    // stream the buffers do not hold, a damaged file) stays with the zlib reader, which also words the errors
+    run_threads((size_t)J.n_in, [&](size_t ii) {  // (the two files of a pair side by side: a handle and a stream each)
+        const int i = (int)ii;
+        Input &I = J.in[i];
+        if (a.host_codec || !I.s.raw_is_gzip()) return;
+        mk_check(mk_codec_create(devs[0], &I.gz_codec), "Error setting up the gzip codec");
+        uint64_t text_bytes = 0;
+        uint32_t taken = 0;
+        const double t_gz = PhaseTimer::now();
+        mk_check(mk_gzip_inflate_device(I.gz_codec, I.s.source().file_bytes(), I.s.source().file_size(), &text_bytes, &taken), "Error inflating the input");
+        if (J.timing) {
+            uint32_t seg = 0;
+            float ms5[5] = {0, 0, 0, 0, 0};
+            (void)mk_gzip_info(I.gz_codec, &seg, ms5);
+            fprintf(stderr, "[timing]   gzip input %d on the device: %s, %.3f s (%u pieces; upload %.1f, block search %.1f, pieces %.1f, resolution %.1f, CRC %.1f ms)\n", i,
+                    taken ? "taken" : "NOT taken (zlib reads it)", PhaseTimer::now() - t_gz, seg, ms5[0], ms5[1], ms5[2], ms5[3], ms5[4]);
+        }
+        if (!taken) {
+            mk_codec_destroy(I.gz_codec);
+            I.gz_codec = nullptr;
+            return;
+        }
+        I.gz_dev = true;
+        I.have_first = false;  // (the window zlib had read for prepare() is not needed)
+        I.gz_text = (const uint8_t *)mk_gzip_text_device(I.gz_codec, &I.gz_bytes);
+        I.gz_next = 0;
+        I.exhausted = I.gz_bytes == 0;
+    });
+    bool any_dev_text = false;
+    for (int i = 0; i < J.n_in; ++i) any_dev_text = any_dev_text || J.in[i].dev_text();
+    if (any_dev_text && !any_bgzf) {  // (the same bound as for BGZF windows: the text, its sequences and tables live on the device)
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(devs[0]) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
+            J.bgzf_target = std::min<uint64_t>(J.bgzf_target, std::max<uint64_t>(64ull << 20, (uint64_t)free_b / (6 * (uint64_t)J.n_in)));
+    }
     // page-locked staging buffers per plain / inflated input: one being filled, one per device in flight, one being written out
     for (int i = 0; i < J.n_in; ++i) {
         Input &I = J.in[i];
-        if (I.bgzf_dev) continue;
+        if (I.dev_text()) continue;
         I.pins.resize(N + 1);
     }
     // (page-locking costs ~0.2 ms per MB: the buffers are made on threads of their own, one per input, beside the first window --
     // which goes up from where it lies --, and handed to the reader as they appear)
     std::vector<std::thread> pin_threads;
     for (int i = 0; i < J.n_in; ++i) {
-        if (J.in[i].bgzf_dev) continue;
+        if (J.in[i].dev_text()) continue;
         pin_threads.emplace_back([&J, i] {
             Input &I = J.in[i];
             for (size_t q = 0; q < I.pins.size(); ++q) {

@@ -121,6 +121,7 @@ struct WindowSource {
     // BGZF: the file as stored and its member table, for a caller that inflates on the device (extract's
     // mk_extract_fastq_bgzf path); seek_member() makes member i the next one more_into() inflates
     bool is_bgzf() const { return kind == BGZF; }
+    bool is_gzip() const { return kind == GZIP; }  // one or more plain gzip members: file_bytes() is the file as stored
     const uint8_t *file_bytes() const { return (const uint8_t *)src.p; }
     uint64_t file_size() const { return src.n; }
     size_t n_bgzf_members() const { return members.size(); }
@@ -180,6 +181,7 @@ struct FastxStream {
     bool raw_fastq() const { return fastq; }
     // bgzip'ed input: the caller walks source()'s members itself and sends them to the device as they are
     bool raw_is_bgzf() const { return src.is_bgzf(); }
+    bool raw_is_gzip() const { return src.is_gzip(); }
     const WindowSource &source() const { return src; }
 
    private:

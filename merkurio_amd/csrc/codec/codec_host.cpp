@@ -389,7 +389,11 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
     uint64_t total = 0;
     bool done = false;
     t0 = now_ms();
-    for (uint64_t ratio : {12ull, 48ull}) {
+    // (ISIZE says how much text there is in all -- below 4 GiB of it: the first guess per piece is half as much again as the stream's
+    // own ratio, which spares a 1.27 GB FASTQ two thirds of a 6 GB allocation; a stream of 4 GiB of text or more starts at 12)
+    const uint64_t whole_ratio = n_in ? (uint64_t)want_isize / n_in + 1 : 1;
+    const uint64_t first_ratio = (n_in < (1ull << 29) && want_isize > n_in) ? std::min<uint64_t>(12, whole_ratio + whole_ratio / 2 + 1) : 12;
+    for (uint64_t ratio : {first_ratio, (uint64_t)48}) {
         uint64_t elems = 0;
         for (uint32_t j = 0; j < J; ++j) {
             const uint64_t b0 = seg_bits[j] >> 3, b1 = j + 1 < J ? seg_bits[j + 1] >> 3 : n_in;
@@ -460,6 +464,12 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
     c->gz_ms[4] = (float)(now_ms() - t0);
     c->gz_text_bytes = total;
     *text_bytes = total, *taken = 1;
+    // what is left to keep is the text: the symbols (24 x the compressed bytes) and the contexts go back to the device now
+    for (void **q : {&c->d_gz_sym, &c->d_gz_ctx, &c->d_gz_in}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    c->gz_sym_cap = c->gz_ctx_cap = c->gz_in_cap = 0;
     return MK_OK;
     MK_ABI_END
 }

@@ -345,7 +345,9 @@ int window_assemble(mk_matcher *m, mk_codec *codec, mk_window_source &S, WindowS
             return fail(MK_E_INVALID_ARG, "mk_extract_window: member %llu lies outside its buffer or its text is not in sequence", (unsigned long long)i);
         body += b.isize;
     }
-    if (S.n_text && S.n_members) return fail(MK_E_INVALID_ARG, "mk_extract_window: a source is plain text or BGZF members, not both");
+    if ((S.n_text != 0) + (S.n_members != 0) + (S.n_device_text != 0) > 1)
+        return fail(MK_E_INVALID_ARG, "mk_extract_window: a source's body is plain text, BGZF members or device text -- one of them");
+    body += S.n_device_text;
     W.n_window = S.n_head + body;
     S.n_window = W.n_window;
     if (W.n_window == 0) return MK_OK;
@@ -382,6 +384,8 @@ int window_assemble(mk_matcher *m, mk_codec *codec, mk_window_source &S, WindowS
     if (S.n_head && hipMemcpyAsync(T.d_text, S.head, S.n_head, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "upload of the head failed");
     if (S.n_text && !ahead && hipMemcpyAsync((uint8_t *)T.d_text + S.n_head, S.text, S.n_text, hipMemcpyHostToDevice, st) != hipSuccess)
         return fail(MK_E_HIP, "upload of the text failed");
+    if (S.n_device_text && hipMemcpyAsync((uint8_t *)T.d_text + S.n_head, S.device_text, S.n_device_text, hipMemcpyDefault, st) != hipSuccess)
+        return fail(MK_E_HIP, "copy of the device text failed");
     if (S.n_members) {
         if (!codec) return fail(MK_E_INVALID_ARG, "mk_extract_window: BGZF members need a codec handle");
         if (codec->device != m->device) return fail(MK_E_INVALID_ARG, "mk_extract_window: the codec and the matcher are on different devices");
@@ -662,7 +666,8 @@ int mk_extract_window(mk_matcher *m, mk_codec *codec, uint32_t format, uint32_t 
     for (uint32_t k = 0; k < n_sources; ++k) {
         mk_window_source &S = src[k];
         S.n_window = S.n_used = S.n_tail = S.n_kept_bytes = S.n_rec_seen = 0;
-        if ((S.n_head && !S.head) || (S.n_text && !S.text) || (S.n_members && (!S.bgzf || !S.members)) || (S.kept_cap && !S.kept) ||
+        if ((S.n_head && !S.head) || (S.n_text && !S.text) || (S.n_members && (!S.bgzf || !S.members)) || (S.n_device_text && !S.device_text) ||
+            (S.kept_cap && !S.kept) ||
             (S.all_cap && !S.all) || (S.tail_cap && !S.tail))
             return fail(MK_E_INVALID_ARG, "mk_extract_window: a size without its buffer in source %u", k);
     }

@@ -97,7 +97,7 @@ class WindowText(C.Structure):
 class WindowSource(C.Structure):
     """mk_window_source (include/merkurio_hip.h, v6): one input file's part of a window handed to mk_extract_window"""
     _fields_ = [("head", C.c_void_p), ("n_head", C.c_uint64), ("text", C.c_void_p), ("n_text", C.c_uint64), ("bgzf", C.c_void_p),
-                ("n_bgzf", C.c_uint64), ("members", C.c_void_p), ("n_members", C.c_uint64), ("ends_at_record", C.c_uint32),
+                ("n_bgzf", C.c_uint64), ("members", C.c_void_p), ("n_members", C.c_uint64), ("device_text", C.c_void_p), ("n_device_text", C.c_uint64), ("ends_at_record", C.c_uint32),
                 ("reserved", C.c_uint32), ("rec_start", C.c_void_p), ("tail", C.c_void_p), ("tail_cap", C.c_uint64), ("kept", C.c_void_p),
                 ("kept_cap", C.c_uint64), ("all", C.c_void_p), ("all_cap", C.c_uint64), ("n_window", C.c_uint64), ("n_used", C.c_uint64),
                 ("n_tail", C.c_uint64), ("n_kept_bytes", C.c_uint64), ("n_rec_seen", C.c_uint64)]
@@ -617,6 +617,9 @@ class Matcher:
                 S.bgzf, S.n_bgzf = (blob.ctypes.data if blob.size else None), blob.size
                 S.members, S.n_members = (mem.ctypes.data if len(mem) else None), len(mem)
                 n_body = int(mem["isize"].sum()) if len(mem) else 0
+            elif "device_text" in sd:  # (pointer, bytes): a range of a text that lies on the device (mk_gzip_text_device)
+                S.device_text, S.n_device_text = sd["device_text"]
+                n_body = S.n_device_text
             else:
                 text = np.frombuffer(sd.get("text", b""), dtype=np.uint8)
                 hold.append(text)

@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
         }
         // the next context: the last 32 KiB of everything so far
         if (text.size() >= mkz::kSegPrefix) memcpy(ctx.data(), text.data() + text.size() - mkz::kSegPrefix, mkz::kSegPrefix);
-        else memcpy(ctx.data() + mkz::kSegPrefix - text.size(), text.data(), text.size());
+        else if (!text.empty()) memcpy(ctx.data() + mkz::kSegPrefix - text.size(), text.data(), text.size());
     }
     fwrite(text.data(), 1, text.size(), stdout);
     return 0;

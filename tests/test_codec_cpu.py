@@ -136,3 +136,39 @@ def test_crc_folded_from_pieces(harness, tmp_path):
         for pieces in (1, 2, 64):
             r = subprocess.run([harness, "crc", str(src), str(pieces)], capture_output=True, text=True, check=True)
             assert int(r.stdout, 16) == zlib.crc32(data), (name, pieces)
+
+
+def test_parallel_gunzip_pieces_match_zlib(tmp_path):
+    """merkurio_amd/csrc/codec/gzip_segments.hpp (r05: one gzip member inflated in parallel pieces) run serially the way the kernels of
+    gzip_inflate.hip run it -- block starts searched from nominal cuts by trying every bit position, pieces decoded into 16-bit symbols
+    with place-holders for the 32 KiB in front, contexts resolved piece by piece -- against zlib's text, for gzip levels 1 / 6 / 9,
+    streams with flush points (stored blocks between the dynamic ones), fixed-code and stored-only streams, tiny inputs"""
+    exe = str(tmp_path / "gzip_harness")
+    subprocess.run(["g++", "-std=c++17", *_FLAGS, "-O2", "-Wall", "-I", os.path.join(ROOT, "merkurio_amd/csrc/codec"), "-I", os.path.join(ROOT, "merkurio_amd/csrc"),
+                    "-o", exe, os.path.join(ROOT, "tests/helpers/gzip_harness.cpp")], check=True)
+    rng = random.Random(11)
+    fastq = b"".join(b"@read%d lane=%d\n%s\n+\n%s\n" % (i, i % 8, bytes(rng.choice(b"ACGT") for _ in range(150)),
+                                                          bytes(rng.choice(b"FFFF:,#") for _ in range(150))) for i in range(6000))
+
+    def check(gz, data, chunk, min_pieces):
+        (tmp_path / "t.gz").write_bytes(gz)
+        p = subprocess.run([exe, str(tmp_path / "t.gz"), str(chunk)], capture_output=True)
+        assert p.returncode == 0, p.stderr[-400:]
+        assert p.stdout == data
+        pieces = int(p.stderr.split()[-1])
+        assert pieces >= min_pieces, (pieces, min_pieces)
+
+    import gzip
+    for level in (1, 6, 9):
+        check(gzip.compress(fastq, level), fastq, 20000, 8)
+        check(gzip.compress(fastq, level), fastq, 150000, 2)
+    # flush points: empty stored blocks between dynamic ones; the searcher only believes a dynamic block that is followed by another
+    # block whose header it can check
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = b"".join(co.compress(fastq[i:i + 40000]) + co.flush(zlib.Z_SYNC_FLUSH if (i // 40000) % 2 else zlib.Z_FULL_FLUSH) for i in range(0, len(fastq), 40000)) + co.flush()
+    check(gz, fastq, 15000, 4)
+    for strategy, level in ((zlib.Z_FIXED, 6), (zlib.Z_HUFFMAN_ONLY, 6), (zlib.Z_DEFAULT_STRATEGY, 0), (zlib.Z_RLE, 6)):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+        check(co.compress(fastq) + co.flush(), fastq, 30000, 1)  # (fixed / stored blocks have no findable starts: fewer pieces, same text)
+    for data in (b"", b"A", b"ACGT" * 10, bytes(70000)):
+        check(gzip.compress(data), data, 20000, 1)
