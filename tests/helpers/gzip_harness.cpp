@@ -81,6 +81,6 @@ int main(int argc, char **argv) {
         if (text.size() >= mkz::kSegPrefix) memcpy(ctx.data(), text.data() + text.size() - mkz::kSegPrefix, mkz::kSegPrefix);
         else if (!text.empty()) memcpy(ctx.data() + mkz::kSegPrefix - text.size(), text.data(), text.size());
     }
-    fwrite(text.data(), 1, text.size(), stdout);
+    if (!text.empty()) fwrite(text.data(), 1, text.size(), stdout);
     return 0;
 }
