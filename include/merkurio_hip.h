@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 6
+#define MK_ABI_VERSION 7
 
 /* ---- error codes.  -1..-3 map 1:1 to PatternError (src/pattern_matching.rs:28-36) ---- */
 #define MK_OK 0
@@ -550,6 +550,62 @@ const void *mk_gzip_text_device(const mk_codec *c, uint64_t *text_bytes);
 int mk_gzip_text_release(mk_codec *c);
 /* pieces of the last mk_gzip_inflate_device and its phases in milliseconds: upload, block search, pieces, resolution, CRC-32 */
 int mk_gzip_info(const mk_codec *c, uint32_t *segments, float ms[5]);
+
+/* -------------------------------------------------------------------------------------
+ * `tag` on a window of a BAM file with the records RESIDENT ON THE DEVICE (v7) -- the reader loop, process_record and the writer
+ * of src/cmd_tag.rs:503-615, :387-497, :254-271 for BAM -> BAM: only compressed members cross the host boundary, in both directions.
+ *
+ * The window's text = head[0, n_head) (the unfinished record the previous window ended with; the first window starts behind the
+ * BAM header) ++ the text of members[0, n_members) of bgzf[0, n_bgzf) (out_off = running sum of ISIZE from 0), inflated on the
+ * device and checked (CRC-32, ISIZE: MK_E_CORRUPT).  On the device: the records' block_size chain is indexed (pieces whose starts
+ * are guessed and then proved by every piece's walk landing on the next piece's start: the table is the serial walk's), the 4-bit
+ * sequences become the upper-case ASCII record.sequence() hands the matcher (:395), the scan, the emission order and the per-record
+ * pattern sets run as in mk_tag_records, a record is kept by the rule of :457-467, and every kept record leaves as
+ * block_size' | record | tag 'Z' value NUL -- the value being its distinct matched patterns, ascending, joined by ',' (:484-490)
+ * -- packed back to back and deflated into BGZF members of block_bytes of text (0 = 65280; the last one shorter) in out[0, out_len).
+ * The members inflate to exactly the bytes the CLI's host path writes for these records.
+ * Outputs: n_window (bytes of text), n_rec whole records covering n_used bytes, tail[0, n_tail) = the text behind them (the next
+ * window's head; tail_cap too small: MK_E_CAPACITY, n_tail = the need), n_kept, out_text_bytes (bytes of the kept records as
+ * written), out_len (out_cap too small: MK_E_CAPACITY, out_len = the need).  out == NULL: nothing is written (`tag -s`).
+ * logging != 0 (the reference's -l / -j): counters and pattern_hit_counts as mk_tag_records, rows[0, n_rows) in emission order
+ * (row.rec = index in the window) and, per row, row_name[r] = offset of the record's NUL-terminated name in names[0, n_names_bytes)
+ * (logger.log_fields' record.name(), :412); too small a rows / names buffer: MK_E_CAPACITY with n_rows / n_names_bytes = the need.
+ * *status != 0: this window is not for the device and NOTHING was produced -- the caller's host reader takes it from the window's
+ * first byte (and words the reference's errors): 1 = a record that fails the parser's checks or a chain that could not be proved,
+ * 2 = optional fields that do not parse, 4 = a kept record that already carries the tag (the reference merges a Z value, :470-481,
+ * and refuses other types), 8 = last != 0 and the text ends inside a record.
+ * ms[]: milliseconds of upload, inflate, index, unpack + scan + sets, tag + emit, deflate, download.
+ * --------------------------------------------------------------------------------------- */
+typedef struct mk_bam_window {
+    /* in */
+    const uint8_t *head;
+    uint64_t n_head;
+    const uint8_t *bgzf;
+    uint64_t n_bgzf;
+    const mk_bgzf_member *members;
+    uint64_t n_members;
+    uint32_t last; /* no text follows this window */
+    uint32_t filter_matching, invert;
+    uint8_t tag[2];
+    uint8_t reserved[2];
+    uint32_t block_bytes;
+    uint8_t *tail;
+    uint64_t tail_cap;
+    uint8_t *out;
+    uint64_t out_cap;
+    mk_row *rows;
+    uint64_t rows_cap;
+    uint64_t *row_name; /* room for rows_cap entries */
+    uint8_t *names;
+    uint64_t names_cap;
+    /* out */
+    uint64_t n_window, n_used, n_tail, n_rec, n_kept, out_text_bytes, out_len, n_rows, n_names_bytes;
+    float ms[8];
+} mk_bam_window;
+int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logging, mk_counters *counters, uint32_t *pattern_hit_counts,
+                      uint32_t *status);
+/* Tuning / test hook: bytes of text per piece of the record-chain index (0 = the default, 65536).  Results do not depend on it. */
+int mk_matcher_set_bam_piece(mk_matcher *m, uint32_t piece_bytes);
 
 /* walks the BSIZE chain of in[0, n): fills members[0, cap) (out_off = running sum of ISIZE), *n_members = how many there are,
  * *consumed = bytes of whole members, *text_bytes = sum of ISIZE.  MK_E_CORRUPT where a header is not BGZF; a trailing

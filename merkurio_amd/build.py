@@ -53,6 +53,7 @@ def _units():
     units.append(("sets.o", "sets.hip", []))
     units.append(("build_tables.o", "build_tables.hip", []))
     units.append(("ingest.o", "ingest.hip", []))
+    units.append(("bam.o", "bam.hip", []))
     # the device BGZF codec (v5 of the ABI)
     units.append(("codec_bgzf_deflate.o", "codec/bgzf_deflate.hip", []))
     units.append(("codec_bgzf_inflate.o", "codec/bgzf_inflate.hip", []))

@@ -802,8 +802,17 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     std::vector<mk_counters> dev_c(ms.size());
     std::vector<std::vector<uint32_t>> dev_counts(ms.size(), std::vector<uint32_t>(counts.size(), 0));
     for (auto &x : dev_c) memset(&x, 0, sizeof(x));
+    bool device_done = false;
+    // BAM -> BAM (or no output at all) on one device: the records stay on the device between inflate and deflate
+    // (tag_windows.cpp); false: a window was not for the device and the loop below takes the input from there
+    if (sam.bam_on_bgzf() && (to_bam || a.suppress_output) && !a.host_codec && !a.host_ingest && ms.size() == 1) {
+        if (to_bam) bw.use_device(devs[0]);
+        const uint64_t dev_window = a.window_mb_given ? window_bytes : (512ull << 20);
+        device_done = tag_bam_windows_on_device(a, sam, m, devs[0], lg, pats, in_name, to_bam ? &bw : nullptr, c, counts, dev_window);
+        tm.mark(device_done ? "windows on the device" : "windows on the device (the rest: host reader)");
+    }
     // (the first window is small: nothing can run beside its read; the later, large ones are read beside their predecessors)
-    bool more_windows = sam.fill(std::min<uint64_t>(window_bytes, 128ull << 20));
+    bool more_windows = !device_done && sam.fill(std::min<uint64_t>(window_bytes, 128ull << 20));
     while (more_windows) {
         const size_t n = sam.recs.size();
         tm.mark("window: read (inflate) + index");

@@ -96,4 +96,11 @@ struct WindowExtract {
              std::vector<std::vector<uint32_t>> &dev_counts, PhaseTimer &tm);
 };
 
+// tag_windows.cpp: BAM input whose records stay on the device (mk_tag_bam_window); bw == nullptr: no output (-S).
+// true: the whole input has been processed; false: `sam` has been positioned where the host reader has to carry on.
+struct SamFile;
+struct BamWriter;
+bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *m, int device, Loggers &lg, const Patterns &pats, const std::string &in_name,
+                               BamWriter *bw, mk_counters &c, std::vector<uint32_t> &counts, uint64_t window_bytes);
+
 }  // namespace cli

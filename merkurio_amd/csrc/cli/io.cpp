@@ -1170,6 +1170,17 @@ void SamFile::open(const std::string &path) {
     data = bytes();
 }
 
+void SamFile::seek_bam(size_t member, const char *head, uint64_t n_head) {
+    std::vector<char> b(head, head + n_head);  // (head may point into buf)
+    buf.swap(b);
+    buf_len = n_head;
+    cursor = 0;
+    recs.clear();
+    have_next = false;
+    src.seek_member(member);
+    data = buf.data();
+}
+
 void SamFile::drop_front(uint64_t k) {
     if (src.mapped() || k == 0) return;
     if (k > buf_len) k = buf_len;
@@ -1388,6 +1399,38 @@ void BamWriter::put_encoded(std::vector<uint8_t> &&bytes) {
     if (pieces_bytes >= (run_members + 1) * kBgzfBlock) flush(false);
 }
 
+constexpr size_t kMaxQueuedRuns = 6;
+
+std::vector<uint8_t> BamWriter::take_raw_buffer(size_t min_size) {
+    std::vector<uint8_t> b;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t k = 0; k < free_raw_.size(); ++k)
+            if (free_raw_[k].size() >= min_size || k + 1 == free_raw_.size()) {
+                b = std::move(free_raw_[k]);
+                free_raw_.erase(free_raw_.begin() + k);
+                break;
+            }
+    }
+    if (b.size() < min_size) b.resize(min_size);
+    return b;
+}
+
+void BamWriter::put_members(std::vector<uint8_t> &&buffer, size_t used) {
+    flush(true);
+    Run run;
+    run.raw = true;
+    run.raw_used = used;
+    run.push_back(std::move(buffer));
+    std::unique_lock<std::mutex> lk(mu_);
+    if (failed_) std::rethrow_exception(failed_);
+    if (!writer_.joinable()) writer_ = std::thread([this] { writer_loop(); });
+    cv_.wait(lk, [&] { return queue_.size() < kMaxQueuedRuns; });
+    queue_.push_back(std::move(run));
+    lk.unlock();
+    cv_.notify_all();
+}
+
 // one BGZF member: gzip header with the BC extra field, raw deflate, crc32, isize
 static void bgzf_compress(const uint8_t *in, size_t n, std::vector<uint8_t> &out) {
     out.resize(n + n / 8 + 1024);
@@ -1412,7 +1455,6 @@ static void bgzf_compress(const uint8_t *in, size_t n, std::vector<uint8_t> &out
     out.resize(clen + 26);
 }
 
-constexpr size_t kMaxQueuedRuns = 6;
 
 void BamWriter::writer_loop() {
     for (;;) {
@@ -1427,7 +1469,16 @@ void BamWriter::writer_loop() {
         }
         cv_.notify_all();
         try {
-            if (!failed_) compress_and_write(run);
+            if (run.raw) {
+                const bool ok = failed_ || fwrite(run[0].data(), 1, run.raw_used, f) == run.raw_used;
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    if (free_raw_.size() < 4) free_raw_.push_back(std::move(run[0]));
+                }
+                if (!ok) bail("Error writing BAM file");
+            } else if (!failed_) {
+                compress_and_write(run);
+            }
         } catch (...) {
             std::lock_guard<std::mutex> lk(mu_);
             if (!failed_) failed_ = std::current_exception();

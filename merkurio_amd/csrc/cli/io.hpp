@@ -132,6 +132,7 @@ struct WindowSource {
         src_pos = i;
         src_eof = i >= members.size();
     }
+    size_t next_member() const { return (size_t)src_pos; }  // BGZF: the first member more_into() has not inflated yet
     ~WindowSource();
     WindowSource() = default;
     WindowSource(const WindowSource &) = delete;
@@ -247,6 +248,17 @@ struct SamFile {
     // value of an existing `tag` field: 0 = absent, 1 = Z value in *val, 2 = present with a
     // non-string type (the reference bails: "Invalid tag value format...")
     int find_tag(size_t i, const std::string &tag, std::string *val) const;
+    // BAM input for a caller that keeps the records on the device (run_tag: mk_tag_bam_window takes windows of members as they are
+    // stored).  After open(): the file and its member table (source()), the bytes open() inflated behind the header but has not
+    // turned into records (the first window's head), and the first member it has not touched.  seek_bam() hands the input back to
+    // fill(): the records continue with head[0, n_head) followed by the text of member `member` onwards.
+    bool bam_on_bgzf() const { return is_bam && src.is_bgzf(); }
+    const WindowSource &source() const { return src; }
+    const char *bam_pending(uint64_t *n) const {
+        *n = buf_len > cursor ? buf_len - cursor : 0;
+        return buf.data() + cursor;
+    }
+    void seek_bam(size_t member, const char *head, uint64_t n_head);
 
    private:
     WindowSource src;
@@ -289,6 +301,11 @@ struct BamWriter {
     // slow part of SAM -> BAM and runs on every host thread), then put_encoded() in record order
     void encode_record(const std::string &sam_line, std::vector<uint8_t> &dst) const;
     void put_encoded(std::vector<uint8_t> &&bytes);
+    // complete BGZF members made elsewhere (mk_tag_bam_window: the tagged records deflated on the device): what has been put so
+    // far is closed with a member of its own, then these bytes follow it in the file as they are
+    void put_members(std::vector<uint8_t> &&buffer, size_t used);
+    // a buffer of at least min_size bytes for such members: one the writer thread has written out (its pages are mapped), or a new one
+    std::vector<uint8_t> take_raw_buffer(size_t min_size);
     // an empty buffer for the next slice of encoded records: one the writer thread is done with (its pages are mapped
     // already: a fresh 16 MB vector costs 4 000 page faults), or a new one
     std::vector<uint8_t> take_buffer();
@@ -297,7 +314,10 @@ struct BamWriter {
     size_t run_members = 1536;   // members per run handed to the writer thread (100 MB of text: two rounds of the deflate kernel's waves)
 
    private:
-    using Run = std::vector<std::vector<uint8_t>>;  // a run of whole members, as the pieces it arrived in
+    struct Run : std::vector<std::vector<uint8_t>> {  // a run of whole members, as the pieces it arrived in
+        bool raw = false;                               // the pieces ARE members already (put_members) ...
+        size_t raw_used = 0;                            // ... in the first raw_used bytes of piece 0
+    };
     void put(const void *p, size_t n);
     void flush(bool all);
     void writer_loop();
@@ -314,6 +334,7 @@ struct BamWriter {
     bool closing_ = false, busy_ = false;
     std::exception_ptr failed_;
     std::vector<std::vector<uint8_t>> free_;  // buffers of written runs (guarded by mu_)
+    std::vector<std::vector<uint8_t>> free_raw_;  // buffers of written raw runs, their size kept (guarded by mu_)
 };
 
 }  // namespace cli

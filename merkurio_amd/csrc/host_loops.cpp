@@ -208,8 +208,9 @@ struct DeviceLoop {
         return pattern_sets(n_rec, nullptr, nullptr, 0, &n_found, counts);
     }
 
-    // the distinct patterns of every record (tuples in set order).  found_off == nullptr: only the counts.
-    int pattern_sets(uint64_t n_rec, uint64_t *found_off, uint32_t *found_pat, uint64_t found_cap, uint64_t *n_found, uint32_t *counts) {
+    // the distinct patterns of every record (tuples in set order) as a CSR in the handle's scratch (m->d_aux): *d_off_out[n_rec + 1],
+    // *d_pat_out[*n_found]; want_counts: *d_cnt_out[n_pat] = entries per pattern (BNDMq's pattern_hit_counts).  The stream is idle on return.
+    int pattern_sets_device(uint64_t n_rec, bool want_counts, unsigned long long **d_off_out, uint32_t **d_pat_out, uint32_t **d_cnt_out, uint64_t *n_found) {
         const uint32_t n_pat = m->n_pat;
         // (the set kernels rank run heads and sum tiles in 32 bits, sets.hip)
         if (found >= (1ull << 32)) return fail(MK_E_UNSUPPORTED, "%llu occurrences in one batch: the per-record pattern sets take at most 2^32 - 1", found);
@@ -227,17 +228,30 @@ struct DeviceLoop {
         launch_pattern_sets(m->d_hits, found, n_rec, d_pat, d_off, d_total, d_tile, st);
         unsigned long long total = 0;
         if (hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
-        if (counts) {
+        if (want_counts) {
             if (hipMemsetAsync(d_cnt, 0, cnt_bytes, st) != hipSuccess) return fail(MK_E_HIP, "memset failed");
         }
         if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "pattern-set kernels failed");
         *n_found = total;
-        std::vector<uint32_t> v;
-        if (counts && total) {
+        if (want_counts && total) {
             launch_count_u32(d_pat, total, d_cnt, n_pat, st);
             if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "count kernel failed");
-            v.resize(n_pat);
         }
+        *d_off_out = d_off, *d_pat_out = d_pat, *d_cnt_out = d_cnt;
+        return MK_OK;
+    }
+
+    // the same, copied to the host.  found_off == nullptr: only the counts.
+    int pattern_sets(uint64_t n_rec, uint64_t *found_off, uint32_t *found_pat, uint64_t found_cap, uint64_t *n_found, uint32_t *counts) {
+        const uint32_t n_pat = m->n_pat;
+        const size_t off_bytes = (n_rec + 1) * 8;
+        unsigned long long *d_off = nullptr;
+        uint32_t *d_pat = nullptr, *d_cnt = nullptr;
+        int rc = pattern_sets_device(n_rec, counts != nullptr, &d_off, &d_pat, &d_cnt, n_found);
+        if (rc) return rc;
+        const uint64_t total = *n_found;
+        std::vector<uint32_t> v;
+        if (counts && total) v.resize(n_pat);
         mark(2);
         if (found_off && hipMemcpy(found_off, d_off, off_bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the set offsets failed");
         const uint64_t n_copy = std::min<uint64_t>(total, found_pat ? found_cap : 0);
@@ -879,6 +893,339 @@ int mk_extract_fastq_bgzf(mk_matcher *m, mk_codec *codec, const uint8_t *head, u
     // (v5 contract: a window without one whole record is the caller's reader's business -- unless nothing follows it)
     if (rc == MK_OK && !*status && S.n_window && S.n_used == 0) *status = last ? 0u : 1u;
     return rc;
+}
+
+// ---- `tag` on a window of BAM text that stays on the device (r05, ABI v7; kernels: bam.hip) ---------------------------------------
+}  // extern "C"
+
+namespace mk {
+void launch_bam_find(const uint8_t *d_text, uint64_t n, uint32_t piece, uint32_t n_pieces, uint32_t *d_start, hipStream_t st);
+void launch_bam_walk_count(const uint8_t *d_text, uint64_t n, uint32_t piece, uint32_t n_pieces, const uint32_t *d_start, uint32_t *d_land,
+                           uint32_t *d_count, hipStream_t st);
+void launch_bam_walk_emit(const uint8_t *d_text, uint64_t n, uint32_t piece, uint32_t n_pieces, const uint32_t *d_start, const uint32_t *d_base,
+                          uint32_t *d_rec_off, uint32_t *d_rec_len, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_st, hipStream_t st);
+void launch_bam_unpack(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off, uint32_t fixed_len,
+                       uint64_t n_rec, uint8_t *d_seq, hipStream_t st);
+void launch_bam_taglen(const uint8_t *d_text, const uint32_t *d_rec_off, const uint32_t *d_rec_len, const uint32_t *d_seq_start, const uint32_t *d_seq_len,
+                       const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint32_t *d_pat_off, uint64_t n_rec, uint32_t filter_matching,
+                       uint32_t invert, uint32_t tag0, uint32_t tag1, uint8_t *d_keep, uint32_t *d_out_len, uint32_t *d_st, hipStream_t st);
+void launch_bam_emit(const uint8_t *d_text, const uint32_t *d_rec_off, const uint32_t *d_rec_len, const uint32_t *d_out_len, const unsigned long long *d_out_off,
+                     const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint8_t *d_pat_bytes, const uint32_t *d_pat_off, uint64_t n_rec,
+                     uint32_t tag0, uint32_t tag1, uint8_t *d_out, hipStream_t st);
+void launch_bam_names(const uint8_t *d_text, const uint32_t *d_rec_off, const uint8_t *d_flags, uint64_t n_rec, uint32_t *d_name_start, uint32_t *d_name_len,
+                      hipStream_t st);
+}  // namespace mk
+
+namespace {
+
+constexpr int kBamProofRounds = 8;  // walks of the record chain before a window is left to the host reader
+
+// the record chain of text[0, n) -> W's tables (d_rec_start = record offsets, d_seq_start, d_seq_len; rec_len behind them):
+// *n_rec records covering *n_used bytes; *fixed > 0: every sequence has this length.  *status |= 1: not for the device.
+int bam_index(mk_matcher *m, WindowSide &W, hipStream_t st, uint64_t *n_rec, uint64_t *n_used, uint32_t **d_rec_len, uint32_t *fixed, uint32_t *status) {
+    mk_matcher::TextSlot &T = *W.T;
+    const uint64_t n = W.n_window;
+    const uint8_t *d_text = (const uint8_t *)T.d_text;
+    const uint32_t piece = m->bam_piece ? m->bam_piece : 65536u;
+    const uint32_t n_pieces = (uint32_t)((n + piece - 1) / piece);
+    int rc;
+    // d_ing_a: start | land | count | base (u32 per piece each) | st[4]
+    if ((rc = ensure_device(&T.d_ing_a, &T.d_ing_a_cap, ((size_t)n_pieces * 4 + 8) * 4))) return rc;
+    uint32_t *d_start = (uint32_t *)T.d_ing_a, *d_land = d_start + n_pieces, *d_count = d_land + n_pieces, *d_base = d_count + n_pieces,
+             *d_st = d_base + n_pieces;
+    launch_bam_find(d_text, n, piece, n_pieces, d_start, st);
+    std::vector<uint32_t> start(n_pieces), land(n_pieces), count(n_pieces);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(start.data(), d_start, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return fail(MK_E_HIP, "BAM record search failed");
+    bool proved = false;
+    std::vector<uint8_t> valid(n_pieces);
+    for (int round = 0; round < kBamProofRounds && !proved; ++round) {
+        launch_bam_walk_count(d_text, n, piece, n_pieces, d_start, d_land, d_count, st);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(land.data(), d_land, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(count.data(), d_count, (size_t)n_pieces * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "BAM record walk failed");
+        // Piece 0 starts at a record start (the caller's contract); a walk that lands on the next piece's start makes that one too.
+        // One pass from the left: a start that is not met is replaced by the landing -- which is right, because everything to its
+        // left is -- and its own landing is then unknown (valid = 0) until the next walk, unless the new start lies behind the
+        // piece altogether (a record longer than a piece: nothing starts in it, the walk is the identity).
+        std::fill(valid.begin(), valid.end(), 1);
+        proved = true;
+        for (uint32_t p = 0; p < n_pieces; ++p) {
+            if (!valid[p]) {
+                const uint64_t stop = p + 1 < n_pieces ? (uint64_t)(p + 1) * piece : n;
+                if (start[p] != 0xFFFFFFFFu && start[p] >= stop) {
+                    land[p] = start[p], count[p] = 0, valid[p] = 1;
+                } else {
+                    proved = false;
+                    continue;
+                }
+            }
+            if (count[p] & 0x80000000u) {  // the text ends inside the record at land[p]: nothing whole follows it
+                for (uint32_t q = p + 1; q < n_pieces; ++q) start[q] = land[q] = land[p], count[q] = 0;
+                break;
+            }
+            if (p + 1 < n_pieces && land[p] != 0xFFFFFFFFu && start[p + 1] != land[p]) {
+                start[p + 1] = land[p];
+                valid[p + 1] = 0;
+            }
+        }
+        if (hipMemcpyAsync(d_start, start.data(), (size_t)n_pieces * 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
+    }
+    for (uint32_t p = 0; p < n_pieces; ++p) proved = proved && start[p] != 0xFFFFFFFFu;
+    if (!proved) {
+        *status |= 1;
+        return MK_OK;
+    }
+    std::vector<uint32_t> base(n_pieces);
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < n_pieces; ++p) {
+        base[p] = (uint32_t)total;
+        total += count[p] & 0x7FFFFFFFu;
+    }
+    *n_rec = total;
+    *n_used = n_pieces ? land[n_pieces - 1] : 0;
+    if (total >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "%llu records in one BAM window", (unsigned long long)total);
+    // tables: record offsets | sequence starts | sequence lengths | record lengths | out lengths (u32, n + 2 each) | out offsets (u64) | tiles (u64)
+    const size_t n_tiles = total / ingest_scan_tile() + 2;
+    if ((rc = ensure_device(&T.d_ing_b, &T.d_ing_b_cap, 5 * (total + 2) * 4 + 16 + (total + 2) * 8 + n_tiles * 8 + 64))) return rc;
+    W.d_rec_start = (uint32_t *)T.d_ing_b;
+    W.d_seq_start = W.d_rec_start + total + 2;
+    W.d_seq_len = W.d_seq_start + total + 2;
+    *d_rec_len = W.d_seq_len + total + 2;
+    const uint32_t st_init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
+    if (hipMemcpyAsync(d_base, base.data(), (size_t)n_pieces * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_st, st_init, sizeof(st_init), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(MK_E_HIP, "copy failed");
+    launch_bam_walk_emit(d_text, n, piece, n_pieces, d_start, d_base, W.d_rec_start, *d_rec_len, W.d_seq_start, W.d_seq_len, d_st, st);
+    uint32_t st_host[4] = {0, 0, 0, 0};
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(st_host, d_st, sizeof(st_host), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "BAM record indexing failed");
+    if (st_host[0]) *status |= 1;  // a record the serial parser refuses ("truncated file"): the host reader words it
+    *fixed = (total && st_host[1] == st_host[2] && st_host[1] > 0) ? st_host[1] : 0;
+    W.d_st = d_st;
+    return MK_OK;
+}
+
+double ms_since(std::chrono::steady_clock::time_point &t) {
+    const auto now = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - t).count();
+    t = now;
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mk_matcher_set_bam_piece(mk_matcher *m, uint32_t piece_bytes) {
+    if (!m || (piece_bytes && piece_bytes < 64)) return fail(MK_E_INVALID_ARG, "mk_matcher_set_bam_piece: handle / a piece of at least 64 bytes");
+    m->bam_piece = piece_bytes;
+    return MK_OK;
+}
+
+int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logging, mk_counters *c, uint32_t *counts, uint32_t *status) {
+    if (!m || !codec || !w || !c || !status || (logging && !counts)) return fail(MK_E_INVALID_ARG, "null argument");
+    if ((w->n_head && !w->head) || (w->n_members && (!w->bgzf || !w->members)) || (w->tail_cap && !w->tail) || (w->out_cap && !w->out) ||
+        (logging && w->rows_cap && (!w->rows || !w->row_name)) || (w->names_cap && !w->names))
+        return fail(MK_E_INVALID_ARG, "mk_tag_bam_window: a size without its buffer");
+    const uint32_t bb = w->block_bytes ? w->block_bytes : mkz::kMaxBlockBytes;
+    if (bb > mkz::kMaxBlockBytes) return fail(MK_E_INVALID_ARG, "mk_tag_bam_window: block_bytes %u > %u", bb, mkz::kMaxBlockBytes);
+    w->n_window = w->n_used = w->n_tail = w->n_rec = w->n_kept = w->out_text_bytes = w->out_len = w->n_rows = w->n_names_bytes = 0;
+    for (float &x : w->ms) x = 0;
+    *status = 0;
+    MK_ABI_BEGIN
+    if (hipSetDevice(m->device) != hipSuccess) return fail(MK_E_HIP, "hipSetDevice failed");
+    DeviceLoop dl(m);
+    hipStream_t st = dl.st;
+    int rc;
+    auto t = std::chrono::steady_clock::now();
+    // ---- the text: head, then the members inflated behind it (window_assemble: upload, inflate, CRC-32 / ISIZE of every member)
+    WindowSide W;
+    W.T = &m->txt[0];
+    mk_window_source S;
+    memset(&S, 0, sizeof(S));
+    S.head = w->head, S.n_head = w->n_head, S.bgzf = w->bgzf, S.n_bgzf = w->n_bgzf, S.members = w->members, S.n_members = w->n_members;
+    if ((rc = window_assemble(m, codec, S, W, dl))) return rc;
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "upload of the window failed");
+    w->ms[1] = (float)ms_since(t);  // (upload + inflate: batch_ms splits them)
+    w->ms[0] = m->batch_ms[0];
+    w->ms[1] -= w->ms[0];
+    w->n_window = W.n_window;
+    const uint64_t n_text = W.n_window;
+    if (n_text == 0) return MK_OK;
+    // ---- the record chain
+    uint64_t n = 0, n_used = 0;
+    uint32_t *d_rec_len = nullptr, fixed = 0;
+    if ((rc = bam_index(m, W, st, &n, &n_used, &d_rec_len, &fixed, status))) return rc;
+    if (*status) return MK_OK;
+    if (w->last && n_used != n_text) {  // the file ends inside a record
+        *status = 8;
+        return MK_OK;
+    }
+    w->n_rec = n, w->n_used = n_used, w->n_tail = n_text - n_used;
+    if (w->n_tail > w->tail_cap) return fail(MK_E_CAPACITY, "mk_tag_bam_window: the text behind the window's records takes %llu bytes", (unsigned long long)w->n_tail);
+    if (w->n_tail && hipMemcpyAsync(w->tail, (const uint8_t *)W.T->d_text + n_used, w->n_tail, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return fail(MK_E_HIP, "download of the tail failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "download of the tail failed");
+    w->ms[2] = (float)ms_since(t);
+    if (n == 0) return MK_OK;
+    uint32_t *d_out_len = d_rec_len + n + 2;
+    unsigned long long *d_out_off = (unsigned long long *)(((uintptr_t)(d_out_len + n + 2) + 15) & ~(uintptr_t)15);
+    unsigned long long *d_tile = d_out_off + n + 2;
+    // ---- sequences -> the scan buffer, scan, emission order, pattern sets
+    unsigned long long n_seq = (unsigned long long)n * fixed;
+    if ((rc = ensure_device((void **)&m->d_flags, &m->d_flags_cap, n + 8)) || (rc = ensure_device((void **)&m->d_off, &m->d_off_cap, (n + 1) * sizeof(uint64_t))))
+        return rc;
+    if (!fixed) {
+        launch_ingest_offsets(W.d_seq_len, n, d_tile, (unsigned long long *)m->d_off, st);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&n_seq, m->d_off + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "offset scan failed");
+    }
+    if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, n_seq + 64))) return rc;
+    launch_bam_unpack((const uint8_t *)W.T->d_text, W.d_seq_start, W.d_seq_len, (const unsigned long long *)m->d_off, fixed, n, m->d_seq, st);
+    if (hipGetLastError() != hipSuccess) return fail(MK_E_HIP, "sequence unpacking failed to launch");
+    m->ragged = !fixed;
+    std::vector<uint8_t> flags(n);
+    uint64_t flagged = 0;
+    const bool ac = m->algo == MK_ALGO_AC;
+    if (n_seq == 0) {
+        dl.found = 0;
+        if (hipMemsetAsync(m->d_flags, 0, n, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
+    } else if ((rc = dl.scan_resident(n_seq, n, MK_MODE_HITS, fixed, flags.data(), &flagged))) {
+        return rc;
+    }
+    bool set_order = false;
+    uint64_t n_rows = 0;
+    // (counters of this window: added to the caller's only when the window is done -- a refused or repeated window counts nothing)
+    mk_counters lc;
+    memset(&lc, 0, sizeof(lc));
+    std::vector<uint32_t> lcounts(logging ? m->n_pat : 0, 0);
+    if (logging) {  // src/cmd_tag.rs:400-416, :443-451
+        lc.nb_hits_tot[0] = dl.found;
+        lc.nb_records_tot = n;
+        lc.nb_bases = n_seq;
+        lc.nb_records_hit[0] = flagged;
+        n_rows = dl.found;
+        if ((rc = dl.order(ac))) return rc;
+        if ((rc = dl.rows_to_host(0, w->rows, w->rows_cap))) return rc;
+        set_order = !ac;
+        if (ac && (rc = dl.pattern_counts(true, n, lcounts.data()))) return rc;
+        // the names of the records with a hit, NUL-terminated, in record order; a row finds its record's by a walk along both
+        if (flagged) {
+            uint32_t *d_name_start = d_out_len, *d_name_len = (uint32_t *)d_out_off;  // (free until the tag step)
+            unsigned long long *d_name_off = (unsigned long long *)m->d_off;          // (the scan is done with the sequence offsets)
+            unsigned long long total = 0;
+            launch_bam_names((const uint8_t *)W.T->d_text, W.d_rec_start, m->d_flags, n, d_name_start, d_name_len, st);
+            launch_ingest_offsets(d_name_len, n, d_tile, d_name_off, st);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, d_name_off + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return fail(MK_E_HIP, "selection of the names failed");
+            w->n_names_bytes = total;
+            if (total <= w->names_cap && n_rows <= w->rows_cap) {
+                // (the unpacked sequences have been scanned: their buffer holds the names now)
+                if ((rc = ensure_device((void **)&m->d_seq, &m->d_seq_cap, total + 64))) return rc;
+                launch_ingest_gather((const uint8_t *)W.T->d_text, d_name_start, d_name_len, d_name_off, 0, n, m->d_seq, st);
+                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(w->names, m->d_seq, total, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return fail(MK_E_HIP, "download of the names failed");
+                // rows are in record order (both emission orders are record-major): r = the flagged record whose name starts at `at`
+                uint64_t r = 0, at = 0;
+                while (r < n && !flags[r]) ++r;
+                for (uint64_t k = 0; k < n_rows; ++k) {
+                    const uint64_t rec = w->rows[k].rec;
+                    while (r < rec && at < total) {
+                        at += strlen((const char *)w->names + at) + 1;
+                        ++r;
+                        while (r < n && !flags[r]) ++r;
+                    }
+                    w->row_name[k] = at;
+                }
+            }
+        }
+    }
+    w->n_rows = n_rows;
+    if (!set_order && (rc = dl.order(false))) return rc;
+    unsigned long long *d_found_off = nullptr;
+    uint32_t *d_found_pat = nullptr, *d_cnt = nullptr;
+    uint64_t n_found = 0;
+    if ((rc = dl.pattern_sets_device(n, logging && !ac, &d_found_off, &d_found_pat, &d_cnt, &n_found))) return rc;
+    if (logging && !ac && n_found) {  // BNDMq: one count per record and pattern (:431-433)
+        if (hipMemcpy(lcounts.data(), d_cnt, (size_t)m->n_pat * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(MK_E_HIP, "copy of the counts failed");
+    }
+    w->ms[3] = (float)ms_since(t);
+    // ---- keep, tag, pack
+    if ((rc = ensure_device((void **)&m->d_flags2, &m->d_flags2_cap, n + 8))) return rc;
+    if (hipMemsetAsync(W.d_st, 0, 4, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
+    launch_bam_taglen((const uint8_t *)W.T->d_text, W.d_rec_start, d_rec_len, W.d_seq_start, W.d_seq_len, d_found_off, d_found_pat, m->d_pat_off, n,
+                      w->filter_matching != 0, w->invert != 0, w->tag[0], w->tag[1], m->d_flags2, d_out_len, W.d_st, st);
+    launch_ingest_offsets(d_out_len, n, d_tile, d_out_off, st);
+    unsigned long long out_text = 0;
+    uint32_t st_tag = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&out_text, d_out_off + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&st_tag, W.d_st, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(flags.data(), m->d_flags2, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "tag kernels failed");
+    if (st_tag) {  // optional fields the device does not decide about: this window is the host path's
+        *status = st_tag & 6u;
+        return MK_OK;
+    }
+    uint64_t kept = 0;
+    for (uint64_t r = 0; r < n; ++r) kept += flags[r];
+    w->n_kept = kept;
+    lc.nb_records_extracted = kept;
+    w->out_text_bytes = out_text;
+    if (logging && (n_rows > w->rows_cap || w->n_names_bytes > w->names_cap))
+        return fail(MK_E_CAPACITY, "mk_tag_bam_window: %llu rows and %llu bytes of names", (unsigned long long)n_rows, (unsigned long long)w->n_names_bytes);
+    auto commit = [&] {
+        c->nb_records_tot += lc.nb_records_tot, c->nb_bases += lc.nb_bases, c->nb_hits_tot[0] += lc.nb_hits_tot[0];
+        c->nb_records_hit[0] += lc.nb_records_hit[0], c->nb_records_extracted += lc.nb_records_extracted;
+        for (size_t i = 0; i < lcounts.size(); ++i) counts[i] += lcounts[i];
+        dl.finish();
+    };
+    if ((!w->out && !w->out_cap) || out_text == 0) {  // tag -s (the checks have run, nothing is written) / nothing is kept
+        commit();
+        return MK_OK;
+    }
+    mk_matcher::TextSlot &O = m->txt[1];
+    if ((rc = ensure_device(&O.d_text, &O.d_text_cap, out_text + mkz::kPad + 64))) return rc;
+    launch_bam_emit((const uint8_t *)W.T->d_text, W.d_rec_start, d_rec_len, d_out_len, d_out_off, d_found_off, d_found_pat, m->d_pat_bytes, m->d_pat_off, n,
+                    w->tag[0], w->tag[1], (uint8_t *)O.d_text, st);
+    if (hipGetLastError() != hipSuccess || hipMemsetAsync((uint8_t *)O.d_text + out_text, 0, mkz::kPad, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(MK_E_HIP, "record output kernel failed");
+    w->ms[4] = (float)ms_since(t);
+    // ---- BGZF members of the output text (the codec's buffers; its kernels on this stream)
+    {
+        std::lock_guard<std::mutex> lock(codec->mu);
+        const uint64_t blocks64 = (out_text + bb - 1) / bb;
+        if (blocks64 >= 0xFFFFFFFFull) return fail(MK_E_UNSUPPORTED, "mk_tag_bam_window: %llu output members", (unsigned long long)blocks64);
+        const uint32_t blocks = (uint32_t)blocks64;
+        const uint32_t grid = mkz::deflate_grid(blocks, codec->num_cus);
+        if ((rc = ensure_device(&codec->d_crc, &codec->crc_cap, blocks * 4ull)) ||
+            (rc = ensure_device(&codec->d_tokens, &codec->tokens_cap, (uint64_t)grid * mkz::kTokensPerWave * 4)) ||
+            (rc = ensure_device(&codec->d_slots, &codec->slots_cap, (uint64_t)blocks * mkz::kSlotBytes)) ||
+            (rc = ensure_device(&codec->d_len, &codec->len_cap, (blocks + 1) * 4ull)) || (rc = ensure_device(&codec->d_off, &codec->off_cap, (blocks + 2) * 8ull)) ||
+            (rc = ensure_device(&codec->d_out, &codec->out_cap, mk_bgzf_deflate_bound(out_text, bb))))
+            return rc;
+        uint64_t *d_total = (uint64_t *)codec->d_off + blocks;
+        mkz::launch_crc((const uint8_t *)O.d_text, out_text, bb, blocks, (uint32_t *)codec->d_crc, st);
+        mkz::launch_deflate((const uint8_t *)O.d_text, out_text, bb, blocks, (const uint32_t *)codec->d_crc, (uint32_t *)codec->d_tokens, (uint8_t *)codec->d_slots,
+                            (uint32_t *)codec->d_len, (uint32_t *)(d_total + 1), grid, st);
+        mkz::launch_pack((const uint8_t *)codec->d_slots, (const uint32_t *)codec->d_len, (uint64_t *)codec->d_off, d_total, blocks, (uint8_t *)codec->d_out, st);
+        uint64_t total = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "BGZF deflate of the tagged records failed");
+        w->ms[5] = (float)ms_since(t);
+        w->out_len = total;
+        if (total > w->out_cap) return fail(MK_E_CAPACITY, "mk_tag_bam_window: the members take %llu bytes", (unsigned long long)total);
+        if (hipMemcpyAsync(w->out, codec->d_out, total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(MK_E_HIP, "download of the members failed");
+        w->ms[6] = (float)ms_since(t);
+    }
+    commit();
+    return MK_OK;
+    MK_ABI_END
 }
 
 // the pair loop with the rows merged on the host (mates of 2 GiB or more under BNDMq: the device pair order keeps

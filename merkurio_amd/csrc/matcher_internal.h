@@ -81,6 +81,7 @@ struct mk_matcher {
         void *d_text = nullptr, *d_ing_a = nullptr, *d_ing_b = nullptr, *d_fa_seq = nullptr;  // d_fa_seq: FASTA sequences without line ends
         size_t d_text_cap = 0, d_ing_a_cap = 0, d_ing_b_cap = 0, d_fa_seq_cap = 0;
     } txt[2];
+    uint32_t bam_piece = 0;  // mk_tag_bam_window: bytes of text per piece of the record-chain index (0 = 64 KiB; mk_matcher_set_bam_piece)
     uint8_t *d_flags2 = nullptr;  // paired windows: mate 1's flags while mate 2 is scanned; the keep flags the kept records are selected by
     size_t d_flags2_cap = 0;
     // mk_upload_text_ahead: text windows copied on a stream of their own while the current window is processed.  Four

@@ -55,6 +55,7 @@ EXPORTS = [
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
     "mk_codec_times", "mk_codec_set_pass_limits", "mk_codec_set_inflate_kernel", "mk_gzip_inflate_device", "mk_gzip_text_read", "mk_gzip_text_device", "mk_gzip_text_release", "mk_gzip_info", "mk_extract_fastq_bgzf", "mk_extract_window",
+    "mk_tag_bam_window", "mk_matcher_set_bam_piece",
 ]
 
 
@@ -104,6 +105,16 @@ class WindowSource(C.Structure):
 
 
 MK_TEXT_FASTQ, MK_TEXT_FASTA = 0, 1
+
+
+class BamWindow(C.Structure):
+    """mk_bam_window (include/merkurio_hip.h, v7): a window of a BAM file handed to mk_tag_bam_window"""
+    _fields_ = [("head", C.c_void_p), ("n_head", C.c_uint64), ("bgzf", C.c_void_p), ("n_bgzf", C.c_uint64), ("members", C.c_void_p), ("n_members", C.c_uint64),
+                ("last", C.c_uint32), ("filter_matching", C.c_uint32), ("invert", C.c_uint32), ("tag", C.c_uint8 * 2), ("reserved", C.c_uint8 * 2),
+                ("block_bytes", C.c_uint32), ("tail", C.c_void_p), ("tail_cap", C.c_uint64), ("out", C.c_void_p), ("out_cap", C.c_uint64),
+                ("rows", C.c_void_p), ("rows_cap", C.c_uint64), ("row_name", C.c_void_p), ("names", C.c_void_p), ("names_cap", C.c_uint64),
+                ("n_window", C.c_uint64), ("n_used", C.c_uint64), ("n_tail", C.c_uint64), ("n_rec", C.c_uint64), ("n_kept", C.c_uint64),
+                ("out_text_bytes", C.c_uint64), ("out_len", C.c_uint64), ("n_rows", C.c_uint64), ("n_names_bytes", C.c_uint64), ("ms", C.c_float * 8)]
 
 
 class Counters(C.Structure):
@@ -239,6 +250,8 @@ def load(build_if_missing=True):
     L.mk_extract_window.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.mk_matcher_order_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mk_tag_bam_window.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BamWindow), C.c_int, C.POINTER(Counters), C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mk_matcher_set_bam_piece.argtypes = [C.c_void_p, C.c_uint32]
     L.mk_extract_paired.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(Counters), C.c_void_p]
@@ -718,6 +731,54 @@ class Matcher:
         rows = self._rows(call)
         found = [res["fpat"][int(foff[i]):int(foff[i + 1])].tolist() for i in range(n)]
         return keep[:n].astype(bool).tolist(), rows, res["c"].as_dict(res["counts"]), found
+
+    def tag_bam_window(self, codec, head: bytes, blob: bytes, members, last, tag=b"km", logging=True, filter_matching=False, invert=False,
+                       write=True, block_bytes=0, piece_bytes=0):
+        """mk_tag_bam_window: head + the text of `members` (entries of bgzf_members(blob), out_off re-based to 0) as BAM records ->
+        dict(status, n_window, n_used, n_rec, n_kept, tail, out (BGZF members of the tagged kept records), out_text_bytes, rows
+        [(name, rec, pat, pos)], counters, ms)"""
+        mem = members.copy()
+        if len(mem):
+            mem["out_off"] -= mem["out_off"][0]
+        hb, bb = np.frombuffer(head, dtype=np.uint8), np.frombuffer(blob, dtype=np.uint8)
+        n_text = len(head) + (int(mem["isize"].sum()) if len(mem) else 0)
+        _check(load().mk_matcher_set_bam_piece(self._h, piece_bytes))
+        w = BamWindow()
+        w.head, w.n_head, w.bgzf, w.n_bgzf = (hb.ctypes.data if len(hb) else None), len(hb), (bb.ctypes.data if len(bb) else None), len(bb)
+        w.members, w.n_members = (mem.ctypes.data if len(mem) else None), len(mem)
+        w.last, w.filter_matching, w.invert, w.block_bytes = int(bool(last)), int(bool(filter_matching)), int(bool(invert)), block_bytes
+        w.tag[0], w.tag[1] = tag[0], tag[1]
+        tail = np.zeros(max(64, n_text), dtype=np.uint8)
+        w.tail, w.tail_cap = tail.ctypes.data, tail.size
+        out = np.zeros(1 << 16, dtype=np.uint8)
+        rows = np.zeros(4096, dtype=ROW_DTYPE)
+        row_name = np.zeros(4096, dtype=np.uint64)
+        names = np.zeros(1 << 16, dtype=np.uint8)
+        status = C.c_uint32()
+        while True:
+            if write:
+                w.out, w.out_cap = out.ctypes.data, out.size
+            w.rows, w.rows_cap, w.row_name, w.names, w.names_cap = rows.ctypes.data, len(rows), row_name.ctypes.data, names.ctypes.data, names.size
+            c2, k2 = Counters(), np.zeros(len(self.patterns), dtype=np.uint32)
+            rc = load().mk_tag_bam_window(self._h, codec._h, C.byref(w), int(logging), C.byref(c2), k2.ctypes.data, C.byref(status))
+            if rc == MK_E_CAPACITY and (w.n_rows > len(rows) or w.n_names_bytes > names.size or w.out_len > out.size):
+                if w.n_rows > len(rows):
+                    rows, row_name = np.zeros(w.n_rows, dtype=ROW_DTYPE), np.zeros(w.n_rows, dtype=np.uint64)
+                if w.n_names_bytes > names.size:
+                    names = np.zeros(w.n_names_bytes, dtype=np.uint8)
+                if w.out_len > out.size:
+                    out = np.zeros(w.out_len, dtype=np.uint8)
+                continue
+            _check(rc)
+            break
+        nb = names[:w.n_names_bytes].tobytes()
+        out_rows = []
+        if logging and status.value == 0:
+            for k in range(w.n_rows):
+                a = int(row_name[k])
+                out_rows.append((nb[a:nb.index(b"\0", a)], int(rows[k]["rec"]), int(rows[k]["pat"]), int(rows[k]["pos"])))
+        return dict(status=status.value, n_window=w.n_window, n_used=w.n_used, n_rec=w.n_rec, n_kept=w.n_kept, tail=tail[:w.n_tail].tobytes(),
+                    out=out[:w.out_len].tobytes(), out_text_bytes=w.out_text_bytes, rows=out_rows, counters=c2.as_dict(k2), ms=list(w.ms))
 
     def tag_value(self, found, existing=None) -> bytes:
         arr = np.asarray(list(found) + [0], dtype=np.uint32)

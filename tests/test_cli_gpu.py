@@ -687,3 +687,82 @@ def test_windows_of_pairs_fasta_and_several_gpus_equal_the_host_reader(golden, t
         assert open(dd / f"out.{ext}", "rb").read() == open(os.path.join(fx, "extract", f"{gold}.extracted.{ext}"), "rb").read()
         assert log_body(dd / "x.log") == log_body(os.path.join(fx, "extract", f"{gold}.log"))
         check_json(dd / "x.json", os.path.join(fx, "extract", f"{gold}.json"))
+
+
+def _bam_stream(path):
+    """the inflated BAM stream of a file, from its first record on (behind the header text, whose @PG line names the command line)"""
+    import gzip
+    import struct
+    raw = gzip.decompress(open(path, "rb").read())
+    assert raw[:4] == b"BAM\x01"
+    p = 8 + struct.unpack_from("<i", raw, 4)[0]
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 8 + struct.unpack_from("<i", raw, p)[0]
+    return raw[p:]
+
+
+def test_tag_bam_records_resident_on_the_device(tmp_path):
+    """BAM -> BAM keeps the records on the device between inflate and deflate (mk_tag_bam_window, cli/tag_windows.cpp); --host-ingest is
+    the r04 path (host record index, host tag append): the two files must hold the same BAM stream and the same logs -- with and
+    without -m / -v / -S, in small windows with the unfinished record carried over, and where a window is left to the host reader
+    (a kept record that already has the tag; a truncated file, whose error the host reader words)."""
+    import random
+    rnd = random.Random(3)
+    kmers = ["".join(rnd.choice("ACGT") for _ in range(25)) for _ in range(60)]
+    (tmp_path / "k.txt").write_text("\n".join(kmers) + "\n")
+    lines = []
+    for i in range(40000):
+        s = "".join(rnd.choice("ACGT") for _ in range(rnd.choice((90, 100, 151, 33))))
+        if i % 7 == 0:
+            k = rnd.choice(kmers)
+            o = rnd.randrange(len(s) - 25) if len(s) > 25 else 0
+            s = (s[:o] + k + s[o + 25:])[:max(len(s), 25)]
+        extra = "\tNM:i:%d\tRG:Z:g%d" % (i % 5, i % 3) if i % 2 else ""
+        lines.append(f"q{i}_{rnd.randrange(10**6)}\t0\tchr1\t{i + 1}\t60\t{len(s)}M\t*\t0\t0\t{s}\t{'F' * len(s)}{extra}\n")
+    sam = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000000\n" + "".join(lines)
+    (tmp_path / "in.sam").write_text(sam)
+    run(["tag", "-i", str(tmp_path / "in.sam"), "-s", "ZZZZZ", "-t", "zz", "-o", str(tmp_path / "in.bam")])  # a BAM of ~8 MB of records
+    for name, extra in (("all", []), ("m", ["-m"]), ("v", ["-v"])):
+        for window in ([], ["--window-mb", "1"]):
+            tagd = "w" if window else "d"
+            p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / f"{name}_{tagd}.bam"), "-l",
+                                str(tmp_path / f"{name}_{tagd}.log"), "-j", str(tmp_path / f"{name}_{tagd}.json"), *extra, *window], capture_output=True,
+                               env=dict(os.environ, MERKURIO_TIMING="1"))
+            assert p.returncode == 0, p.stderr.decode()
+            assert b"windows on the device:" in p.stderr and b"left to the host reader" not in p.stderr
+            if window:
+                assert int(p.stderr.split(b" windows on the device:")[0].rsplit(b" ", 1)[1]) >= 5
+        run(["tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / f"{name}_h.bam"), "-l", str(tmp_path / f"{name}_h.log"),
+             "-j", str(tmp_path / f"{name}_h.json"), "--host-ingest", *extra])
+        host = _bam_stream(tmp_path / f"{name}_h.bam")
+        assert len(host) > (100_000 if name == "m" else 4_000_000)
+        for tagd in ("d", "w"):
+            assert _bam_stream(tmp_path / f"{name}_{tagd}.bam") == host
+            assert log_body(tmp_path / f"{name}_{tagd}.log") == log_body(tmp_path / f"{name}_h.log")
+            check_json(tmp_path / f"{name}_{tagd}.json", tmp_path / f"{name}_h.json")
+    # -S: no output, logs only
+    run(["tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-S", "-l", str(tmp_path / "s_d.log")])
+    assert log_body(tmp_path / "s_d.log") == log_body(tmp_path / "all_h.log")
+    # tagging the tagged file again with the same tag: the kept records carry it already -> the reference's merge rule, on the host
+    p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-o", str(tmp_path / "again_d.bam")], capture_output=True,
+                       env=dict(os.environ, MERKURIO_TIMING="1"))
+    assert p.returncode == 0 and b"left to the host reader (existing tag)" in p.stderr
+    run(["tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-o", str(tmp_path / "again_h.bam"), "--host-ingest"])
+    assert _bam_stream(tmp_path / "again_d.bam") == _bam_stream(tmp_path / "again_h.bam")
+    # ... in small windows: the first ones on the device (under -m only records with a hit are kept: the first window with one of
+    # them that has the tag hands over), the stream continuous across the hand-over
+    p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-m", "-o", str(tmp_path / "again_m_d.bam"), "--window-mb", "1"],
+                       capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
+    assert p.returncode == 0 and b"left to the host reader (existing tag)" in p.stderr
+    run(["tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-m", "-o", str(tmp_path / "again_m_h.bam"), "--host-ingest"])
+    assert _bam_stream(tmp_path / "again_m_d.bam") == _bam_stream(tmp_path / "again_m_h.bam")
+    # a truncated file: both paths end with the host reader's message
+    raw = open(tmp_path / "in.bam", "rb").read()
+    import gzip
+    text = gzip.decompress(raw)
+    (tmp_path / "cut.bam").write_bytes(_bgzf(text[:len(text) - 11]))
+    for extra in ([], ["--host-ingest"]):
+        p = run(["tag", "-i", str(tmp_path / "cut.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "cut_out.bam"), *extra], check=False)
+        assert p.returncode == 1 and b"truncated file" in p.stderr

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = mk.load()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.mk_abi_version() == 6
+    assert L.mk_abi_version() == 7
 
 
 def test_no_cpu_fallback_without_gpu():

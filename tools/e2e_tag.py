@@ -34,8 +34,13 @@ open(km, "wb").write(b"\n".join(p.tobytes() for p in pats) + b"\n")
 print(f"generated {n} records ({os.path.getsize(sam) / 1e6:.0f} MB SAM) in {time.time() - t0:.1f} s", flush=True)
 binp = os.environ.get("MERKURIO_BIN") or os.path.join(ROOT, "merkurio_amd", "lib", "merkurio")
 bam0, out = os.path.join(tmp, "e2e_in.bam"), os.path.join(tmp, "e2e_out")
-for label, args in (("SAM -> SAM", ["-i", sam, "-o", out + ".sam"]), ("SAM -> BAM", ["-i", sam, "-o", bam0]),
-                    ("BAM -> BAM, -m", ["-i", bam0, "-o", out + ".bam", "-m"]), ("BAM -> BAM", ["-i", bam0, "-o", out + "3.bam"]), ("BAM -> SAM", ["-i", bam0, "-o", out + "2.sam"])):
+# (the input BAM of the BAM rows is written with another tag name: records that already carry `km` take the reference's merge rule,
+# which lives on the host path -- r05: BAM -> BAM keeps the records on the device, --host-ingest is the r04 path)
+for label, args in (("SAM -> SAM", ["-i", sam, "-o", out + ".sam"]), ("SAM -> BAM", ["-i", sam, "-o", bam0, "-t", "zz"]),
+                    ("BAM -> BAM, -m", ["-i", bam0, "-o", out + ".bam", "-m"]), ("BAM -> BAM, -m, --host-ingest", ["-i", bam0, "-o", out + "h.bam", "-m", "--host-ingest"]),
+                    ("BAM -> BAM", ["-i", bam0, "-o", out + "3.bam"]), ("BAM -> BAM, --host-ingest", ["-i", bam0, "-o", out + "3h.bam", "--host-ingest"]),
+                    ("BAM -> BAM (second run)", ["-i", bam0, "-o", out + "3.bam"]),
+                    ("BAM -> SAM", ["-i", bam0, "-o", out + "2.sam"])):
     t0 = time.time()
     subprocess.run([binp, "tag", "-f", km, *args], check=True, env=dict(os.environ, MERKURIO_TIMING="1"))
     dt = time.time() - t0
