@@ -574,7 +574,7 @@ int mk_gzip_info(const mk_codec *c, uint32_t *segments, float ms[5]);
  * first byte (and words the reference's errors): 1 = a record that fails the parser's checks or a chain that could not be proved,
  * 2 = optional fields that do not parse, 4 = a kept record that already carries the tag (the reference merges a Z value, :470-481,
  * and refuses other types), 8 = last != 0 and the text ends inside a record.
- * ms[]: milliseconds of upload, inflate, index, unpack + scan + sets, tag + emit, deflate, download.
+ * ms[]: milliseconds of upload, inflate, index, unpack + scan + sets, tag + emit, deflate, download; ms[7]: of these, growing device buffers.
  * --------------------------------------------------------------------------------------- */
 typedef struct mk_bam_window {
     /* in */
@@ -598,6 +598,11 @@ typedef struct mk_bam_window {
     uint64_t *row_name; /* room for rows_cap entries */
     uint8_t *names;
     uint64_t names_cap;
+    /* optional: called from inside the call as soon as tail[0, n_tail) is known -- right after the record index, before the scan --
+     * so that a caller with a second handle can start the next window (whose head this is) beside the rest of this one.  Not called
+     * when the window is refused by the index (*status 1 or 8) or fails before that point. */
+    void (*on_tail)(void *ctx, const uint8_t *tail, uint64_t n_tail);
+    void *on_tail_ctx;
     /* out */
     uint64_t n_window, n_used, n_tail, n_rec, n_kept, out_text_bytes, out_len, n_rows, n_names_bytes;
     float ms[8];

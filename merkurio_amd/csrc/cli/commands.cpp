@@ -804,11 +804,16 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     for (auto &x : dev_c) memset(&x, 0, sizeof(x));
     bool device_done = false;
     // BAM -> BAM (or no output at all) on one device: the records stay on the device between inflate and deflate
-    // (tag_windows.cpp); false: a window was not for the device and the loop below takes the input from there
+    // (tag_windows.cpp; two windows in flight, each on a handle of its own); false: a window was not for the device and the loop
+    // below takes the input from there
+    mk_matcher *second = nullptr;
     if (sam.bam_on_bgzf() && (to_bam || a.suppress_output) && !a.host_codec && !a.host_ingest && ms.size() == 1) {
         if (to_bam) bw.use_device(devs[0]);
-        const uint64_t dev_window = a.window_mb_given ? window_bytes : (512ull << 20);
-        device_done = tag_bam_windows_on_device(a, sam, m, devs[0], lg, pats, in_name, to_bam ? &bw : nullptr, c, counts, dev_window);
+        const uint64_t dev_window = a.window_mb_given ? window_bytes : (256ull << 20);
+        bool ac2 = false;
+        second = make_matcher(a, pats, &ac2, devs[0]);
+        mk_matcher *both[2] = {m, second};
+        device_done = tag_bam_windows_on_device(a, sam, both, 2, devs[0], lg, pats, in_name, to_bam ? &bw : nullptr, c, counts, dev_window);
         tm.mark(device_done ? "windows on the device" : "windows on the device (the rest: host reader)");
     }
     // (the first window is small: nothing can run beside its read; the later, large ones are read beside their predecessors)
@@ -890,6 +895,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         lg.json.finalize(meta, cj, sum, nullptr);
     }
     release_matchers(ms);
+    if (second) release_matchers({second});
     return 0;
 }
 

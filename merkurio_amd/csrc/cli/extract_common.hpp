@@ -100,7 +100,8 @@ struct WindowExtract {
 // true: the whole input has been processed; false: `sam` has been positioned where the host reader has to carry on.
 struct SamFile;
 struct BamWriter;
-bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *m, int device, Loggers &lg, const Patterns &pats, const std::string &in_name,
-                               BamWriter *bw, mk_counters &c, std::vector<uint32_t> &counts, uint64_t window_bytes);
+// handles[0, n_handles): matchers on `device`; with two of them two windows are in flight.
+bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const *handles, int n_handles, int device, Loggers &lg, const Patterns &pats,
+                               const std::string &in_name, BamWriter *bw, mk_counters &c, std::vector<uint32_t> &counts, uint64_t window_bytes);
 
 }  // namespace cli

@@ -1040,6 +1040,11 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
     hipStream_t st = dl.st;
     int rc;
     auto t = std::chrono::steady_clock::now();
+    g_alloc_ms = 0;
+    struct AllocMs {  // (device buffers grown inside the call: part of the phases above, reported on its own as ms[7])
+        float *out;
+        ~AllocMs() { *out = (float)g_alloc_ms; }
+    } alloc_ms{&w->ms[7]};
     // ---- the text: head, then the members inflated behind it (window_assemble: upload, inflate, CRC-32 / ISIZE of every member)
     WindowSide W;
     W.T = &m->txt[0];
@@ -1068,6 +1073,7 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
     if (w->n_tail && hipMemcpyAsync(w->tail, (const uint8_t *)W.T->d_text + n_used, w->n_tail, hipMemcpyDeviceToHost, st) != hipSuccess)
         return fail(MK_E_HIP, "download of the tail failed");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(MK_E_HIP, "download of the tail failed");
+    if (w->on_tail) w->on_tail(w->on_tail_ctx, w->tail, w->n_tail);
     w->ms[2] = (float)ms_since(t);
     if (n == 0) return MK_OK;
     uint32_t *d_out_len = d_rec_len + n + 2;
@@ -1205,21 +1211,27 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
         if ((rc = ensure_device(&codec->d_crc, &codec->crc_cap, blocks * 4ull)) ||
             (rc = ensure_device(&codec->d_tokens, &codec->tokens_cap, (uint64_t)grid * mkz::kTokensPerWave * 4)) ||
             (rc = ensure_device(&codec->d_slots, &codec->slots_cap, (uint64_t)blocks * mkz::kSlotBytes)) ||
-            (rc = ensure_device(&codec->d_len, &codec->len_cap, (blocks + 1) * 4ull)) || (rc = ensure_device(&codec->d_off, &codec->off_cap, (blocks + 2) * 8ull)) ||
-            (rc = ensure_device(&codec->d_out, &codec->out_cap, mk_bgzf_deflate_bound(out_text, bb))))
+            (rc = ensure_device(&codec->d_len, &codec->len_cap, (blocks + 1) * 4ull)) || (rc = ensure_device(&codec->d_off, &codec->off_cap, (blocks + 2) * 8ull)))
             return rc;
+        // the packed members go where the window's text was: it has been read for the last time by the record output kernel (a buffer
+        // of the output's size less to grow -- growing device buffers is what a job's first windows spend most of their time on)
+        void *d_packed = W.T->d_text;
+        if (W.T->d_text_cap < mk_bgzf_deflate_bound(out_text, bb)) {
+            if ((rc = ensure_device(&codec->d_out, &codec->out_cap, mk_bgzf_deflate_bound(out_text, bb)))) return rc;
+            d_packed = codec->d_out;
+        }
         uint64_t *d_total = (uint64_t *)codec->d_off + blocks;
         mkz::launch_crc((const uint8_t *)O.d_text, out_text, bb, blocks, (uint32_t *)codec->d_crc, st);
         mkz::launch_deflate((const uint8_t *)O.d_text, out_text, bb, blocks, (const uint32_t *)codec->d_crc, (uint32_t *)codec->d_tokens, (uint8_t *)codec->d_slots,
                             (uint32_t *)codec->d_len, (uint32_t *)(d_total + 1), grid, st);
-        mkz::launch_pack((const uint8_t *)codec->d_slots, (const uint32_t *)codec->d_len, (uint64_t *)codec->d_off, d_total, blocks, (uint8_t *)codec->d_out, st);
+        mkz::launch_pack((const uint8_t *)codec->d_slots, (const uint32_t *)codec->d_len, (uint64_t *)codec->d_off, d_total, blocks, (uint8_t *)d_packed, st);
         uint64_t total = 0;
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return fail(MK_E_HIP, "BGZF deflate of the tagged records failed");
         w->ms[5] = (float)ms_since(t);
         w->out_len = total;
         if (total > w->out_cap) return fail(MK_E_CAPACITY, "mk_tag_bam_window: the members take %llu bytes", (unsigned long long)total);
-        if (hipMemcpyAsync(w->out, codec->d_out, total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        if (hipMemcpyAsync(w->out, d_packed, total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return fail(MK_E_HIP, "download of the members failed");
         w->ms[6] = (float)ms_since(t);
     }

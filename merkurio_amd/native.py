@@ -113,6 +113,7 @@ class BamWindow(C.Structure):
                 ("last", C.c_uint32), ("filter_matching", C.c_uint32), ("invert", C.c_uint32), ("tag", C.c_uint8 * 2), ("reserved", C.c_uint8 * 2),
                 ("block_bytes", C.c_uint32), ("tail", C.c_void_p), ("tail_cap", C.c_uint64), ("out", C.c_void_p), ("out_cap", C.c_uint64),
                 ("rows", C.c_void_p), ("rows_cap", C.c_uint64), ("row_name", C.c_void_p), ("names", C.c_void_p), ("names_cap", C.c_uint64),
+                ("on_tail", C.c_void_p), ("on_tail_ctx", C.c_void_p),
                 ("n_window", C.c_uint64), ("n_used", C.c_uint64), ("n_tail", C.c_uint64), ("n_rec", C.c_uint64), ("n_kept", C.c_uint64),
                 ("out_text_bytes", C.c_uint64), ("out_len", C.c_uint64), ("n_rows", C.c_uint64), ("n_names_bytes", C.c_uint64), ("ms", C.c_float * 8)]
 

@@ -731,9 +731,11 @@ def test_tag_bam_records_resident_on_the_device(tmp_path):
                                 str(tmp_path / f"{name}_{tagd}.log"), "-j", str(tmp_path / f"{name}_{tagd}.json"), *extra, *window], capture_output=True,
                                env=dict(os.environ, MERKURIO_TIMING="1"))
             assert p.returncode == 0, p.stderr.decode()
-            assert b"windows on the device:" in p.stderr and b"left to the host reader" not in p.stderr
+            import re
+            done = re.search(rb"\[timing\] (\d+) of (\d+) windows on the device \((\d+) in flight\)", p.stderr)
+            assert done and done.group(1) == done.group(2) and b"left to the host reader" not in p.stderr
             if window:
-                assert int(p.stderr.split(b" windows on the device:")[0].rsplit(b" ", 1)[1]) >= 5
+                assert int(done.group(1)) >= 5 and int(done.group(3)) == 2
         run(["tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / f"{name}_h.bam"), "-l", str(tmp_path / f"{name}_h.log"),
              "-j", str(tmp_path / f"{name}_h.json"), "--host-ingest", *extra])
         host = _bam_stream(tmp_path / f"{name}_h.bam")
