@@ -1401,29 +1401,49 @@ void BamWriter::put_encoded(std::vector<uint8_t> &&bytes) {
 
 constexpr size_t kMaxQueuedRuns = 6;
 
-std::vector<uint8_t> BamWriter::take_raw_buffer(size_t min_size) {
-    std::vector<uint8_t> b;
+void BamWriter::free_raw_buffer(RawBuffer &b) {
+    if (b.p) {
+        if (b.pinned) mk_host_free(b.p);
+        else free(b.p);
+    }
+    b = RawBuffer();
+}
+
+BamWriter::RawBuffer BamWriter::take_raw_buffer(size_t min_size) {
+    RawBuffer b;
     {
         std::lock_guard<std::mutex> lk(mu_);
         for (size_t k = 0; k < free_raw_.size(); ++k)
-            if (free_raw_[k].size() >= min_size || k + 1 == free_raw_.size()) {
-                b = std::move(free_raw_[k]);
+            if (free_raw_[k].cap >= min_size || k + 1 == free_raw_.size()) {
+                b = free_raw_[k];
                 free_raw_.erase(free_raw_.begin() + k);
                 break;
             }
     }
-    if (b.size() < min_size) b.resize(min_size);
+    if (b.cap >= min_size) return b;
+    free_raw_buffer(b);
+    const size_t want = min_size + min_size / 8;
+    void *q = nullptr;
+    if (mk_host_alloc(want, &q) == MK_OK) {
+        b.p = (uint8_t *)q, b.cap = want, b.pinned = true;
+    } else {
+        b.p = (uint8_t *)malloc(want), b.cap = want, b.pinned = false;
+        if (!b.p) bail("Error writing BAM file: out of memory");
+    }
     return b;
 }
 
-void BamWriter::put_members(std::vector<uint8_t> &&buffer, size_t used) {
+void BamWriter::put_members(RawBuffer buffer, size_t used) {
     flush(true);
     Run run;
     run.raw = true;
+    run.raw_buf = buffer;
     run.raw_used = used;
-    run.push_back(std::move(buffer));
     std::unique_lock<std::mutex> lk(mu_);
-    if (failed_) std::rethrow_exception(failed_);
+    if (failed_) {
+        free_raw_buffer(buffer);
+        std::rethrow_exception(failed_);
+    }
     if (!writer_.joinable()) writer_ = std::thread([this] { writer_loop(); });
     cv_.wait(lk, [&] { return queue_.size() < kMaxQueuedRuns; });
     queue_.push_back(std::move(run));
@@ -1470,11 +1490,15 @@ void BamWriter::writer_loop() {
         cv_.notify_all();
         try {
             if (run.raw) {
-                const bool ok = failed_ || fwrite(run[0].data(), 1, run.raw_used, f) == run.raw_used;
+                const bool ok = failed_ || fwrite(run.raw_buf.p, 1, run.raw_used, f) == run.raw_used;
                 {
                     std::lock_guard<std::mutex> lk(mu_);
-                    if (free_raw_.size() < 4) free_raw_.push_back(std::move(run[0]));
+                    if (free_raw_.size() < 4) {
+                        free_raw_.push_back(run.raw_buf);
+                        run.raw_buf = RawBuffer();
+                    }
                 }
+                free_raw_buffer(run.raw_buf);
                 if (!ok) bail("Error writing BAM file");
             } else if (!failed_) {
                 compress_and_write(run);
@@ -1854,6 +1878,8 @@ void BamWriter::close() {
     fclose(f);
     f = nullptr;
     if (codec_) mk_codec_destroy((mk_codec *)codec_), codec_ = nullptr;
+    for (auto &b : free_raw_) free_raw_buffer(b);
+    free_raw_.clear();
     closing_ = false;
     failed_ = nullptr;
     if (err) std::rethrow_exception(err);

@@ -303,9 +303,17 @@ struct BamWriter {
     void put_encoded(std::vector<uint8_t> &&bytes);
     // complete BGZF members made elsewhere (mk_tag_bam_window: the tagged records deflated on the device): what has been put so
     // far is closed with a member of its own, then these bytes follow it in the file as they are
-    void put_members(std::vector<uint8_t> &&buffer, size_t used);
-    // a buffer of at least min_size bytes for such members: one the writer thread has written out (its pages are mapped), or a new one
-    std::vector<uint8_t> take_raw_buffer(size_t min_size);
+    // (the buffer: page-locked memory the device writes into directly -- a fresh pageable buffer costs a page fault per 4 KiB inside
+    // the copy, more than the copy itself --, handed back and forth between the caller and the writer thread)
+    struct RawBuffer {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+        bool pinned = false;
+    };
+    void put_members(RawBuffer buffer, size_t used);
+    // a buffer of at least min_size bytes for such members: one the writer thread has written out, or a new one
+    RawBuffer take_raw_buffer(size_t min_size);
+    static void free_raw_buffer(RawBuffer &b);
     // an empty buffer for the next slice of encoded records: one the writer thread is done with (its pages are mapped
     // already: a fresh 16 MB vector costs 4 000 page faults), or a new one
     std::vector<uint8_t> take_buffer();
@@ -315,8 +323,9 @@ struct BamWriter {
 
    private:
     struct Run : std::vector<std::vector<uint8_t>> {  // a run of whole members, as the pieces it arrived in
-        bool raw = false;                               // the pieces ARE members already (put_members) ...
-        size_t raw_used = 0;                            // ... in the first raw_used bytes of piece 0
+        bool raw = false;                               // the run IS members already (put_members) ...
+        RawBuffer raw_buf;                              // ... in the first raw_used bytes of this buffer
+        size_t raw_used = 0;
     };
     void put(const void *p, size_t n);
     void flush(bool all);
@@ -334,7 +343,7 @@ struct BamWriter {
     bool closing_ = false, busy_ = false;
     std::exception_ptr failed_;
     std::vector<std::vector<uint8_t>> free_;  // buffers of written runs (guarded by mu_)
-    std::vector<std::vector<uint8_t>> free_raw_;  // buffers of written raw runs, their size kept (guarded by mu_)
+    std::vector<RawBuffer> free_raw_;  // buffers of written raw runs (guarded by mu_)
 };
 
 }  // namespace cli

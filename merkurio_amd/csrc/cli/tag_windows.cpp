@@ -134,7 +134,7 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
     const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t)n_handles, std::min<size_t>(2, n_win)));
     double t_dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // (BAM-shaped text deflates to a third; a window that does not fit is done again with the size it asked for)
-    auto out_guess = [](uint64_t text) { return text / 2 + (4u << 20); };
+    auto out_guess = [](uint64_t text) { return text / 3 + (4u << 20); };
 
     auto worker = [&](size_t id) {
         mk_matcher *m = handles[id];
@@ -147,7 +147,12 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
             }
         } guard{codec};
         PinnedBuffer stage;
-        std::vector<uint8_t> tail(1u << 20), names(1u << 16), out;
+        std::vector<uint8_t> tail(1u << 20), names(1u << 16);
+        BamWriter::RawBuffer out;
+        struct OutGuard {
+            BamWriter::RawBuffer &b;
+            ~OutGuard() { BamWriter::free_raw_buffer(b); }
+        } out_guard{out};
         std::vector<mk_row> rows(4096);
         std::vector<uint64_t> row_name(4096);
         for (size_t k = id; k < n_win; k += n_workers) {
@@ -160,7 +165,10 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
                 stage.need(X.file_hi - X.file_lo);
                 copy_in(file, X.file_lo, X.file_hi, stage.p);
             }
-            if (bw && out.size() < out_guess(X.text + (1u << 20))) out = bw->take_raw_buffer(out_guess(X.text + (1u << 20)));
+            if (bw && out.cap < out_guess(X.text + (1u << 20))) {
+                BamWriter::free_raw_buffer(out);
+                out = bw->take_raw_buffer(out_guess(X.text + (1u << 20)));
+            }
             std::vector<uint8_t> head;
             {
                 std::unique_lock<std::mutex> lk(pipe.mu);
@@ -185,13 +193,17 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
                 memset(&wc, 0, sizeof(wc));
                 std::fill(wcounts.begin(), wcounts.end(), 0);
                 w.tail = tail.data(), w.tail_cap = tail.size();
-                w.out = bw ? out.data() : nullptr, w.out_cap = bw ? out.size() : 0;
+                w.out = bw ? out.p : nullptr, w.out_cap = bw ? out.cap : 0;
                 w.rows = rows.data(), w.rows_cap = rows.size(), w.row_name = row_name.data(), w.names = names.data(), w.names_cap = names.size();
                 rc = mk_tag_bam_window(m, codec, &w, lg.active, &wc, wcounts.data(), &status);
                 if (rc != MK_E_CAPACITY) break;
                 bool grew = false;
                 if (w.n_tail > tail.size()) tail.resize(w.n_tail + (1u << 20)), grew = true;
-                if (bw && w.out_len > out.size()) out.resize(w.out_len), grew = true;
+                if (bw && w.out_len > out.cap) {
+                    BamWriter::free_raw_buffer(out);
+                    out = bw->take_raw_buffer(w.out_len);
+                    grew = true;
+                }
                 if (w.n_rows > rows.size()) rows.resize(w.n_rows), row_name.resize(w.n_rows), grew = true;
                 if (w.n_names_bytes > names.size()) names.resize(w.n_names_bytes), grew = true;
                 if (!grew) break;
@@ -239,8 +251,8 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
                         },
                         [&](const mk_row &) -> const std::string & { return in_name; });
                 if (bw && w.out_len) {
-                    bw->put_members(std::move(out), w.out_len);
-                    out = std::vector<uint8_t>();
+                    bw->put_members(out, w.out_len);
+                    out = BamWriter::RawBuffer();
                 }
             } catch (const Error &e) {
                 emit_err = e.what()[0] ? e.what() : "error";

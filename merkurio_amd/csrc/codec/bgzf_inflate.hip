@@ -42,16 +42,26 @@ uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
     return lanes;
 }
 
-// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in ~2 ms and holds four members per
-// CU: its time grows with the members per CU.  A lane per member takes 15-25 ms for its slowest lane whatever the call holds and
-// stays there up to tens of thousands of members.  They cross at ~4 members per CU-slot (64 MB: 6-10 ms against 14-22; 256 MB: 16-26 against 16-24) (profiles/r05_codec_inflate_kernels.txt).
-constexpr uint32_t kWaveRounds = 3;
+// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in 2-6 ms; with the most recent
+// 8 KiB of the member's text in LDS twelve of them fit a CU (3 072 on the part): its time grows with the members per slot.  A lane
+// per member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands of members.
+// zlib level-6 members of BAM records: 64 MB 6.3 against 24.1 ms, 256 MB 14.1 against 23.1, 1 GiB 44.0 against 40.5 -- they cross
+// at ~three rounds of the wave kernel's slots (profiles/r05_codec_real.txt).
+constexpr uint32_t kWaveRounds = 3, kWaveSlotsPerCu = 12;
 
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s, int which) {
     if (!n_members) return;
-    if (which == 2 || (which == 0 && n_members <= (uint32_t)num_cus * 4u * kWaveRounds)) {
+    if (which == 3 || which == 4) {
+        launch_inflate_wave(in, n_in, members, n_members, out, status, s, which == 3 ? 8192u : 16384u);
+        return;
+    }
+    if (which == 2) {
         launch_inflate_wave(in, n_in, members, n_members, out, status, s);
+        return;
+    }
+    if (which == 0 && n_members <= (uint32_t)num_cus * kWaveSlotsPerCu * kWaveRounds) {
+        launch_inflate_wave(in, n_in, members, n_members, out, status, s, 8192u);
         return;
     }
     const uint32_t lanes = inflate_lanes(n_members, num_cus);

@@ -28,10 +28,15 @@ namespace mkz {
 
 namespace {
 
-constexpr uint32_t kRing = 32768, kRingMask = kRing - 1;
 constexpr uint32_t kFlush = 4096;
 constexpr int kFastLl = 10, kFastD = 9;
 
+// kRing bytes of the member's most recent text.  32 KiB hold everything a DEFLATE distance can reach (4 waves per CU).  With a
+// SHORTER ring (r05, second step) the waves per CU go up -- 8 KiB: 12, 16 KiB: 7 -- which is what hides a token turn's chain of
+// dependent LDS accesses; a match that reaches behind the ring reads its source from global memory, where those bytes went with a
+// flush (text that is still in flight, [flushed, op), is always in the ring: kRing >= 2 * kFlush).  In BAM / FASTQ text most
+// matches point at the previous record or two, a few hundred bytes back.
+template <uint32_t kRing>
 struct WaveLds {
     uint8_t ring[kRing];
     uint16_t ll_fast[1 << kFastLl];  // symbol << 4 | length for codewords of <= 10 bits, else 0
@@ -40,7 +45,8 @@ struct WaveLds {
     uint16_t ll_sorted[288], d_sorted[32];
     uint8_t lens[320];  // code lengths of the block being set up: literal / length [0, 288), distance [288, 320)
 };
-static_assert(sizeof(WaveLds) <= 40 * 1024, "four waves per CU");
+static_assert(sizeof(WaveLds<32768>) <= 40 * 1024, "four waves per CU");
+static_assert(sizeof(WaveLds<8192>) <= 13 * 1024, "twelve waves per CU");
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -105,10 +111,13 @@ __device__ void wave_fill_fast(uint16_t *fast, int bits, const uint16_t *sorted,
 
 }  // namespace
 
+template <uint32_t kRing>
 __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t *__restrict__ in_all, uint64_t n_in_all, const Member *__restrict__ members,
                                                                   uint32_t n_members, uint8_t *__restrict__ out_all, int32_t *__restrict__ status_out) {
+    static_assert(kRing >= 2 * kFlush && (kRing & (kRing - 1)) == 0, "ring: a power of two that holds two flush pieces");
+    constexpr uint32_t kRingMask = kRing - 1;
     extern __shared__ uint8_t lds_raw[];
-    WaveLds &S = *reinterpret_cast<WaveLds *>(lds_raw);
+    WaveLds<kRing> &S = *reinterpret_cast<WaveLds<kRing> *>(lds_raw);
     const uint32_t lane = lane_id();
     const uint32_t mi = blockIdx.x;
     if (mi >= n_members) return;
@@ -160,6 +169,8 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t 
             }
             flushed += kFlush;
         }
+        // (a shorter ring reads flushed text back: the stores above must have arrived before such a load is issued)
+        if (kRing < 32768) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     };
 
     for (bool last_block = false; !last_block && status == 0;) {
@@ -346,7 +357,15 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t 
                 }
                 // byte i of the match = byte (i mod distance) of the `distance` bytes in front of it: every source byte exists already
                 const uint32_t src0 = op - dist;
-                if (dist >= len) {
+                if (kRing < 32768 && dist + len > kRing) {
+                    // the source has (partly) left the ring: bytes below `flushed` come back from global memory (past the CU's L1:
+                    // a line may have been cached before its last bytes were stored), the rest is still in the ring
+                    for (uint32_t i = lane; i < len; i += 64) {
+                        const uint32_t p = src0 + i;  // (dist > kRing - 258 > len: no wrap inside the match)
+                        const uint8_t b = p < flushed ? __hip_atomic_load(out + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.ring[p & kRingMask];
+                        S.ring[(op + i) & kRingMask] = b;
+                    }
+                } else if (dist >= len) {
                     for (uint32_t i = lane; i < len; i += 64) S.ring[(op + i) & kRingMask] = S.ring[(src0 + i) & kRingMask];
                 } else {
                     for (uint32_t i = lane; i < len; i += 64) S.ring[(op + i) & kRingMask] = S.ring[(src0 + i % dist) & kRingMask];
@@ -371,14 +390,22 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t 
 #undef MKW_RAN_OUT
 }
 
-void launch_inflate_wave(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s) {
-    if (!n_members) return;
-    static bool raised = false;  // (36 KiB of dynamic LDS: above the default limit of a kernel)
+template <uint32_t kRing>
+static void launch_ring(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s) {
+    static bool raised = false;  // (up to 36 KiB of dynamic LDS)
     if (!raised) {
-        (void)hipFuncSetAttribute((const void *)mk_bgzf_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WaveLds));
+        (void)hipFuncSetAttribute((const void *)mk_bgzf_inflate_wave_kernel<kRing>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WaveLds<kRing>));
         raised = true;
     }
-    hipLaunchKernelGGL(mk_bgzf_inflate_wave_kernel, dim3(n_members), dim3(64), sizeof(WaveLds), s, in, n_in, members, n_members, out, status);
+    hipLaunchKernelGGL(mk_bgzf_inflate_wave_kernel<kRing>, dim3(n_members), dim3(64), sizeof(WaveLds<kRing>), s, in, n_in, members, n_members, out, status);
+}
+
+void launch_inflate_wave(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s,
+                         uint32_t ring_bytes) {
+    if (!n_members) return;
+    if (ring_bytes == 8192) launch_ring<8192>(in, n_in, members, n_members, out, status, s);
+    else if (ring_bytes == 16384) launch_ring<16384>(in, n_in, members, n_members, out, status, s);
+    else launch_ring<32768>(in, n_in, members, n_members, out, status, s);
 }
 
 }  // namespace mkz

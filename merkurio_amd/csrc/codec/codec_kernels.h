@@ -44,11 +44,13 @@ void launch_pack(const uint8_t *slots, const uint32_t *slot_len, uint64_t *slot_
 // `in` readable up to in + n_in + kPad.
 // (1 to 64 members per wave, by how many there are: inflate_lanes)
 uint32_t inflate_lanes(uint32_t n_members, int num_cus);
-// which: 0 = by the number of members (up to kWaveMembersMax per CU-quarter... see bgzf_inflate.hip), 1 = one lane per member
+// which: 3 / 4 = a wave per member with a ring of 8 / 16 KiB (measurement); 0 = by the number of members (up to kWaveMembersMax per CU-quarter... see bgzf_inflate.hip), 1 = one lane per member
 // (bgzf_inflate.hip), 2 = one wave per member with the text in LDS (bgzf_inflate_wave.hip)
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s, int which = 0);
-void launch_inflate_wave(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s);
+// ring_bytes: 32768 (all of a member's reach in LDS, 4 waves per CU), 16384 (7) or 8192 (12; far matches read flushed text back)
+void launch_inflate_wave(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s,
+                         uint32_t ring_bytes = 32768);
 
 // ---- one gzip member inflated in parallel pieces (gzip_inflate.hip, gzip_segments.hpp) ----
 // starts[c] (c = 1 .. n_chunks - 1) = bit position of the first confirmed block start at or behind byte c * chunk_bytes, searched

@@ -74,8 +74,8 @@ for label, make in (("BAM records, 4-bin qualities", lambda mb: bam_like(mb * (1
             else:
                 reps = mb // unit_mb
                 blob, want = blob_unit * reps, None
-            for which, kname in ((0, "chosen by size"), (1, "lane per member"), (2, "wave per member")):
-                if which == 2 and mb > 1024:
+            for which, kname in ((0, "chosen by size"), (1, "lane per member"), (2, "wave, 32 KiB ring"), (4, "wave, 16 KiB ring"), (3, "wave,  8 KiB ring")):
+                if which in (2, 3, 4) and mb > 1024:
                     continue
                 codec.set_inflate_kernel(which)
                 best = None
