@@ -809,7 +809,8 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     mk_matcher *second = nullptr;
     if (sam.bam_on_bgzf() && (to_bam || a.suppress_output) && !a.host_codec && !a.host_ingest && ms.size() == 1) {
         if (to_bam) bw.use_device(devs[0]);
-        const uint64_t dev_window = a.window_mb_given ? window_bytes : (256ull << 20);
+        // (240 MiB of text: the tagged records of a window then fill one round of the deflate kernel's 4 096 resident waves, not one and a bit)
+        const uint64_t dev_window = a.window_mb_given ? window_bytes : (240ull << 20);
         bool ac2 = false;
         second = make_matcher(a, pats, &ac2, devs[0]);
         mk_matcher *both[2] = {m, second};

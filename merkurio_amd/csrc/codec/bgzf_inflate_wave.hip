@@ -15,9 +15,12 @@
 //     all lanes from the canonical description (limits / bases / symbols by length), which also decodes the rare longer codewords;
 //   * the tables are built in parallel -- counts per length by lane, symbol ranks by ballot -- so that a block header costs
 //     microseconds; nothing of the decoder lives in private memory (0 bytes of scratch).
-// 36.1 KiB of LDS per wave: 4 waves per CU, one per SIMD, 1 024 members in flight on an MI355X.  A token turn is ~150 (literal) to
-// ~500 (match) cycles of dependent LDS latency: ~2 ms per 64 KiB member.  Calls of up to kWaveMembersMax members take this kernel
-// (launch_inflate decides); above that the lane-per-member kernel's sheer parallelism wins.
+// With the whole 32 KiB in LDS a wave takes 36.1 KiB: 4 waves per CU, one per SIMD -- nothing fills the waits of a token turn's
+// ~150 (literal) to ~500 (match) cycles of dependent LDS latency.  The kernel is a template on the ring's size: with the most
+// recent 8 KiB (12.4 KiB per wave, 12 waves per CU, 3 072 members in flight on an MI355X) the same member takes as long but three
+// times as many run beside it; matches that reach behind the ring come back from global memory (see WaveLds).  launch_inflate
+// (bgzf_inflate.hip) takes the 8 KiB ring for calls of up to 9 216 members; above that the lane-per-member kernel's sheer
+// parallelism wins (profiles/r05_codec_real_rings.txt).
 // RFC 1951; the reference's inflate is flate2 under `bam 0.1.4` (src/cmd_tag.rs:503-506) and needletail (src/cmd_extract.rs:281).
 #include <hip/hip_runtime.h>
 

@@ -1040,7 +1040,7 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
     hipStream_t st = dl.st;
     int rc;
     auto t = std::chrono::steady_clock::now();
-    g_alloc_ms = 0;
+    g_alloc_ms = 0, g_free_ms = 0;
     struct AllocMs {  // (device buffers grown inside the call: part of the phases above, reported on its own as ms[7])
         float *out;
         ~AllocMs() { *out = (float)g_alloc_ms; }

@@ -261,18 +261,28 @@ static ClassPlan plan_classes(std::vector<uint32_t> lens, const mk_matcher_optio
 
 using namespace mk;
 
+thread_local double mk::g_free_ms = 0;  // ... of it, in hipFree
 thread_local double mk::g_alloc_ms = 0;  // time the calling thread has spent growing device buffers (diagnostic: mk_bam_window::ms[7])
 
 int mk::ensure_device(void **p, size_t *cap, size_t need) {
     if (need <= *cap) return MK_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    if (*p) (void)hipFree(*p);
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    double free_ms = 0;
+    if (*p) {
+        (void)hipFree(*p);  // (waits for the device: every stream's kernels, another handle's included)
+        free_ms = ms_since(t0);
+        g_free_ms += free_ms;
+    }
     *p = nullptr;
     *cap = 0;
-    // (room to grow without another allocation: a quarter for small buffers, a sixteenth from 64 MiB on -- growing costs ~30 ms per GiB)
+    // (room to grow without another allocation: a quarter for small buffers, a sixteenth from 64 MiB on)
     size_t want = need + (need < (64u << 20) ? need / 4 : need / 16) + 4096;
     hipError_t e = hipMalloc(p, want);
-    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g_alloc_ms += ms_since(t0);
+#ifdef MK_ALLOC_LOG  // (tagged diagnostic build, tools/tag_alloc_log.sh: which buffer growths cost what)
+    fprintf(stderr, "[alloc] %8.1f MiB: hipFree %7.2f ms, hipMalloc %7.2f ms\n", want / 1048576.0, free_ms, ms_since(t0) - free_ms);
+#endif
     if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     *cap = want;
     return MK_OK;

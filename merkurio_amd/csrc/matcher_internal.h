@@ -113,7 +113,7 @@ struct mk_matcher {
 namespace mk {
 // matcher.cpp: host-buffer batches in steps (mk_scan_batch, host_loops.cpp)
 int ensure_device(void **p, size_t *cap, size_t need);
-extern thread_local double g_alloc_ms;
+extern thread_local double g_alloc_ms, g_free_ms;
 int batch_check(const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint64_t *n_bytes);
 int batch_upload(mk_matcher *m, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_rec, uint64_t n_bytes, uint32_t *batch_len);
 int batch_scan(mk_matcher *m, uint64_t n_bytes, uint64_t n_rec, uint32_t mode, uint32_t batch_len, uint64_t cap, uint64_t limit,
