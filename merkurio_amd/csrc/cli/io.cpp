@@ -20,6 +20,8 @@ __attribute__((weak)) int mk_bgzf_deflate_pieces(mk_codec *c, const uint8_t *con
 __attribute__((weak)) int mk_bgzf_inflate(mk_codec *c, const uint8_t *in, uint64_t n_in, const mk_bgzf_member *members, uint64_t n_members, uint8_t *out,
                                           uint64_t out_cap, uint64_t *bad_member);
 __attribute__((weak)) const char *mk_last_error(void);
+__attribute__((weak)) int mk_host_alloc(size_t bytes, void **out);
+__attribute__((weak)) void mk_host_free(void *p);
 }
 
 #include <algorithm>
@@ -1424,7 +1426,7 @@ BamWriter::RawBuffer BamWriter::take_raw_buffer(size_t min_size) {
     free_raw_buffer(b);
     const size_t want = min_size + min_size / 8;
     void *q = nullptr;
-    if (mk_host_alloc(want, &q) == MK_OK) {
+    if (mk_host_alloc && mk_host_alloc(want, &q) == MK_OK) {  // (weak: the CPU harnesses link without the library)
         b.p = (uint8_t *)q, b.cap = want, b.pinned = true;
     } else {
         b.p = (uint8_t *)malloc(want), b.cap = want, b.pinned = false;

@@ -3,13 +3,36 @@
 // cut into BGZF members by the writer's queue + writer thread and deflated by zlib on the host threads (the --host-codec
 // path; the device path shares everything but the deflate call).
 // usage: harness <in.sam> <out.bam> <records per piece> [members per run of the writer queue, default 1536]
+//        harness --members <header.sam> <out.bam> <file of finished BGZF members>...: the header through the writer, then members made
+//        elsewhere passed through as they are (BamWriter::put_members: what `tag` does with the members the device hands back)
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "io.hpp"
 using namespace cli;
 int main(int argc, char **argv) {
     try {
+        if (argc > 3 && std::string(argv[1]) == "--members") {
+            SamFile h;
+            h.open(argv[2]);
+            BamWriter bw;
+            bw.open(argv[3], h.header);
+            for (int k = 4; k < argc; ++k) {
+                FILE *g = fopen(argv[k], "rb");
+                if (!g) bail(std::string("cannot open ") + argv[k]);
+                fseek(g, 0, SEEK_END);
+                const size_t n = (size_t)ftell(g);
+                fseek(g, 0, SEEK_SET);
+                BamWriter::RawBuffer b = bw.take_raw_buffer(n + (k % 2 ? 100000 : 0));  // (buffers larger than their content; recycled ones)
+                if (fread(b.p, 1, n, g) != n) bail("short read");
+                fclose(g);
+                bw.put_members(b, n);
+            }
+            bw.close();
+            printf("#members files %d\n", argc - 4);
+            return 0;
+        }
         SamFile f;
         f.open(argv[1]);
         const size_t per = (size_t)strtoull(argv[3], nullptr, 10);

@@ -375,6 +375,29 @@ def test_bam_writer_pieces_queue_and_encoder(tmp_path):
             f[6] = "*"  # "the same reference" of an unmapped read is no reference
         return "\t".join(f)
     assert len(got) == n and [norm(l) for l in got] == [norm(l) for l in lines]
+    # members made elsewhere passed through (put_members, r05: `tag` hands the writer the members the device deflated): the header
+    # is closed with a member of its own, the files follow as they are, in order, through the writer's queue and recycled buffers
+    import zlib
+    def bgzf(data, block=0xff00):
+        out = bytearray()
+        for b in range(0, len(data), block):
+            chunk = data[b:b + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            c = co.compress(chunk) + co.flush()
+            out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", len(c) + 25) + c
+            out += struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        return bytes(out)
+    (tmp_path / "h.sam").write_text(header)
+    payloads = [bytes(rnd.randrange(256) for _ in range(k)) * 50 for k in (3000, 1, 70000 // 50, 2500, 9000, 17, 4000)]
+    for k, p in enumerate(payloads):
+        (tmp_path / f"m{k}.bin").write_bytes(bgzf(p))
+    r = subprocess.run([wexe, "--members", str(tmp_path / "h.sam"), str(tmp_path / "pass.bam"), *[str(tmp_path / f"m{k}.bin") for k in range(len(payloads))]],
+                       capture_output=True, text=True)
+    assert r.stdout.strip() == f"#members files {len(payloads)}", (r.stdout, r.stderr)
+    raw = (tmp_path / "pass.bam").read_bytes()
+    hdr_stream = streams[0][:streams[0].index(b"read0/x") - 36]  # the BAM header as the first runs wrote it (records start 36 bytes in front of the first name)
+    assert gzip.decompress(raw) == hdr_stream + b"".join(payloads)
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
 
 
 def test_log_rows_are_formatted_like_serde_json(tmp_path):
