@@ -32,7 +32,8 @@ struct CommonArgs {
     bool device_codec_always = false;  // --device-codec-always: BGZF input goes through the device codec however few members a call holds (tests: the
                                        // reference's own small BAM / bgzip'ed fixtures through mk_bgzf_inflate)
     bool window_mb_given = false;      // --window-mb was on the command line (its default does not bind the paths that keep the text on the device)
-    bool host_ingest = false;  // --host-ingest: extract parses FASTQ records on the host threads even where the device could index them
+    bool host_ingest = false;  // --host-ingest: extract parses its records on the host threads even where the device could index them; tag keeps the r04 path
+                               // (BAM records indexed and tagged on the host threads) where BAM -> BAM would keep them on the device
 };
 
 // set by main(): the process ends right after the command (handles are not destroyed one by one, commands.cpp)

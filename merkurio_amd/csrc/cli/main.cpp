@@ -60,6 +60,7 @@ void print_help(const char *sub) {
              "  -m, --filter-matching        keep only records with a hit\n  -v, --invert-match           keep only records without a hit\n"
              "  -p, --threads <N>            at most N host threads for the BAM/SAM codec work [all cores]\n  -r -c -l -j -S -I -L -U -q -a --device --gpus --batch-mb  as for extract\n"
              "      --host-codec             BGZF members deflated by zlib on the host threads (default: on the GPU)\n"
+             "      --host-ingest            BAM records indexed and tagged on the host threads (default: BAM -> BAM keeps them on the GPU)\n"
              "      --device-codec-always    BGZF input inflated on the GPU however few members a window holds");
     }
 }

@@ -42,18 +42,19 @@ uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
     return lanes;
 }
 
-// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in 2-6 ms; with the most recent
-// 8 KiB of the member's text in LDS twelve of them fit a CU (3 072 on the part): its time grows with the members per slot.  A lane
-// per member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands of members.
-// zlib level-6 members of BAM records: 64 MB 6.3 against 24.1 ms, 256 MB 14.1 against 23.1, 1 GiB 44.0 against 40.5 -- they cross
-// at ~three rounds of the wave kernel's slots (profiles/r05_codec_real.txt).
-constexpr uint32_t kWaveRounds = 3, kWaveSlotsPerCu = 12;
+// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in 2-6 ms; with only the most recent
+// 4 KiB of the member's text in LDS nineteen of them fit a CU (4 864 on the part): its time grows with the members per slot.  A
+// lane per member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands of members.
+// zlib level-6 members of BAM records: 64 MB 6.2 against 21-24 ms, 256 MB 10.9 against 22.7, 1 GiB 35.7 against 40.5, 2 GiB 66.6
+// against 41.3 -- they cross at about four rounds of the wave kernel's slots (profiles/r05_codec_real_rings.txt; rings of 2, 8, 16
+// and 32 KiB are in the same table: 4 KiB is the best or within 7 % of it at every size).
+constexpr uint32_t kWaveRounds = 4, kWaveSlotsPerCu = 19, kWaveRing = 4096;
 
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s, int which) {
     if (!n_members) return;
-    if (which == 3 || which == 4) {
-        launch_inflate_wave(in, n_in, members, n_members, out, status, s, which == 3 ? 8192u : 16384u);
+    if (which >= 3 && which <= 6) {
+        launch_inflate_wave(in, n_in, members, n_members, out, status, s, which == 3 ? 8192u : which == 4 ? 16384u : which == 5 ? 4096u : 2048u);
         return;
     }
     if (which == 2) {
@@ -61,7 +62,7 @@ void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uin
         return;
     }
     if (which == 0 && n_members <= (uint32_t)num_cus * kWaveSlotsPerCu * kWaveRounds) {
-        launch_inflate_wave(in, n_in, members, n_members, out, status, s, 8192u);
+        launch_inflate_wave(in, n_in, members, n_members, out, status, s, kWaveRing);
         return;
     }
     const uint32_t lanes = inflate_lanes(n_members, num_cus);

@@ -18,9 +18,9 @@
 // With the whole 32 KiB in LDS a wave takes 36.1 KiB: 4 waves per CU, one per SIMD -- nothing fills the waits of a token turn's
 // ~150 (literal) to ~500 (match) cycles of dependent LDS latency.  The kernel is a template on the ring's size: with the most
 // recent 8 KiB (12.4 KiB per wave, 12 waves per CU, 3 072 members in flight on an MI355X) the same member takes as long but three
-// times as many run beside it; matches that reach behind the ring come back from global memory (see WaveLds).  launch_inflate
-// (bgzf_inflate.hip) takes the 8 KiB ring for calls of up to 9 216 members; above that the lane-per-member kernel's sheer
-// parallelism wins (profiles/r05_codec_real_rings.txt).
+// times as many run beside it (4 KiB: 8.3 KiB per wave, 19 per CU, 4 864 in flight); matches that reach behind the ring come back
+// from global memory (see WaveLds).  launch_inflate (bgzf_inflate.hip) takes the 4 KiB ring for calls of up to ~19 000 members; above
+// that the lane-per-member kernel's sheer parallelism wins (profiles/r05_codec_real_rings.txt).
 // RFC 1951; the reference's inflate is flate2 under `bam 0.1.4` (src/cmd_tag.rs:503-506) and needletail (src/cmd_extract.rs:281).
 #include <hip/hip_runtime.h>
 
@@ -31,7 +31,6 @@ namespace mkz {
 
 namespace {
 
-constexpr uint32_t kFlush = 4096;
 constexpr int kFastLl = 10, kFastD = 9;
 
 // kRing bytes of the member's most recent text.  32 KiB hold everything a DEFLATE distance can reach (4 waves per CU).  With a
@@ -117,7 +116,8 @@ __device__ void wave_fill_fast(uint16_t *fast, int bits, const uint16_t *sorted,
 template <uint32_t kRing>
 __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t *__restrict__ in_all, uint64_t n_in_all, const Member *__restrict__ members,
                                                                   uint32_t n_members, uint8_t *__restrict__ out_all, int32_t *__restrict__ status_out) {
-    static_assert(kRing >= 2 * kFlush && (kRing & (kRing - 1)) == 0, "ring: a power of two that holds two flush pieces");
+    constexpr uint32_t kFlush = kRing >= 8192 ? 4096u : kRing / 2;  // (the text leaves in pieces of this size; the ring holds two of them)
+    static_assert(kRing >= 2 * kFlush && kFlush >= 1024 && (kRing & (kRing - 1)) == 0, "ring: a power of two that holds two flush pieces");
     constexpr uint32_t kRingMask = kRing - 1;
     extern __shared__ uint8_t lds_raw[];
     WaveLds<kRing> &S = *reinterpret_cast<WaveLds<kRing> *>(lds_raw);
@@ -406,7 +406,9 @@ static void launch_ring(const uint8_t *in, uint64_t n_in, const Member *members,
 void launch_inflate_wave(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, hipStream_t s,
                          uint32_t ring_bytes) {
     if (!n_members) return;
-    if (ring_bytes == 8192) launch_ring<8192>(in, n_in, members, n_members, out, status, s);
+    if (ring_bytes == 2048) launch_ring<2048>(in, n_in, members, n_members, out, status, s);
+    else if (ring_bytes == 4096) launch_ring<4096>(in, n_in, members, n_members, out, status, s);
+    else if (ring_bytes == 8192) launch_ring<8192>(in, n_in, members, n_members, out, status, s);
     else if (ring_bytes == 16384) launch_ring<16384>(in, n_in, members, n_members, out, status, s);
     else launch_ring<32768>(in, n_in, members, n_members, out, status, s);
 }

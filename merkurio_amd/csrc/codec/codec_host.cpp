@@ -193,7 +193,7 @@ int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inf
 }
 
 int mk_codec_set_inflate_kernel(mk_codec *c, int which) {
-    if (!c || which < 0 || which > 4) return mk::fail(MK_E_INVALID_ARG, "mk_codec_set_inflate_kernel: handle / selector");
+    if (!c || which < 0 || which > 6) return mk::fail(MK_E_INVALID_ARG, "mk_codec_set_inflate_kernel: handle / selector");
     std::lock_guard<std::mutex> lock(c->mu);
     c->inflate_kernel = which;
     return MK_OK;

@@ -22,7 +22,7 @@ from textio import bam_like
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4], ids=["kernel-by-size", "lane-per-member", "wave-per-member", "wave-8k-ring", "wave-16k-ring"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4, 5, 6], ids=["kernel-by-size", "lane-per-member", "wave-per-member", "wave-8k-ring", "wave-16k-ring", "wave-4k-ring", "wave-2k-ring"])
 def codec(request):
     """every test runs three times: the inflate kernel chosen per call (a wave per member for small calls, a lane per member for
     large ones: bgzf_inflate.hip), and each of the two forced (mk_codec_set_inflate_kernel)"""

@@ -59,7 +59,7 @@ for label, make in (("BAM records, 4-bin qualities", lambda mb: bam_like(mb * (1
     print(f"{label}: {len(unit) / 1e6:.0f} MB unit, zlib level 6 ratio {len(unit) / len(z_unit):.2f}, device deflate ratio {len(unit) / len(d_unit):.2f} "
           f"({time.time() - t0:.0f} s to make)", flush=True)
     mem_z, _, _ = mk.bgzf_members(z_unit)
-    for mb in (64, 256, 1024, 2048):
+    for mb in (64, 256, 1024, 2048):  # (2048: the lane-per-member kernel and the smallest rings only)
         if mb > top:
             continue
         for kind, blob_unit in (("zlib level 6 members", z_unit), ("device-written members", d_unit)):
@@ -74,8 +74,8 @@ for label, make in (("BAM records, 4-bin qualities", lambda mb: bam_like(mb * (1
             else:
                 reps = mb // unit_mb
                 blob, want = blob_unit * reps, None
-            for which, kname in ((0, "chosen by size"), (1, "lane per member"), (2, "wave, 32 KiB ring"), (4, "wave, 16 KiB ring"), (3, "wave,  8 KiB ring")):
-                if which in (2, 3, 4) and mb > 1024:
+            for which, kname in ((0, "chosen by size"), (1, "lane per member"), (2, "wave, 32 KiB ring"), (4, "wave, 16 KiB ring"), (3, "wave,  8 KiB ring"), (5, "wave,  4 KiB ring"), (6, "wave,  2 KiB ring")):
+                if which in (2, 4) and mb > 256 or which == 3 and mb > 1024:
                     continue
                 codec.set_inflate_kernel(which)
                 best = None
