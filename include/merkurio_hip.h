@@ -561,7 +561,8 @@ int mk_gzip_info(const mk_codec *c, uint32_t *segments, float ms[5]);
  * are guessed and then proved by every piece's walk landing on the next piece's start: the table is the serial walk's), the 4-bit
  * sequences become the upper-case ASCII record.sequence() hands the matcher (:395), the scan, the emission order and the per-record
  * pattern sets run as in mk_tag_records, a record is kept by the rule of :457-467, and every kept record leaves as
- * block_size' | record | tag 'Z' value NUL -- the value being its distinct matched patterns, ascending, joined by ',' (:484-490)
+ * block_size' | record | tag 'Z' value NUL -- the value being its distinct matched patterns, ascending, joined by ',' (:484-490),
+ * merged with the items of the record's existing Z field of that name if it has one (:470-485; the old field stays)
  * -- packed back to back and deflated into BGZF members of block_bytes of text (0 = 65280; the last one shorter) in out[0, out_len).
  * The members inflate to exactly the bytes the CLI's host path writes for these records.
  * Outputs: n_window (bytes of text), n_rec whole records covering n_used bytes, tail[0, n_tail) = the text behind them (the next
@@ -572,8 +573,8 @@ int mk_gzip_info(const mk_codec *c, uint32_t *segments, float ms[5]);
  * (logger.log_fields' record.name(), :412); too small a rows / names buffer: MK_E_CAPACITY with n_rows / n_names_bytes = the need.
  * *status != 0: this window is not for the device and NOTHING was produced -- the caller's host reader takes it from the window's
  * first byte (and words the reference's errors): 1 = a record that fails the parser's checks or a chain that could not be proved,
- * 2 = optional fields that do not parse, 4 = a kept record that already carries the tag (the reference merges a Z value, :470-481,
- * and refuses other types), 8 = last != 0 and the text ends inside a record.
+ * 2 = optional fields that do not parse, 4 = a kept record whose field of the tag's name is not a string (the reference refuses it,
+ * :482) or holds a value that is not plain ASCII or longer than 2 KiB, 8 = last != 0 and the text ends inside a record.
  * ms[]: milliseconds of upload, inflate, index, unpack + scan + sets, tag + emit, deflate, download; ms[7]: of these, growing device buffers.
  * --------------------------------------------------------------------------------------- */
 typedef struct mk_bam_window {

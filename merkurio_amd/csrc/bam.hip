@@ -191,24 +191,63 @@ __global__ __launch_bounds__(256) void mk_bam_unpack_kernel(const uint8_t *__res
     }
 }
 
+// ---- the value of a record that already carries the tag (src/cmd_tag.rs:470-485): the found patterns and the ','-separated items of
+// the existing Z value, sort_unstable + dedup (Rust's String order = bytewise), joined by ','.  Both kernels below enumerate that
+// merge the same way: "the smallest item that is greater than the previous one", found by a scan over both lists -- quadratic in the
+// number of items, which is a handful (values above kBamMergeBytes are left to the host path).
+constexpr uint32_t kBamMergeBytes = 2048;
+
+__device__ __forceinline__ int bam_cmp(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb) {
+    const uint32_t m = min(na, nb);
+    for (uint32_t k = 0; k < m; ++k)
+        if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+    return na < nb ? -1 : na > nb ? 1 : 0;
+}
+// *best = the smallest item > prev (have_prev == false: the smallest of all); false: there is none
+__device__ bool bam_merge_next(const uint8_t *__restrict__ ex, uint32_t nex, unsigned long long f0, unsigned long long f1, const uint32_t *__restrict__ found_pat,
+                               const uint8_t *__restrict__ pat_bytes, const uint32_t *__restrict__ pat_off, bool have_prev, const uint8_t *prev, uint32_t nprev,
+                               const uint8_t **best, uint32_t *nbest) {
+    bool have = false;
+    const uint8_t *bp = nullptr;
+    uint32_t bn = 0;
+    auto offer = [&](const uint8_t *p, uint32_t n) {
+        if (have_prev && bam_cmp(p, n, prev, nprev) <= 0) return;
+        if (!have || bam_cmp(p, n, bp, bn) < 0) have = true, bp = p, bn = n;
+    };
+    for (unsigned long long f = f0; f < f1; ++f) {
+        const uint32_t pt = found_pat[f];
+        offer(pat_bytes + pat_off[pt], pat_off[pt + 1] - pat_off[pt]);
+    }
+    for (uint32_t a = 0; a <= nex;) {  // (an empty value has been taken for "no tag" before: nex > 0; "a,,b" holds an empty item)
+        uint32_t b = a;
+        while (b < nex && ex[b] != ',') ++b;
+        offer(ex + a, b - a);
+        a = b + 1;
+    }
+    *best = bp, *nbest = bn;
+    return have;
+}
+
 // Per record: keep or drop (src/cmd_tag.rs:457-467), and for a kept one the size of the record it leaves as --
 // 4 + block_size + tag (2) + 'Z' + value + NUL, the value being its distinct matched patterns joined by ',' (:484-490; ascending
-// pattern index = sort_unstable order of the sorted unique pattern list).  A kept record's optional fields are walked: one that
-// already carries the tag (the reference merges a Z value, :470-481, and refuses other types) or that does not parse sets a status
-// bit -- the caller's host path then does this window, where those rules live.
+// pattern index = sort_unstable order of the sorted unique pattern list), merged with the record's existing Z value of that name if
+// it has one (:470-485).  A kept record's optional fields are walked for that: fields that do not parse, a field of that name that is
+// not a string (the reference refuses it), or a value that is not plain ASCII or very long set a status bit -- the caller's host
+// path then does this window, where those rules live.
 __global__ __launch_bounds__(256) void mk_bam_taglen_kernel(const uint8_t *__restrict__ text, const uint32_t *__restrict__ rec_off,
                                                            const uint32_t *__restrict__ rec_len, const uint32_t *__restrict__ seq_start,
                                                            const uint32_t *__restrict__ seq_len, const unsigned long long *__restrict__ found_off,
                                                            const uint32_t *__restrict__ found_pat, const uint32_t *__restrict__ pat_off, uint64_t n_rec,
-                                                           uint32_t filter_matching, uint32_t invert, uint32_t tag0, uint32_t tag1,
-                                                           uint8_t *__restrict__ keep, uint32_t *__restrict__ out_len, uint32_t *__restrict__ st) {
+                                                           const uint8_t *__restrict__ pat_bytes, uint32_t filter_matching, uint32_t invert, uint32_t tag0,
+                                                           uint32_t tag1, uint8_t *__restrict__ keep, uint32_t *__restrict__ out_len,
+                                                           uint32_t *__restrict__ ex_off, uint32_t *__restrict__ st) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bad = 0;
     if (i < n_rec) {
         const unsigned long long f0 = found_off[i], f1 = found_off[i + 1];
         const bool has = f1 > f0;
         const bool kept = filter_matching ? has : (invert ? !has : true);
-        uint32_t len = 0;
+        uint32_t len = 0, ex_at = 0, ex_n = 0;
         if (kept) {
             const uint32_t l = seq_len[i];
             uint64_t p = (uint64_t)seq_start[i] + (l + 1) / 2 + l;
@@ -219,7 +258,8 @@ __global__ __launch_bounds__(256) void mk_bam_taglen_kernel(const uint8_t *__res
                     break;
                 }
                 const uint32_t t0 = text[p], t1 = text[p + 1], type = text[p + 2];
-                if (t0 == tag0 && t1 == tag1) bad |= 4;  // the tag exists already
+                const bool mine = t0 == tag0 && t1 == tag1 && ex_at == 0 && !(bad & 4);  // (record.tags().get(): the first field of that name)
+                if (mine && type != 'Z') bad |= 4;  // the reference refuses it: the host path words that
                 p += 3;
                 if (type == 'A' || type == 'c' || type == 'C') {
                     p += 1;
@@ -228,7 +268,14 @@ __global__ __launch_bounds__(256) void mk_bam_taglen_kernel(const uint8_t *__res
                 } else if (type == 'i' || type == 'I' || type == 'f') {
                     p += 4;
                 } else if (type == 'Z' || type == 'H') {
-                    while (p < e && text[p]) ++p;
+                    const uint64_t v0 = p;
+                    uint32_t high = 0;
+                    while (p < e && text[p]) high |= text[p], ++p;
+                    if (mine && type == 'Z') {
+                        // (not plain ASCII: the reference checks UTF-8 first -- the host path's business; so is a very long value)
+                        if ((high & 0x80u) || p - v0 > kBamMergeBytes) bad |= 4;
+                        else ex_at = (uint32_t)v0, ex_n = (uint32_t)(p - v0);
+                    }
                     ++p;
                 } else if (type == 'B') {
                     if (e - p < 5) {
@@ -250,15 +297,25 @@ __global__ __launch_bounds__(256) void mk_bam_taglen_kernel(const uint8_t *__res
             }
             if (p > e) bad |= 2;
             uint32_t vlen = 0;
-            for (unsigned long long k = f0; k < f1; ++k) {
-                const uint32_t pt = found_pat[k];
-                vlen += pat_off[pt + 1] - pat_off[pt];
+            if (ex_n == 0) {  // no tag of that name, or an empty value ("do nothing if tag is empty", :472-473)
+                ex_at = 0;
+                for (unsigned long long k = f0; k < f1; ++k) {
+                    const uint32_t pt = found_pat[k];
+                    vlen += pat_off[pt + 1] - pat_off[pt];
+                }
+                if (has) vlen += (uint32_t)(f1 - f0) - 1;
+            } else if (!bad) {
+                const uint8_t *prev = nullptr, *it;
+                uint32_t nprev = 0, nit, items = 0;
+                while (bam_merge_next(text + ex_at, ex_n, f0, f1, found_pat, pat_bytes, pat_off, items != 0, prev, nprev, &it, &nit))
+                    vlen += nit, prev = it, nprev = nit, ++items;
+                vlen += items - 1;
             }
-            if (has) vlen += (uint32_t)(f1 - f0) - 1;
             len = rec_len[i] + 3 + vlen + 1;
         }
         keep[i] = kept ? 1 : 0;
         out_len[i] = len;
+        ex_off[i] = ex_at;
     }
     if (__ballot(bad != 0)) {
         uint32_t all = bad;
@@ -273,8 +330,8 @@ __global__ __launch_bounds__(256) void mk_bam_emit_kernel(const uint8_t *__restr
                                                          const uint32_t *__restrict__ rec_len, const uint32_t *__restrict__ out_len,
                                                          const unsigned long long *__restrict__ out_off, const unsigned long long *__restrict__ found_off,
                                                          const uint32_t *__restrict__ found_pat, const uint8_t *__restrict__ pat_bytes,
-                                                         const uint32_t *__restrict__ pat_off, uint64_t n_rec, uint32_t tag0, uint32_t tag1,
-                                                         uint8_t *__restrict__ out) {
+                                                         const uint32_t *__restrict__ pat_off, const uint32_t *__restrict__ ex_off, uint64_t n_rec,
+                                                         uint32_t tag0, uint32_t tag1, uint8_t *__restrict__ out) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t sub = threadIdx.x & 15u;
     if (i >= n_rec) return;
@@ -294,11 +351,24 @@ __global__ __launch_bounds__(256) void mk_bam_emit_kernel(const uint8_t *__restr
         t[0] = (uint8_t)tag0, t[1] = (uint8_t)tag1, t[2] = 'Z';
         t += 3;
         const unsigned long long f0 = found_off[i], f1 = found_off[i + 1];
-        for (unsigned long long f = f0; f < f1; ++f) {
-            if (f > f0) *t++ = ',';
-            const uint32_t pt = found_pat[f];
-            const uint32_t a = pat_off[pt], b = pat_off[pt + 1];
-            for (uint32_t j = a; j < b; ++j) *t++ = pat_bytes[j];
+        const uint32_t ex_at = ex_off[i];
+        if (ex_at == 0) {
+            for (unsigned long long f = f0; f < f1; ++f) {
+                if (f > f0) *t++ = ',';
+                const uint32_t pt = found_pat[f];
+                const uint32_t a = pat_off[pt], b = pat_off[pt + 1];
+                for (uint32_t j = a; j < b; ++j) *t++ = pat_bytes[j];
+            }
+        } else {  // merged with the record's existing value (the old field stays where it is: push_string appends, :488-490)
+            uint32_t ex_n = 0;
+            while (text[ex_at + ex_n]) ++ex_n;
+            const uint8_t *prev = nullptr, *it;
+            uint32_t nprev = 0, nit, items = 0;
+            while (bam_merge_next(text + ex_at, ex_n, f0, f1, found_pat, pat_bytes, pat_off, items != 0, prev, nprev, &it, &nit)) {
+                if (items) *t++ = ',';
+                for (uint32_t j = 0; j < nit; ++j) *t++ = it[j];
+                prev = it, nprev = nit, ++items;
+            }
         }
         *t = 0;
     }
@@ -335,18 +405,19 @@ void launch_bam_unpack(const uint8_t *d_text, const uint32_t *d_seq_start, const
                        n_rec, d_seq);
 }
 void launch_bam_taglen(const uint8_t *d_text, const uint32_t *d_rec_off, const uint32_t *d_rec_len, const uint32_t *d_seq_start, const uint32_t *d_seq_len,
-                       const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint32_t *d_pat_off, uint64_t n_rec, uint32_t filter_matching,
-                       uint32_t invert, uint32_t tag0, uint32_t tag1, uint8_t *d_keep, uint32_t *d_out_len, uint32_t *d_st, hipStream_t st) {
+                       const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint32_t *d_pat_off, const uint8_t *d_pat_bytes, uint64_t n_rec,
+                       uint32_t filter_matching, uint32_t invert, uint32_t tag0, uint32_t tag1, uint8_t *d_keep, uint32_t *d_out_len, uint32_t *d_ex_off,
+                       uint32_t *d_st, hipStream_t st) {
     if (!n_rec) return;
     hipLaunchKernelGGL(mk_bam_taglen_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, d_text, d_rec_off, d_rec_len, d_seq_start, d_seq_len,
-                       d_found_off, d_found_pat, d_pat_off, n_rec, filter_matching, invert, tag0, tag1, d_keep, d_out_len, d_st);
+                       d_found_off, d_found_pat, d_pat_off, n_rec, d_pat_bytes, filter_matching, invert, tag0, tag1, d_keep, d_out_len, d_ex_off, d_st);
 }
 void launch_bam_emit(const uint8_t *d_text, const uint32_t *d_rec_off, const uint32_t *d_rec_len, const uint32_t *d_out_len, const unsigned long long *d_out_off,
-                     const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint8_t *d_pat_bytes, const uint32_t *d_pat_off, uint64_t n_rec,
-                     uint32_t tag0, uint32_t tag1, uint8_t *d_out, hipStream_t st) {
+                     const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint8_t *d_pat_bytes, const uint32_t *d_pat_off,
+                     const uint32_t *d_ex_off, uint64_t n_rec, uint32_t tag0, uint32_t tag1, uint8_t *d_out, hipStream_t st) {
     if (!n_rec) return;
     hipLaunchKernelGGL(mk_bam_emit_kernel, dim3((unsigned)((n_rec * 16 + 255) / 256)), dim3(256), 0, st, d_text, d_rec_off, d_rec_len, d_out_len, d_out_off,
-                       d_found_off, d_found_pat, d_pat_bytes, d_pat_off, n_rec, tag0, tag1, d_out);
+                       d_found_off, d_found_pat, d_pat_bytes, d_pat_off, d_ex_off, n_rec, tag0, tag1, d_out);
 }
 void launch_bam_names(const uint8_t *d_text, const uint32_t *d_rec_off, const uint8_t *d_flags, uint64_t n_rec, uint32_t *d_name_start, uint32_t *d_name_len,
                       hipStream_t st) {

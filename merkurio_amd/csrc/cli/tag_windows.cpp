@@ -13,8 +13,8 @@
 // its members are copied into page-locked memory (a mapped file is not a DMA source) beside all of that.  Results are emitted in
 // window order; the writer thread writes window k - 1 meanwhile.
 //
-// A window the device refuses -- a record that fails the parser's checks, optional fields that do not parse, a kept record that
-// already carries the tag, a damaged member -- hands the input back to the host reader AT THAT WINDOW'S FIRST BYTE
+// A window the device refuses -- a record that fails the parser's checks, optional fields that do not parse, a kept record whose
+// field of the tag's name is not a plain string, a damaged member -- hands the input back to the host reader AT THAT WINDOW'S FIRST BYTE
 // (SamFile::seek_bam): the r04 path takes the rest of the file and words the reference's errors.  (The window behind it may have
 // been started already: its results are dropped.)
 #include <algorithm>

@@ -907,11 +907,12 @@ void launch_bam_walk_emit(const uint8_t *d_text, uint64_t n, uint32_t piece, uin
 void launch_bam_unpack(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off, uint32_t fixed_len,
                        uint64_t n_rec, uint8_t *d_seq, hipStream_t st);
 void launch_bam_taglen(const uint8_t *d_text, const uint32_t *d_rec_off, const uint32_t *d_rec_len, const uint32_t *d_seq_start, const uint32_t *d_seq_len,
-                       const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint32_t *d_pat_off, uint64_t n_rec, uint32_t filter_matching,
-                       uint32_t invert, uint32_t tag0, uint32_t tag1, uint8_t *d_keep, uint32_t *d_out_len, uint32_t *d_st, hipStream_t st);
+                       const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint32_t *d_pat_off, const uint8_t *d_pat_bytes, uint64_t n_rec,
+                       uint32_t filter_matching, uint32_t invert, uint32_t tag0, uint32_t tag1, uint8_t *d_keep, uint32_t *d_out_len, uint32_t *d_ex_off,
+                       uint32_t *d_st, hipStream_t st);
 void launch_bam_emit(const uint8_t *d_text, const uint32_t *d_rec_off, const uint32_t *d_rec_len, const uint32_t *d_out_len, const unsigned long long *d_out_off,
-                     const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint8_t *d_pat_bytes, const uint32_t *d_pat_off, uint64_t n_rec,
-                     uint32_t tag0, uint32_t tag1, uint8_t *d_out, hipStream_t st);
+                     const unsigned long long *d_found_off, const uint32_t *d_found_pat, const uint8_t *d_pat_bytes, const uint32_t *d_pat_off,
+                     const uint32_t *d_ex_off, uint64_t n_rec, uint32_t tag0, uint32_t tag1, uint8_t *d_out, hipStream_t st);
 void launch_bam_names(const uint8_t *d_text, const uint32_t *d_rec_off, const uint8_t *d_flags, uint64_t n_rec, uint32_t *d_name_start, uint32_t *d_name_len,
                       hipStream_t st);
 }  // namespace mk
@@ -985,9 +986,9 @@ int bam_index(mk_matcher *m, WindowSide &W, hipStream_t st, uint64_t *n_rec, uin
     *n_rec = total;
     *n_used = n_pieces ? land[n_pieces - 1] : 0;
     if (total >= 0xFFFFFFF0ull) return fail(MK_E_UNSUPPORTED, "%llu records in one BAM window", (unsigned long long)total);
-    // tables: record offsets | sequence starts | sequence lengths | record lengths | out lengths (u32, n + 2 each) | out offsets (u64) | tiles (u64)
+    // tables: record offsets | sequence starts | sequence lengths | record lengths | out lengths | existing-tag offsets (u32, n + 2 each) | out offsets (u64) | tiles (u64)
     const size_t n_tiles = total / ingest_scan_tile() + 2;
-    if ((rc = ensure_device(&T.d_ing_b, &T.d_ing_b_cap, 5 * (total + 2) * 4 + 16 + (total + 2) * 8 + n_tiles * 8 + 64))) return rc;
+    if ((rc = ensure_device(&T.d_ing_b, &T.d_ing_b_cap, 6 * (total + 2) * 4 + 16 + (total + 2) * 8 + n_tiles * 8 + 64))) return rc;
     W.d_rec_start = (uint32_t *)T.d_ing_b;
     W.d_seq_start = W.d_rec_start + total + 2;
     W.d_seq_len = W.d_seq_start + total + 2;
@@ -1076,8 +1077,8 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
     if (w->on_tail) w->on_tail(w->on_tail_ctx, w->tail, w->n_tail);
     w->ms[2] = (float)ms_since(t);
     if (n == 0) return MK_OK;
-    uint32_t *d_out_len = d_rec_len + n + 2;
-    unsigned long long *d_out_off = (unsigned long long *)(((uintptr_t)(d_out_len + n + 2) + 15) & ~(uintptr_t)15);
+    uint32_t *d_out_len = d_rec_len + n + 2, *d_ex_off = d_out_len + n + 2;
+    unsigned long long *d_out_off = (unsigned long long *)(((uintptr_t)(d_ex_off + n + 2) + 15) & ~(uintptr_t)15);
     unsigned long long *d_tile = d_out_off + n + 2;
     // ---- sequences -> the scan buffer, scan, emission order, pattern sets
     unsigned long long n_seq = (unsigned long long)n * fixed;
@@ -1164,8 +1165,8 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
     // ---- keep, tag, pack
     if ((rc = ensure_device((void **)&m->d_flags2, &m->d_flags2_cap, n + 8))) return rc;
     if (hipMemsetAsync(W.d_st, 0, 4, st) != hipSuccess) return fail(MK_E_HIP, "hipMemsetAsync failed");
-    launch_bam_taglen((const uint8_t *)W.T->d_text, W.d_rec_start, d_rec_len, W.d_seq_start, W.d_seq_len, d_found_off, d_found_pat, m->d_pat_off, n,
-                      w->filter_matching != 0, w->invert != 0, w->tag[0], w->tag[1], m->d_flags2, d_out_len, W.d_st, st);
+    launch_bam_taglen((const uint8_t *)W.T->d_text, W.d_rec_start, d_rec_len, W.d_seq_start, W.d_seq_len, d_found_off, d_found_pat, m->d_pat_off, m->d_pat_bytes, n,
+                      w->filter_matching != 0, w->invert != 0, w->tag[0], w->tag[1], m->d_flags2, d_out_len, d_ex_off, W.d_st, st);
     launch_ingest_offsets(d_out_len, n, d_tile, d_out_off, st);
     unsigned long long out_text = 0;
     uint32_t st_tag = 0;
@@ -1196,7 +1197,7 @@ int mk_tag_bam_window(mk_matcher *m, mk_codec *codec, mk_bam_window *w, int logg
     }
     mk_matcher::TextSlot &O = m->txt[1];
     if ((rc = ensure_device(&O.d_text, &O.d_text_cap, out_text + mkz::kPad + 64))) return rc;
-    launch_bam_emit((const uint8_t *)W.T->d_text, W.d_rec_start, d_rec_len, d_out_len, d_out_off, d_found_off, d_found_pat, m->d_pat_bytes, m->d_pat_off, n,
+    launch_bam_emit((const uint8_t *)W.T->d_text, W.d_rec_start, d_rec_len, d_out_len, d_out_off, d_found_off, d_found_pat, m->d_pat_bytes, m->d_pat_off, d_ex_off, n,
                     w->tag[0], w->tag[1], (uint8_t *)O.d_text, st);
     if (hipGetLastError() != hipSuccess || hipMemsetAsync((uint8_t *)O.d_text + out_text, 0, mkz::kPad, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return fail(MK_E_HIP, "record output kernel failed");

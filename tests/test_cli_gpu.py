@@ -747,22 +747,33 @@ def test_tag_bam_records_resident_on_the_device(tmp_path):
     # -S: no output, logs only
     run(["tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-S", "-l", str(tmp_path / "s_d.log")])
     assert log_body(tmp_path / "s_d.log") == log_body(tmp_path / "all_h.log")
-    # tagging the tagged file again with the same tag: the kept records carry it already -> the reference's merge rule, on the host
-    p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-o", str(tmp_path / "again_d.bam")], capture_output=True,
-                       env=dict(os.environ, MERKURIO_TIMING="1"))
-    assert p.returncode == 0 and b"left to the host reader (existing tag)" in p.stderr
-    run(["tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-o", str(tmp_path / "again_h.bam"), "--host-ingest"])
-    assert _bam_stream(tmp_path / "again_d.bam") == _bam_stream(tmp_path / "again_h.bam")
-    # ... in small windows: the first ones on the device (under -m only records with a hit are kept: the first window with one of
-    # them that has the tag hands over), the stream continuous across the hand-over
-    p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-m", "-o", str(tmp_path / "again_m_d.bam"), "--window-mb", "1"],
-                       capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
-    assert p.returncode == 0 and b"left to the host reader (existing tag)" in p.stderr
-    run(["tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], "-m", "-o", str(tmp_path / "again_m_h.bam"), "--host-ingest"])
-    assert _bam_stream(tmp_path / "again_m_d.bam") == _bam_stream(tmp_path / "again_m_h.bam")
+    # tagging the tagged file again with the same tag: the kept records carry it already -> the reference's merge rule (the found
+    # patterns and the items of the existing value, sorted, unique), on the device too
+    for extra in ([], ["-m"], ["-m", "--window-mb", "1"]):
+        p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], kmers[2][:-1] + "A", "-o", str(tmp_path / "again_d.bam"), *extra],
+                           capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
+        assert p.returncode == 0 and b"left to the host reader" not in p.stderr and b"windows on the device" in p.stderr
+        run(["tag", "-i", str(tmp_path / "all_d.bam"), "-s", kmers[0], kmers[1], kmers[2][:-1] + "A", "-o", str(tmp_path / "again_h.bam"), "--host-ingest",
+             *[e for e in extra if e in ("-m",)]])
+        assert _bam_stream(tmp_path / "again_d.bam") == _bam_stream(tmp_path / "again_h.bam")
+    # a field of the tag's name that is not a string: the window is handed to the host reader, which words the reference's refusal --
+    # in small windows after the windows in front of it have been written on the device
+    import gzip
+    raw_in = gzip.decompress(open(tmp_path / "in.bam", "rb").read())
+    cut_at = len(raw_in) - len(_bam_stream(tmp_path / "in.bam"))
+    recs_bytes = raw_in[cut_at:]
+    first_len = int.from_bytes(recs_bytes[:4], "little")
+    odd = bytearray(recs_bytes[:4 + first_len]) + b"kmi" + (7).to_bytes(4, "little")
+    odd[0:4] = (first_len + 7).to_bytes(4, "little")
+    (tmp_path / "odd.bam").write_bytes(_bgzf(raw_in + bytes(odd)))
+    for extra in ([], ["--window-mb", "1"], ["--host-ingest"]):
+        p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "odd.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "odd_out.bam"), *extra],
+                           capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
+        assert p.returncode == 1 and b"Invalid tag value format. Expected string value." in p.stderr
+        if extra == ["--window-mb", "1"]:
+            assert b"left to the host reader (existing tag)" in p.stderr
     # a truncated file: both paths end with the host reader's message
     raw = open(tmp_path / "in.bam", "rb").read()
-    import gzip
     text = gzip.decompress(raw)
     (tmp_path / "cut.bam").write_bytes(_bgzf(text[:len(text) - 11]))
     for extra in ([], ["--host-ingest"]):

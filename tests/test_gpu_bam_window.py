@@ -98,15 +98,16 @@ def make_records(rnd, n, patterns, lens=(150,), hit=0.2, alpha=b"ACGT", aux_kind
     return recs
 
 
-def expected(ob_m, patterns, recs, tag, logging, filter_matching, invert):
-    """oracle: keep, rows [(name, rec, pat, pos)], counters, output text of the kept records with their tag appended"""
+def expected(ob_m, patterns, recs, tag, logging, filter_matching, invert, existing=None):
+    """oracle: keep, rows [(name, rec, pat, pos)], counters, output text of the kept records with their tag appended
+    (existing: per record, the Z value of a field of that name the record already carries, or None)"""
     dec = [decode(r) for r in recs]
     keep, rows, c, found = ob.tag_records(ob_m, [s for _, s in dec], logging=logging, filter_matching=filter_matching, invert=invert)
     out = bytearray()
-    for r, k, f in zip(recs, keep, found):
+    for i, (r, k, f) in enumerate(zip(recs, keep, found)):
         if not k:
             continue
-        val = ob.tag_value(patterns, f)
+        val = ob.tag_value(patterns, f, existing[i] if existing and existing[i] else None)
         body = r[4:] + tag + b"Z" + val + b"\0"
         out += struct.pack("<i", len(body)) + body
     names = [(dec[rec][0], rec, pat, pos) for (_, rec, pat, pos) in rows]
@@ -230,14 +231,17 @@ def test_refusals(mk):
         members, _, _ = mk.bgzf_members(blob)
         return m.tag_bam_window(codec, b"", blob, members, last=True, **kw)
 
-    # a kept record that already has the tag: the host merges (Z) or bails (other types)
+    # a kept record with a field of the tag's name that is not a string (the reference bails), whose value is not plain ASCII (the
+    # reference checks UTF-8 first) or is very long: the host path's
     hit_seq = pats[0] + b"A" * 40
-    r = run(good + [bam_record(b"old", hit_seq, b"kmZ" + b"AAA,CCC\0")] + good)
+    r = run(good + [bam_record(b"old", hit_seq, b"kmi" + struct.pack("<i", 5))] + good)
     assert r["status"] == 4 and r["out"] == b""
-    r = run(good + [bam_record(b"old", hit_seq, b"kmi" + struct.pack("<i", 5))])
+    r = run(good + [bam_record(b"old", hit_seq, b"kmZ" + "AAA,\u00e9".encode() + b"\0")])
+    assert r["status"] == 4
+    r = run(good + [bam_record(b"old", hit_seq, b"kmZ" + b"ACGT," * 500 + b"\0")])
     assert r["status"] == 4
     # ... but not when that record is dropped (-v drops records with a hit; the reference never looks at a dropped record's tags)
-    r = run(good + [bam_record(b"old", hit_seq, b"kmZ" + b"AAA\0")], invert=True)
+    r = run(good + [bam_record(b"old", hit_seq, b"kmi" + struct.pack("<i", 5))], invert=True)
     assert r["status"] == 0
     # optional fields that do not parse
     r = run(good + [bam_record(b"odd", b"ACGT" * 10, b"XX?" + b"1234")])
@@ -268,6 +272,48 @@ def test_refusals(mk):
     with pytest.raises(mk.MerkurioError) as e:
         m.tag_bam_window(codec, b"", bytes(blob), members, last=True)
     assert e.value.code == mk.MK_E_CORRUPT
+    codec.close()
+
+
+def test_existing_tag_values_are_merged(mk):
+    """records that already carry the tag (src/cmd_tag.rs:470-485): the new field's value = the found patterns and the ','-separated
+    items of the FIRST field of that name, sort_unstable + dedup, joined -- unsorted values, duplicates, empty items, items equal to
+    found patterns, an empty value ("do nothing"), a second field of the same name (ignored); the old field stays in the record"""
+    rnd = random.Random(8)
+    pats = patterns31(mk, 30)
+    m, codec = mk.Matcher(pats, device=0), mk.Codec(0)
+    om = ob.Matcher(pats, True, 0, False)
+    values = [b"", b"ZZZ", b"TTT,AAA,CCC", b"AAA,AAA,AAA", b",,", b"x,", b",x", pats[3], pats[5] + b"," + pats[1], b"a," + pats[0] + b",B,b,A", b"ACGT" * 100,
+              b"0,00,000,0000", pats[2][:-1], pats[2] + b"A"]
+    recs, existing = [], []
+    for i in range(600):
+        s = bytearray(rnd.choice(b"ACGT") for _ in range(120))
+        for _ in range(rnd.randrange(0, 4)):
+            p = rnd.choice(pats[:8])
+            k = rnd.randrange(0, 120 - 31)
+            s[k:k + 31] = p
+        v = rnd.choice(values) if i % 3 else None
+        aux = b"NMC\x02"
+        if v is not None:
+            aux += b"kmZ" + v + b"\0"
+            if i % 7 == 0:
+                aux += b"kmZ" + b"second,field" + b"\0"  # (only the first field of that name is looked at)
+        aux += b"ASi" + struct.pack("<i", i)
+        recs.append(bam_record(b"e%d" % i, bytes(s), aux))
+        existing.append(v)
+    blob = _bgzf(b"".join(recs))
+    members, _, _ = mk.bgzf_members(blob)
+    for fm in (False, True):
+        keep, rows, c, out = expected(om, pats, recs, b"km", True, fm, False, existing=existing)
+        r = m.tag_bam_window(codec, b"", blob, members, last=True, logging=True, filter_matching=fm)
+        assert r["status"] == 0 and r["n_kept"] == sum(keep)
+        got = gzip.decompress(r["out"] + mk.bgzf_eof()) if r["out"] else b""
+        if got != out:  # (which record differs, for the failure message)
+            a, _ = split_records(got)
+            b, _ = split_records(out)
+            bad = [k for k, (x, y) in enumerate(zip(a, b)) if x != y][:3]
+            raise AssertionError(f"records {bad}: {[(a[k][-80:], b[k][-80:]) for k in bad]}")
+        assert r["rows"] == rows
     codec.close()
 
 
