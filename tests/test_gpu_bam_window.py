@@ -394,3 +394,53 @@ def test_reference_bam_fixture(mk):
         want = [f for f in fields[11:] if f.startswith(b"km:Z:")][0][5:]
         assert rec.endswith(b"kmZ" + want + b"\0")
     codec.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_windows_against_the_oracle(mk, seed):
+    """seeded differential test: random record shapes (lengths 0 ... 3 000, every optional-field type, existing values of the tag on some
+    records), member sizes, window cuts with the tail carried, piece sizes, filter flags, AC and BNDMq pattern sets -- the members the
+    device returns must inflate to the oracle's tagged records, rows and counters must agree"""
+    rnd = random.Random(1000 + seed)
+    few = rnd.random() < 0.3
+    if few:
+        pats = mk.parse_pattern_list(kmer_seq=[bytes(rnd.choice(b"ACGT") for _ in range(rnd.choice((5, 9, 21)))) for _ in range(rnd.randrange(1, 9))])
+    else:
+        pats = patterns31(mk, rnd.choice((20, 300)), seed=seed)
+    m, codec = mk.Matcher(pats, device=0), mk.Codec(0)
+    om = ob.Matcher(pats, m.use_ac, 0, False)
+    n = rnd.choice((1, 40, 700, 2500))
+    lens = rnd.choice(((150,), (0, 1, 2, 33, 150, 151), (100, 3000), (75,)))
+    recs = make_records(rnd, n, pats, lens=lens, hit=rnd.choice((0.0, 0.1, 0.9)), alpha=rnd.choice((b"ACGT", b"ACGTN", b"ACGTNRYKM=")))
+    existing = [None] * n
+    tag = rnd.choice((b"km", b"XK"))
+    if rnd.random() < 0.5:  # some records carry the tag already
+        for i in range(n):
+            if rnd.random() < 0.3:
+                v = rnd.choice((b"", b"AAA", b"T,A,T", pats[0], pats[-1] + b",zz", b",", b"b,a,,c"))
+                body = recs[i][4:] + tag + b"Z" + v + b"\0"
+                recs[i] = struct.pack("<i", len(body)) + body
+                existing[i] = v
+    text = b"".join(recs)
+    blob = _bgzf(text, block=rnd.choice((500, 7001, 65280)), level=rnd.choice((1, 6)))
+    members, _, _ = mk.bgzf_members(blob)
+    fm, inv = rnd.choice(((False, False), (True, False), (False, True)))
+    logging = rnd.random() < 0.7
+    keep, rows, c, out = expected(om, pats, recs, tag, logging, fm, inv, existing=existing)
+    step = rnd.choice((1, 3, 50, len(members)))
+    cuts = list(range(0, len(members), max(1, step))) + [len(members)]
+    res = run_windows(mk, m, codec, blob, members, cuts, tag=tag, logging=logging, filter_matching=fm, invert=inv,
+                      piece_bytes=rnd.choice((64, 300, 5000, 0)), block_bytes=rnd.choice((0, 1000, 40000)))
+    assert all(x["status"] == 0 for x in res), [x["status"] for x in res]
+    assert sum(x["n_rec"] for x in res) == n and sum(x["n_kept"] for x in res) == sum(keep)
+    got = b"".join(gzip.decompress(x["out"] + mk.bgzf_eof()) if x["out"] else b"" for x in res)
+    assert got == out
+    if logging:
+        got_rows, base = [], 0
+        for x in res:
+            got_rows += [(nm, rec + base, pat, pos) for (nm, rec, pat, pos) in x["rows"]]
+            base += x["n_rec"]
+        assert got_rows == rows
+        assert sum(x["counters"]["hits"][0] for x in res) == c["hits"][0] and sum(x["counters"]["records_hit"][0] for x in res) == c["records_hit"][0]
+        assert np.array_equal(np.sum([x["counters"]["pattern_hit_counts"] for x in res], axis=0), c["pattern_hit_counts"])
+    codec.close()
