@@ -728,8 +728,10 @@ def other_configs(mk, lib, torch, dev, dev_index, m0, mate0, n_rec0, L0, seed, s
                 "kernel": m0.kernel_name, "steps": steps, "launches_per_step": 2, "ms_per_step": round(dt / steps * 1e3, 4),
                 "value_gbases_per_s": round(2 * n3 * L0 * steps / dt / 1e9, 1), "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes_per_launch": algo, "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "pairs_kept": int(d_keep[:n3].sum().item()), "traffic": None,
-                "traffic_source": "no committed PMC profile of this workload (tools/profile_gpu.sh writes one per workload it is run on)"})
+                "pairs_kept": int(d_keep[:n3].sum().item())})
+    res[-1]["traffic"], res[-1]["traffic_source"] = measured_traffic(m0.kernel_name, n3, L0, len(m0.patterns), 100)
+    if res[-1]["traffic"] is None and not res[-1]["traffic_source"]:
+        res[-1]["traffic_source"] = "no committed PMC profile of this workload (tools/profile_gpu.sh writes one per workload it is run on)"
     del pair, d_keep
 
     m, a, b, c, n_pat = fresh(10_000_000, 150, 1024, 31, True, 100, 11)
