@@ -806,15 +806,24 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
     // BAM -> BAM (or no output at all) on one device: the records stay on the device between inflate and deflate
     // (tag_windows.cpp; two windows in flight, each on a handle of its own); false: a window was not for the device and the loop
     // below takes the input from there
-    mk_matcher *second = nullptr;
-    if (sam.bam_on_bgzf() && (to_bam || a.suppress_output) && !a.host_codec && !a.host_ingest && ms.size() == 1) {
+    std::vector<mk_matcher *> seconds;
+    if (sam.bam_on_bgzf() && (to_bam || a.suppress_output) && !a.host_codec && !a.host_ingest) {
         if (to_bam) bw.use_device(devs[0]);
         // (240 MiB of text: the tagged records of a window then fill one round of the deflate kernel's 4 096 resident waves, not one and a bit)
-        const uint64_t dev_window = a.window_mb_given ? window_bytes : (240ull << 20);
-        bool ac2 = false;
-        second = make_matcher(a, pats, &ac2, devs[0]);
-        mk_matcher *both[2] = {m, second};
-        device_done = tag_bam_windows_on_device(a, sam, both, 2, devs[0], lg, pats, in_name, to_bam ? &bw : nullptr, c, counts, dev_window);
+        // (an explicit --window-mb is honoured up to 2 GiB: a window's text, head included, has to stay below 4 GiB on the device)
+        const uint64_t dev_window = a.window_mb_given ? std::min<uint64_t>(window_bytes, 2048ull << 20) : (240ull << 20);
+        seconds.assign(ms.size(), nullptr);
+        run_threads(ms.size(), [&](size_t d) {
+            bool ac2 = false;
+            seconds[d] = make_matcher(a, pats, &ac2, devs[d]);
+        });
+        // window k runs on handle k mod 2N: devices in turn, and two windows per device in flight.  One device: the job's counters;
+        // several: the per-device vectors that RCCL sums at the end
+        std::vector<TagHandle> handles;
+        for (int rep = 0; rep < 2; ++rep)
+            for (size_t d = 0; d < ms.size(); ++d)
+                handles.push_back(TagHandle{rep ? seconds[d] : ms[d], devs[d], ms.size() == 1 ? &c : &dev_c[d], ms.size() == 1 ? &counts : &dev_counts[d]});
+        device_done = tag_bam_windows_on_device(a, sam, handles, lg, pats, in_name, to_bam ? &bw : nullptr, dev_window);
         tm.mark(device_done ? "windows on the device" : "windows on the device (the rest: host reader)");
     }
     // (the first window is small: nothing can run beside its read; the later, large ones are read beside their predecessors)
@@ -896,7 +905,7 @@ int run_tag(const TagArgs &a, const std::vector<std::string> &argv) {
         lg.json.finalize(meta, cj, sum, nullptr);
     }
     release_matchers(ms);
-    if (second) release_matchers({second});
+    release_matchers(seconds);
     return 0;
 }
 

@@ -98,10 +98,17 @@ struct WindowExtract {
 
 // tag_windows.cpp: BAM input whose records stay on the device (mk_tag_bam_window); bw == nullptr: no output (-S).
 // true: the whole input has been processed; false: `sam` has been positioned where the host reader has to carry on.
+// handles: matchers with the device they live on and where their windows' counters are added (two handles per device keep two
+// windows per device in flight; window k runs on handle k mod handles.size()).
 struct SamFile;
 struct BamWriter;
-// handles[0, n_handles): matchers on `device`; with two of them two windows are in flight.
-bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const *handles, int n_handles, int device, Loggers &lg, const Patterns &pats,
-                               const std::string &in_name, BamWriter *bw, mk_counters &c, std::vector<uint32_t> &counts, uint64_t window_bytes);
+struct TagHandle {
+    mk_matcher *m;
+    int device;
+    mk_counters *counters;
+    std::vector<uint32_t> *pattern_counts;
+};
+bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, const std::vector<TagHandle> &handles, Loggers &lg, const Patterns &pats,
+                               const std::string &in_name, BamWriter *bw, uint64_t window_bytes);
 
 }  // namespace cli

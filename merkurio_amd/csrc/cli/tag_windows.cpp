@@ -8,7 +8,7 @@
 // is the window's last unfinished record (the next window's head), the log rows with their record names, and finished BGZF
 // members that go to the file as they are.
 //
-// Two windows are in flight, each on a handle (and stream) of its own: window k + 1 needs only the TAIL of window k -- known right
+// Two windows per device are in flight, each on a handle (and stream) of its own (--gpus N: consecutive windows on different devices): window k + 1 needs only the TAIL of window k -- known right
 // after k's record index (mk_bam_window::on_tail) -- so its upload and inflate run beside k's scan, tag, deflate and download, and
 // its members are copied into page-locked memory (a mapped file is not a DMA source) beside all of that.  Results are emitted in
 // window order; the writer thread writes window k - 1 meanwhile.
@@ -94,8 +94,8 @@ void on_tail(void *ctx, const uint8_t *tail, uint64_t n_tail) {
 
 }  // namespace
 
-bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const *handles, int n_handles, int device, Loggers &lg, const Patterns &pats,
-                               const std::string &in_name, BamWriter *bw, mk_counters &c, std::vector<uint32_t> &counts, uint64_t window_bytes) {
+bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, const std::vector<TagHandle> &handles, Loggers &lg, const Patterns &pats,
+                               const std::string &in_name, BamWriter *bw, uint64_t window_bytes) {
     const WindowSource &src = sam.source();
     const size_t n_mem = src.n_bgzf_members();
     const uint8_t *file = src.file_bytes();
@@ -131,15 +131,18 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
         wins.push_back(std::move(W));
     }
     const size_t n_win = wins.size();
-    const size_t n_workers = std::max<size_t>(1, std::min<size_t>((size_t)n_handles, std::min<size_t>(2, n_win)));
+    // (window k runs on handle k mod n_workers: with the handles of several devices in a row, consecutive windows go to different devices)
+    const size_t n_workers = std::max<size_t>(1, std::min<size_t>(handles.size(), n_win));
     double t_dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // (BAM-shaped text deflates to a third; a window that does not fit is done again with the size it asked for)
     auto out_guess = [](uint64_t text) { return text / 3 + (4u << 20); };
 
     auto worker = [&](size_t id) {
-        mk_matcher *m = handles[id];
+        mk_matcher *m = handles[id].m;
+        mk_counters &c = *handles[id].counters;
+        std::vector<uint32_t> &counts = *handles[id].pattern_counts;
         mk_codec *codec = nullptr;
-        if (mk_codec_create(device, &codec) != MK_OK) bail(std::string("Error during BAM record parsing: ") + mk_last_error());
+        if (mk_codec_create(handles[id].device, &codec) != MK_OK) bail(std::string("Error during BAM record parsing: ") + mk_last_error());
         struct CodecGuard {
             mk_codec *c;
             ~CodecGuard() {
@@ -186,7 +189,7 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
             w.tag[0] = (uint8_t)a.tag[0], w.tag[1] = (uint8_t)a.tag[1];
             w.on_tail = on_tail, w.on_tail_ctx = &tctx;
             mk_counters wc;
-            std::vector<uint32_t> wcounts(lg.active ? counts.size() : 0, 0);
+            std::vector<uint32_t> wcounts(lg.active ? pats.list.size() : 0, 0);
             uint32_t status = 0;
             int rc;
             for (;;) {
@@ -235,7 +238,7 @@ bool tag_bam_windows_on_device(const TagArgs &a, SamFile &sam, mk_matcher *const
                 return;
             }
             lk.unlock();
-            // (only the worker whose turn it is gets here: the job's counters, the loggers and the writer are its alone)
+            // (only the worker whose turn it is gets here: the counters of its device, the loggers and the writer are its alone)
             c.nb_records_tot += wc.nb_records_tot, c.nb_bases += wc.nb_bases, c.nb_hits_tot[0] += wc.nb_hits_tot[0];
             c.nb_records_hit[0] += wc.nb_records_hit[0], c.nb_records_extracted += wc.nb_records_extracted;
             for (size_t i = 0; i < wcounts.size(); ++i) counts[i] += wcounts[i];

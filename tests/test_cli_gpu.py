@@ -744,6 +744,15 @@ def test_tag_bam_records_resident_on_the_device(tmp_path):
             assert _bam_stream(tmp_path / f"{name}_{tagd}.bam") == host
             assert log_body(tmp_path / f"{name}_{tagd}.log") == log_body(tmp_path / f"{name}_h.log")
             check_json(tmp_path / f"{name}_{tagd}.json", tmp_path / f"{name}_h.json")
+    # --gpus 2 (on a one-GPU box both handles' devices are the same card: four windows in flight): windows dealt to the devices in turn,
+    # counters per device summed at the end -- the same stream, the same logs
+    p = subprocess.run([BIN, "tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / "g2.bam"), "-l", str(tmp_path / "g2.log"),
+                        "-j", str(tmp_path / "g2.json"), "--gpus", "2", "--window-mb", "1"], capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    assert re.search(rb"windows on the device \(4 in flight\)", p.stderr) and b"left to the host reader" not in p.stderr
+    assert _bam_stream(tmp_path / "g2.bam") == _bam_stream(tmp_path / "all_h.bam")
+    assert log_body(tmp_path / "g2.log") == log_body(tmp_path / "all_h.log")
+    check_json(tmp_path / "g2.json", tmp_path / "all_h.json")
     # -S: no output, logs only
     run(["tag", "-i", str(tmp_path / "in.bam"), "-f", str(tmp_path / "k.txt"), "-S", "-l", str(tmp_path / "s_d.log")])
     assert log_body(tmp_path / "s_d.log") == log_body(tmp_path / "all_h.log")
