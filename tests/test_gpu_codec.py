@@ -24,10 +24,18 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=[0, 1, 2, 3, 4, 5, 6], ids=["kernel-by-size", "lane-per-member", "wave-per-member", "wave-8k-ring", "wave-16k-ring", "wave-4k-ring", "wave-2k-ring"])
 def codec(request):
-    """every test runs three times: the inflate kernel chosen per call (a wave per member for small calls, a lane per member for
-    large ones: bgzf_inflate.hip), and each of the two forced (mk_codec_set_inflate_kernel)"""
+    """every inflate test runs seven times: the inflate kernel chosen per call (a wave per member with a 4 KiB ring for calls of up to
+    ~19 000 members, a lane per member above: bgzf_inflate.hip), and each of the six variants forced (mk_codec_set_inflate_kernel)"""
     c = mk.Codec()
     c.set_inflate_kernel(request.param)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def plain_codec():
+    """a handle for the tests that do not touch the BGZF inflate kernels (the deflate side, the parallel gunzip)"""
+    c = mk.Codec()
     yield c
     c.close()
 
@@ -89,7 +97,8 @@ def test_deflate_sizes_around_a_block_and_a_device_pass(codec):
     assert len(blob) == len(noise) + 3 * 31
 
 
-def test_deflate_of_pieces_equals_deflate_of_their_concatenation(codec):
+def test_deflate_of_pieces_equals_deflate_of_their_concatenation(plain_codec):
+    codec = plain_codec
     """mk_bgzf_deflate_pieces (the BAM writer's per-thread record buffers): the pieces are joined on the device only"""
     rng = random.Random(23)
     data = bam_like(9000, seed=4)
@@ -107,7 +116,8 @@ def test_deflate_of_pieces_equals_deflate_of_their_concatenation(codec):
     assert codec.deflate_pieces([]) == b"" and codec.deflate_pieces([b"", b""]) == b""
 
 
-def test_deflate_compresses_like_a_fast_zlib_level(codec):
+def test_deflate_compresses_like_a_fast_zlib_level(plain_codec):
+    codec = plain_codec
     """not a parity claim -- a guard against a parse that stops finding matches: within 25 % of zlib level 1 on BAM-like
     records, FASTQ text and a run-heavy block"""
     for name, data in (("bam", bam_like(40000)), ("bam const qual", bam_like(40000, const_qual=True)), ("fastq", corpora()["fastq"] * 8),
@@ -323,7 +333,8 @@ def _fastq_text(n, seed=3):
     return "".join(out).encode()
 
 
-def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(codec):
+def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(plain_codec):
+    codec = plain_codec
     """tests/data/sample.fasta.gz (the reference's own: one small member, a single piece) and 30 MB of FASTQ as gzip -1 / -6 / -9 wrote
     it (hundreds of pieces: block starts found on the device, pieces decoded side by side, place-holders resolved): the text zlib gives"""
     blob = open(os.path.join(GOLDEN, "data/sample.fasta.gz"), "rb").read()
@@ -345,7 +356,8 @@ def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(codec):
     assert L.mk_gzip_text_read(codec._h, n - 3, out.ctypes.data, 4) == mk.MK_E_INVALID_ARG
 
 
-def test_gunzip_shapes_the_device_takes_or_hands_back(codec):
+def test_gunzip_shapes_the_device_takes_or_hands_back(plain_codec):
+    codec = plain_codec
     """streams of every block type and of many flush points; what is not for this path comes back as 'not taken' (None) and never as a
     wrong text: several members, a damaged stream, a stream the buffers do not hold"""
     rnd = random.Random(8)
