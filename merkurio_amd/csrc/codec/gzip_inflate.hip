@@ -2,9 +2,9 @@
 // pieces of gzip_segments.hpp, which says what the scheme is.  Replaces needletail's gzip reader under `merkurio extract`
 // (src/cmd_extract.rs:281-282) for files plain gzip wrote; mk_gzip_inflate_device (codec_host.cpp) drives it.
 //
-//   mk_gzip_find_kernel      a wave per nominal chunk of the stream: 64 bit positions per step through seg_header_plausible (registers
-//                            only; almost every position fails within its first dwords), the rare survivor confirmed by ONE lane that
-//                            decodes its block dry and looks for the next header (LDS: one decoder's tables per wave)
+//   mk_gzip_find_kernel      a wave per nominal chunk of the stream: 64 bit positions per step through the three levels of the header
+//                            test, each level on full waves (survivors queued in LDS), the rare survivor of all three confirmed by ONE
+//                            lane that decodes its block dry and looks for the next header (LDS: one decoder's tables per wave)
 //   mk_gzip_prefix_kernel    the place-holders in front of every segment's symbol buffer
 //   mk_gzip_segments_kernel  a lane per segment (1 .. 64 per wave, as few as the part's residency allows: the lanes of a wave move in
 //                            lockstep): inflate_segment into 16-bit symbols; tables in LDS, 836 B per lane
@@ -19,31 +19,100 @@
 
 namespace mkz {
 
+// The test of a position has three levels of very different cost and pass rate (gzip_segments.hpp); run position by position, one
+// lane of 64 is in the expensive one at any time and the others wait for it (53-58 ms of a 156 ms call).  Here the levels are run
+// on FULL waves: level 1 on all 64 positions of a step from three wave-uniform dwords (no per-lane stream reader), its survivors
+// queued in LDS; level 2 (the code-length code) on 64 queued positions at a time, its survivors queued again; level 3 (all code
+// lengths) + confirmation on what gathers there, at the latest every kDeepEvery steps.  Any confirmed start in the range will do:
+// the pieces are cut wherever starts were found.
+constexpr uint32_t kFindQueue = 192, kDeepEvery = 128;
+
 __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restrict__ in, uint64_t n_in, uint64_t chunk_bytes, uint32_t n_chunks,
                                                           uint64_t search_bytes, unsigned long long *__restrict__ starts) {
     __shared__ uint16_t t[kLaneTableU16];
+    __shared__ uint32_t q1[kFindQueue], q2[kFindQueue];  // bit positions relative to bit0
     const uint32_t c = blockIdx.x + 1;  // (chunk 0 starts where the stream does)
     if (c >= n_chunks) return;
     const uint32_t lane = threadIdx.x;
     const uint64_t bit0 = (uint64_t)c * chunk_bytes * 8;
     const uint64_t bit1 = min(bit0 + search_bytes * 8, n_in * 8);
     unsigned long long found = ~0ull;
-    for (uint64_t base = bit0; base < bit1 && found == ~0ull; base += 64) {
-        const uint64_t bit = base + lane;
-        const bool pass = bit < bit1 && seg_header_plausible(in, n_in, bit);
-        uint64_t m = __ballot(pass);
-        while (m && found == ~0ull) {  // the survivors of this step, lowest position first: confirmed by their own lane, one at a time
-            const uint32_t l = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            int ok = 0;
-            if (lane == l) ok = seg_confirm_block_start(in, n_in, bit, t) ? 1 : 0;
-            ok = __shfl(ok, (int)l);
-            if (ok) found = base + l;
+    uint32_t n1 = 0, n2 = 0, steps = 0;  // (wave-uniform)
+    auto push = [&](uint32_t *q, uint32_t &n, bool mine, uint32_t value) {
+        const uint64_t m = __ballot(mine);
+        if (mine) q[n + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = value;
+        n += (uint32_t)__popcll(m);
+    };
+    // One loop, one place per level (each of the two expensive tests is instantiated once): what to do next is decided from the
+    // queues' fill -- the deepest level that has a full wave of work (or, once the range is exhausted, any work) goes first.
+    uint64_t base = bit0;
+    bool draining = false, deep_due = false;
+    while (found == ~0ull) {
+        if (n2 >= 64 || (n2 && (draining ? n1 == 0 : deep_due))) {
+            // level 3 + confirmation of the positions in q2 (at most 127 are there: the first 64 now)
+            const uint32_t take = min(n2, 64u);
+            const bool have = lane < take;
+            const uint32_t rel = have ? q2[lane] : 0u;
+            const uint64_t bit = bit0 + rel;
+            const bool pass = have && seg_header_plausible(in, n_in, bit);
+            uint64_t m = __ballot(pass);
+            while (m && found == ~0ull) {  // the survivors, lowest queue slot first: confirmed by their own lane, one at a time
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                int ok = 0;
+                if (lane == l) ok = seg_confirm_block_start(in, n_in, bit, t) ? 1 : 0;
+                ok = __shfl(ok, (int)l);
+                if (ok) found = bit0 + (uint32_t)__shfl((int)rel, (int)l);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rest = n2 - take;
+            uint32_t a = 0;
+            if (lane < rest) a = q2[take + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) q2[lane] = a;
+            n2 = rest;
+            deep_due = false;
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
+        if (n1 >= 64 || (n1 && draining)) {
+            // level 2 on the first min(n1, 64) positions of q1
+            const uint32_t take = min(n1, 64u);
+            const bool have = lane < take;
+            const uint32_t rel = have ? q1[lane] : 0u;
+            const bool pass = have && seg_header_cl_plausible(in, n_in, bit0 + rel);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rest = n1 - take;  // (moves to the queue's front: at most 63 entries)
+            uint32_t a = 0;
+            if (lane < rest) a = q1[take + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) q1[lane] = a;
+            n1 = rest;
+            push(q2, n2, pass, rel);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        if (base < bit1) {
+            // level 1: the 13 bits at (base + lane) out of the 96 bits that hold all 64 of them
+            const uint64_t byte = base >> 3;
+            const uint32_t w0 = byte <= n_in + 8 ? load_le32(in + byte) : 0u, w1 = byte + 4 <= n_in + 8 ? load_le32(in + byte + 4) : 0u,
+                           w2 = byte + 8 <= n_in + 8 ? load_le32(in + byte + 8) : 0u;
+            const uint32_t sh = (uint32_t)(base & 7) + lane;  // 0 .. 70
+            const uint64_t lo = (uint64_t)w0 | (uint64_t)w1 << 32, hi = (uint64_t)w1 | (uint64_t)w2 << 32;
+            const uint32_t v = (uint32_t)((sh < 32 ? lo >> sh : hi >> (sh - 32)) & 0x1fffu);
+            const uint64_t bit = base + lane;
+            const bool pass = bit < bit1 && bit + 64 <= n_in * 8 && seg_header_bits_plausible(v);
+            push(q1, n1, pass, (uint32_t)(bit - bit0));
+            __builtin_amdgcn_wave_barrier();
+            base += 64;
+            if ((++steps % kDeepEvery) == 0) deep_due = true;
+            continue;
+        }
+        if (draining) break;  // the range is exhausted and both queues are empty
+        draining = true;
     }
     if (lane == 0) starts[c] = found;
 }
-
 __global__ __launch_bounds__(256) void mk_gzip_prefix_kernel(uint16_t *__restrict__ sym, const unsigned long long *__restrict__ seg_off, uint32_t n_seg) {
     const uint32_t j = blockIdx.y;
     if (j >= n_seg) return;

@@ -165,6 +165,28 @@ MKZ_HD void seg_fixed_tables(uint16_t *t) {
     for (uint32_t k = 0; k < 32; ++k) t[kOffDSorted + k] = (uint16_t)k;
 }
 
+// The first two levels of that test on their own (the search kernel runs them on all positions / on the survivors, so that the lanes of
+// a wave do the same work at the same time).  Level 1: BFINAL = 0, BTYPE = dynamic, HLIT / HDIST in range -- the 13 bits `v` at the
+// position (1 in 9 passes).  Level 2: the code-length code is complete and not empty (~1 in 100 of those).
+MKZ_HD bool seg_header_bits_plausible(uint32_t v) { return (v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u; }
+MKZ_HD bool seg_header_cl_plausible(const uint8_t *in, uint64_t n_in, uint64_t bit) {
+    if (bit + 64 > n_in * 8) return false;
+    SegReader r;
+    r.in = in, r.n_in = n_in;
+    sr_seek(r, bit);
+    if (!seg_header_bits_plausible((uint32_t)r.bitbuf)) return false;
+    const uint32_t hclen = ((uint32_t)(r.bitbuf >> 13) & 15u) + 4;
+    sr_take(r, 17);
+    uint64_t cl = 0;
+    for (uint32_t i = 0; i < hclen; ++i) {
+        sr_need32(r);
+        cl |= (uint64_t)((uint32_t)r.bitbuf & 7u) << (3 * cl_order_at(i));
+        sr_take(r, 3);
+    }
+    ClCode clc;
+    return cl != 0 && cl_build(cl, clc) == 0;
+}
+
 // is `bit` the start of a non-final dynamic block, as far as its header says?  (registers only)
 MKZ_HD bool seg_header_plausible(const uint8_t *in, uint64_t n_in, uint64_t bit) {
     if (bit + 64 > n_in * 8) return false;

@@ -35,11 +35,21 @@ int main(int argc, char **argv) {
     std::vector<uint64_t> starts{0};
     for (uint64_t cut = chunk; cut < n_in; cut += chunk) {
         uint64_t found = ~0ull;
-        for (uint64_t bit = cut * 8; bit < (cut + 4 * chunk) * 8 && bit + 64 < n_in * 8; ++bit)
-            if (mkz::seg_header_plausible(in.data(), n_in, bit) && mkz::seg_confirm_block_start(in.data(), n_in, bit, t.data())) {
+        for (uint64_t bit = cut * 8; bit < (cut + 4 * chunk) * 8 && bit + 64 < n_in * 8; ++bit) {
+            // the levels the search kernel runs on their own must be necessary conditions of the whole test, position by position
+            uint32_t v = 0;
+            for (int k = 0; k < 13; ++k) v |= (uint32_t)((in[(bit + k) >> 3] >> ((bit + k) & 7)) & 1u) << k;
+            const bool l1 = mkz::seg_header_bits_plausible(v), l2 = mkz::seg_header_cl_plausible(in.data(), n_in, bit);
+            const bool l3 = mkz::seg_header_plausible(in.data(), n_in, bit);
+            if ((l2 && !l1) || (l3 && !l2)) {
+                fprintf(stderr, "levels of the header test disagree at bit %llu: %d %d %d\n", (unsigned long long)bit, (int)l1, (int)l2, (int)l3);
+                return 3;
+            }
+            if (l3 && mkz::seg_confirm_block_start(in.data(), n_in, bit, t.data())) {
                 found = bit;
                 break;
             }
+        }
         if (found != ~0ull && found > starts.back()) starts.push_back(found);
     }
     fprintf(stderr, "segments %zu\n", starts.size());
