@@ -312,8 +312,7 @@ int mk_extract_single(mk_matcher *m, const uint8_t *seq, const uint64_t *off, ui
 namespace mk {
 void launch_ingest_count(const uint8_t *d_text, uint64_t n, uint32_t *d_block_cnt, uint32_t *d_total, hipStream_t st);
 void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start,
-                           uint8_t *d_line_info, uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status,
-                           hipStream_t st);
+                           uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status, hipStream_t st);
 void launch_ingest_lines(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start, hipStream_t st);
 void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st);
 void launch_ingest_gather(const uint8_t *d_text, const uint32_t *d_seq_start, const uint32_t *d_seq_len, const unsigned long long *d_off,
@@ -505,19 +504,18 @@ int window_index(mk_matcher *m, uint32_t format, bool ends_at_record, WindowSide
     }
     const uint64_t n_rec = n_lines / 4;
     W.n_avail = n_rec;
-    // workspace: line starts | record starts (+1) | sequence starts | sequence lengths | tile sums | line info bytes
+    // workspace: line starts | record starts (+1) | sequence starts | sequence lengths | tile sums
     const size_t n_tiles = n_rec / ingest_scan_tile() + 2;
-    const size_t ws = ((size_t)total_nl + 4 + 3 * (n_rec + 2) + 8) * 4 + n_tiles * 8 + 64 + ((size_t)total_nl + 8);
+    const size_t ws = ((size_t)total_nl + 4 + 3 * (n_rec + 2) + 8) * 4 + n_tiles * 8 + 64;
     if ((rc = ensure_device(&T.d_ing_b, &T.d_ing_b_cap, ws))) return rc;
     W.d_line = (uint32_t *)T.d_ing_b;
     W.d_rec_start = W.d_line + total_nl + 4;
     W.d_seq_start = W.d_rec_start + n_rec + 2;
     W.d_seq_len = W.d_seq_start + n_rec + 2;
     W.d_tile = (unsigned long long *)(((uintptr_t)(W.d_seq_len + n_rec + 2) + 15) & ~(uintptr_t)15);
-    uint8_t *d_line_info = (uint8_t *)(W.d_tile + n_tiles);
     const uint32_t st_init[3] = {0u, 0xFFFFFFFFu, 0u};
     if (hipMemcpyAsync(W.d_st, st_init, sizeof(st_init), hipMemcpyHostToDevice, st) != hipSuccess) return fail(MK_E_HIP, "copy failed");
-    launch_ingest_records(d_text, n_text, W.d_block, W.d_total, W.d_line, d_line_info, n_rec, W.d_rec_start, W.d_seq_start, W.d_seq_len, W.d_st, st);
+    launch_ingest_records(d_text, n_text, W.d_block, W.d_total, W.d_line, n_rec, W.d_rec_start, W.d_seq_start, W.d_seq_len, W.d_st, st);
     uint32_t st_host[3] = {0, 0, 0};
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(st_host, W.d_st, sizeof(st_host), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)

@@ -97,13 +97,8 @@ __global__ __launch_bounds__(1024) void mk_ingest_scan_blocks_kernel(uint32_t *_
 
 // line_start[k] = first byte of line k (line 0 starts at 0; a text that ends in '\n' has an empty last "line" at n);
 // one more entry behind the last: n + 1, the virtual newline that ends a text without a final '\n'
-// line_info (may be null): per line start k, what the record kernel wants to know of the text there, so that it never has to go
-// back to it (r05: its four scattered reads per record were 0.57 ms per 3 M records, the furthest below the roofline of the window
-// kernels): bit 0 = the line's first byte is '@', bit 1 = it is '+', bit 2 = the line END in front of it is "\r\n" (for the entry
-// behind the last line: the text's last byte is '\r').
 __global__ __launch_bounds__(kIngestThreads) void mk_ingest_lines_kernel(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ block_off,
-                                                                         const uint32_t *__restrict__ total, uint32_t *__restrict__ line_start,
-                                                                         uint8_t *__restrict__ line_info) {
+                                                                         const uint32_t *__restrict__ total, uint32_t *__restrict__ line_start) {
     __shared__ uint32_t wave_sum[4];
     const uint64_t pos = (uint64_t)blockIdx.x * kIngestBlockBytes + threadIdx.x * kIngestBytesPerThread;
     uint32_t w[16];
@@ -129,32 +124,18 @@ __global__ __launch_bounds__(kIngestThreads) void mk_ingest_lines_kernel(const u
             while (mk_) {
                 const uint32_t b = (uint32_t)__ffs(mk_) - 1u;  // bit 7 of the byte
                 mk_ &= mk_ - 1;
-                const uint32_t at = 4 * d + (b >> 3);  // the newline's place among this thread's 64 bytes
-                if (line_info) {
-                    // the byte behind the newline and the one in front of it: in this thread's registers unless the newline is its last /
-                    // first byte
-                    const uint32_t nxt = at + 1 < 64 ? (w[(at + 1) >> 2] >> (8 * ((at + 1) & 3))) & 0xFFu : (pos + 64 < n ? text[pos + 64] : 0u);
-                    const uint32_t prv = at > 0 ? (w[(at - 1) >> 2] >> (8 * ((at - 1) & 3))) & 0xFFu : (pos > 0 ? text[pos - 1] : 0u);
-                    line_info[k] = (uint8_t)((nxt == '@' ? 1u : 0u) | (nxt == '+' ? 2u : 0u) | (prv == '\r' ? 4u : 0u));
-                }
-                line_start[k++] = (uint32_t)(pos + at + 1);
+                line_start[k++] = (uint32_t)(pos + 4 * d + (b >> 3) + 1);
             }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         line_start[0] = 0;
         line_start[*total + 1] = (uint32_t)(n + 1);
-        if (line_info) {
-            const uint32_t first = n ? text[0] : 0u;
-            line_info[0] = (uint8_t)((first == '@' ? 1u : 0u) | (first == '+' ? 2u : 0u));
-            line_info[*total + 1] = (uint8_t)((n && text[n - 1] == '\r') ? 4u : 0u);
-        }
     }
 }
 
-// st[0] status bits, st[1] smallest, st[2] largest sequence length.  Reads the line table and its info bytes only (the text is not
-// touched: mk_ingest_lines_kernel has looked at it).
-__global__ __launch_bounds__(256) void mk_ingest_records_kernel(uint64_t n, const uint32_t *__restrict__ line_start, const uint8_t *__restrict__ line_info,
+// st[0] status bits, st[1] smallest, st[2] largest sequence length
+__global__ __launch_bounds__(256) void mk_ingest_records_kernel(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ line_start,
                                                                uint64_t n_rec, uint32_t *__restrict__ rec_start, uint32_t *__restrict__ seq_start,
                                                                uint32_t *__restrict__ seq_len, uint32_t *__restrict__ st) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,16 +146,14 @@ __global__ __launch_bounds__(256) void mk_ingest_records_kernel(uint64_t n, cons
     if (live) {
         const uint32_t l0 = line_start[4 * i], l1 = line_start[4 * i + 1], l2 = line_start[4 * i + 2], l3 = line_start[4 * i + 3],
                        l4 = line_start[4 * i + 4];
-        const uint32_t i0 = line_info[4 * i], i2 = line_info[4 * i + 2], i4 = line_info[4 * i + 4];
-        // line k is [l_k, l_{k+1} - 1) without its '\n'; a '\r' in front of the '\n' belongs to the line end.  (The entry behind the
-        // text's last line stands for a virtual newline at n: its '\r' bit looks at the text's last byte.)
+        // line k is [l_k, l_{k+1} - 1) without its '\n'; a '\r' in front of the '\n' belongs to the line end
         uint32_t e1 = l2 - 1, e3 = l4 - 1;
-        if (e1 > l1 && (i2 & 4u)) --e1;
-        if (e3 > l3 && (i4 & 4u)) --e3;
+        if (e1 > l1 && text[e1 - 1] == '\r') --e1;
+        if (e3 > l3 && e3 - 1 < n && text[e3 - 1] == '\r') --e3;
         len = e1 - l1;
-        bad |= !(i0 & 1u);  // '@'
+        bad |= text[l0] != '@';
         bad |= l1 - l0 < 2;  // "@\n": no id at all is left to the host reader
-        bad |= (l3 - l2 < 2) || !(i2 & 2u);  // '+'
+        bad |= (l3 - l2 < 2) || text[l2] != '+';
         bad |= (e3 - l3) != len;
         rec_start[i] = l0;
         seq_start[i] = l1;
@@ -187,9 +166,11 @@ __global__ __launch_bounds__(256) void mk_ingest_records_kernel(uint64_t n, cons
         mx = max(mx, (uint32_t)__shfl_down(mx, o));
     }
     if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&st[0], 1u);
+    // (47 000 waves of a 3 M-record window, two words: the atomics only where they would change something -- reads of one length
+    // stop issuing them after the first waves; the plain loads may be stale, which only costs an atomic that changes nothing)
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&st[1], mn);
-        atomicMax(&st[2], mx);
+        if (mn < __atomic_load_n(&st[1], __ATOMIC_RELAXED)) atomicMin(&st[1], mn);
+        if (mx > __atomic_load_n(&st[2], __ATOMIC_RELAXED)) atomicMax(&st[2], mx);
     }
 }
 
@@ -453,7 +434,7 @@ void launch_ingest_fasta_emit(const uint8_t *d_text, uint64_t n, const uint32_t 
 // the line table alone (FASTA: no record kernel follows it)
 void launch_ingest_lines(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start, hipStream_t st) {
     const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
-    hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start, (uint8_t *)nullptr);
+    hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start);
 }
 
 // flags |= other (paired windows: a pair is kept if either mate hits, src/cmd_extract.rs:600-606)
@@ -478,15 +459,13 @@ void launch_ingest_count(const uint8_t *d_text, uint64_t n, uint32_t *d_block_cn
     hipLaunchKernelGGL(mk_ingest_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d_block_cnt, n_blocks, d_total);
 }
 
-// d_line_info: one byte per line table entry (total newlines + 2)
 void launch_ingest_records(const uint8_t *d_text, uint64_t n, const uint32_t *d_block_off, const uint32_t *d_total, uint32_t *d_line_start,
-                           uint8_t *d_line_info, uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status,
-                           hipStream_t st) {
+                           uint64_t n_rec, uint32_t *d_rec_start, uint32_t *d_seq_start, uint32_t *d_seq_len, uint32_t *d_status, hipStream_t st) {
     const uint32_t n_blocks = (uint32_t)((n + kIngestBlockBytes - 1) / kIngestBlockBytes);
-    hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start, d_line_info);
+    hipLaunchKernelGGL(mk_ingest_lines_kernel, dim3(n_blocks), dim3(kIngestThreads), 0, st, d_text, n, d_block_off, d_total, d_line_start);
     // (n_rec + 1 lanes: the last one writes the end of the records)
-    hipLaunchKernelGGL(mk_ingest_records_kernel, dim3((unsigned)((n_rec + 1 + 255) / 256)), dim3(256), 0, st, n, d_line_start, (const uint8_t *)d_line_info, n_rec,
-                       d_rec_start, d_seq_start, d_seq_len, d_status);
+    hipLaunchKernelGGL(mk_ingest_records_kernel, dim3((unsigned)((n_rec + 1 + 255) / 256)), dim3(256), 0, st, d_text, n, d_line_start, n_rec, d_rec_start,
+                       d_seq_start, d_seq_len, d_status);
 }
 
 void launch_ingest_offsets(const uint32_t *d_seq_len, uint64_t n_rec, unsigned long long *d_tile, unsigned long long *d_off, hipStream_t st) {
