@@ -42,13 +42,14 @@ uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
     return lanes;
 }
 
-// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in 2-6 ms; with only the most recent
-// 4 KiB of the member's text in LDS nineteen of them fit a CU (4 864 on the part): its time grows with the members per slot.  A
-// lane per member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands of members.
-// zlib level-6 members of BAM records: 64 MB 6.2 against 21-24 ms, 256 MB 10.9 against 22.7, 1 GiB 35.7 against 40.5, 2 GiB 66.6
+// Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in 2-5 ms; with only the most recent
+// 4 KiB of the member's text in LDS seventeen of them fit a CU (4 352 on the part): its time grows with the members per slot -- and
+// with them per CU: the kernel is bound by its scalar instructions (~770 000 per member on one scalar unit per CU).  A lane per
+// member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands of members.
+// zlib level-6 members of BAM records: 64 MB 5.2 against 21-24 ms, 256 MB 10.4 against 23.3, 1 GiB 30.8 against 40.4, 2 GiB ~62
 // against 41.3 -- they cross at about four rounds of the wave kernel's slots (profiles/r05_codec_real_rings.txt; rings of 2, 8, 16
-// and 32 KiB are in the same table: 4 KiB is the best or within 7 % of it at every size).
-constexpr uint32_t kWaveRounds = 4, kWaveSlotsPerCu = 19, kWaveRing = 4096;
+// and 32 KiB are in the same table: 4 KiB is the best or within 12 % of it at every size).
+constexpr uint32_t kWaveRounds = 4, kWaveSlotsPerCu = 17, kWaveRing = 4096;
 
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s, int which) {

@@ -18,8 +18,8 @@
 // With the whole 32 KiB in LDS a wave takes 36.1 KiB: 4 waves per CU, one per SIMD -- nothing fills the waits of a token turn's
 // ~150 (literal) to ~500 (match) cycles of dependent LDS latency.  The kernel is a template on the ring's size: with the most
 // recent 8 KiB (12.4 KiB per wave, 12 waves per CU, 3 072 members in flight on an MI355X) the same member takes as long but three
-// times as many run beside it (4 KiB: 8.3 KiB per wave, 19 per CU, 4 864 in flight); matches that reach behind the ring come back
-// from global memory (see WaveLds).  launch_inflate (bgzf_inflate.hip) takes the 4 KiB ring for calls of up to ~19 000 members; above
+// times as many run beside it (4 KiB: 9.3 KiB per wave, 17 per CU, 4 352 in flight); matches that reach behind the ring come back
+// from global memory (see WaveLds).  launch_inflate (bgzf_inflate.hip) takes the 4 KiB ring for calls of up to ~17 000 members; above
 // that the lane-per-member kernel's sheer parallelism wins (profiles/r05_codec_real_rings.txt).
 // RFC 1951; the reference's inflate is flate2 under `bam 0.1.4` (src/cmd_tag.rs:503-506) and needletail (src/cmd_extract.rs:281).
 #include <hip/hip_runtime.h>
@@ -41,14 +41,19 @@ constexpr int kFastLl = 10, kFastD = 9;
 template <uint32_t kRing>
 struct WaveLds {
     uint8_t ring[kRing];
-    uint16_t ll_fast[1 << kFastLl];  // symbol << 4 | length for codewords of <= 10 bits, else 0
-    uint16_t d_fast[1 << kFastD];
+    // direct tables for codewords of <= 10 / 9 bits (else 0), everything a token turn needs in ONE read (r05: the kernel is bound by
+    // its scalar instructions -- 107 per token, 1 M per member, one scalar unit per CU --, so what can be looked up is not computed):
+    // ll_fast: a literal or end-of-block = symbol << 4 | codeword length (< 0x8000); a length symbol = 0x8000 | (base - 3) << 7 |
+    // extra bits << 4 | codeword length.  d_fast: distance base << 8 | extra bits << 4 | codeword length.
+    uint16_t ll_fast[1 << kFastLl];
+    uint32_t d_fast[1 << kFastD];
     uint16_t ll_limit[16], ll_base[16], d_limit[16], d_base[16];
     uint16_t ll_sorted[288], d_sorted[32];
     uint8_t lens[320];  // code lengths of the block being set up: literal / length [0, 288), distance [288, 320)
 };
 static_assert(sizeof(WaveLds<32768>) <= 40 * 1024, "four waves per CU");
-static_assert(sizeof(WaveLds<8192>) <= 13 * 1024, "twelve waves per CU");
+static_assert(sizeof(WaveLds<8192>) <= 14 * 1024, "eleven waves per CU");
+static_assert(sizeof(WaveLds<4096>) <= 9728, "seventeen waves per CU");
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -102,12 +107,32 @@ __device__ int wave_build_tables(const uint8_t *lens, uint32_t n, uint16_t *sort
     return 0;
 }
 
-// direct table of `bits` bits from the canonical description: entry e = what decode_codeword makes of the stream bits e, if that
-// codeword is at most `bits` long
-__device__ void wave_fill_fast(uint16_t *fast, int bits, const uint16_t *sorted, const uint16_t *limit, const uint16_t *base) {
-    for (uint32_t e = lane_id(); e < (1u << bits); e += 64) {
+// what decode_codeword makes of a literal / length codeword (symbol << 4 | length, 0 = none) in the form of ll_fast; 0: not a symbol
+// of the alphabet (286, 287)
+__device__ __forceinline__ uint32_t pack_ll(uint32_t r) {
+    const uint32_t sym = r >> 4;
+    if (sym <= 256) return r;
+    if (sym > 285) return 0;
+    const uint32_t idx = sym - 257;
+    return 0x8000u | (length_base(idx) - 3) << 7 | length_extra_bits(idx) << 4 | (r & 15u);
+}
+__device__ __forceinline__ uint32_t pack_d(uint32_t r) {
+    const uint32_t sym = r >> 4;
+    if (r == 0 || sym > 29) return 0;
+    return distance_base(sym) << 8 | distance_extra_bits(sym) << 4 | (r & 15u);
+}
+// direct tables from the canonical descriptions: entry e = what decode_codeword makes of the stream bits e, if that codeword is at
+// most `bits` long
+__device__ void wave_fill_fast_ll(uint16_t *fast, const uint16_t *sorted, const uint16_t *limit, const uint16_t *base) {
+    for (uint32_t e = lane_id(); e < (1u << kFastLl); e += 64) {
         const uint32_t r = decode_codeword(e, sorted, limit, base);
-        fast[e] = (uint16_t)((r & 15u) <= (uint32_t)bits ? r : 0u);
+        fast[e] = (uint16_t)((r & 15u) <= (uint32_t)kFastLl ? pack_ll(r) : 0u);
+    }
+}
+__device__ void wave_fill_fast_d(uint32_t *fast, const uint16_t *sorted, const uint16_t *limit, const uint16_t *base) {
+    for (uint32_t e = lane_id(); e < (1u << kFastD); e += 64) {
+        const uint32_t r = decode_codeword(e, sorted, limit, base);
+        fast[e] = (r & 15u) <= (uint32_t)kFastD ? pack_d(r) : 0u;
     }
 }
 
@@ -305,57 +330,51 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t 
             break;
         }
         __builtin_amdgcn_wave_barrier();
-        wave_fill_fast(S.ll_fast, kFastLl, S.ll_sorted, S.ll_limit, S.ll_base);
-        wave_fill_fast(S.d_fast, kFastD, S.d_sorted, S.d_limit, S.d_base);
+        wave_fill_fast_ll(S.ll_fast, S.ll_sorted, S.ll_limit, S.ll_base);
+        wave_fill_fast_d(S.d_fast, S.d_sorted, S.d_limit, S.d_base);
         __builtin_amdgcn_wave_barrier();
 
-        // ---- the symbols of the block: one token per turn, the same turn on every lane
+        // ---- the symbols of the block: one token per turn, the same turn on every lane.  The turn is kept short (the scalar unit is
+        // the bound): bases and extra bits come out of the tables, and what need not be known per token -- has the stream run out,
+        // has the text outgrown ISIZE -- is asked where the text is about to leave for global memory and at the block's end (until
+        // then the ring's index mask keeps every write in place, and bytes are only flushed below ISIZE).
+        uint32_t flush_at = flushed + kFlush;
         for (;;) {
             MKW_NEED32();
             uint32_t e = S.ll_fast[(uint32_t)bitbuf & ((1u << kFastLl) - 1)];
-            if (e == 0) e = decode_codeword((uint32_t)bitbuf, S.ll_sorted, S.ll_limit, S.ll_base);
-            MKW_TAKE(e & 15u);
-            const uint32_t sym = e >> 4;
-            if (e == 0 || MKW_RAN_OUT()) {
-                status = e == 0 ? kInfBadSymbol : kInfTruncated;
-                break;
-            }
-            if (sym < 256) {
-                if (op == n_out) {
-                    status = kInfOutputOverrun;
-                    break;
-                }
-                if (lane == 0) S.ring[op & kRingMask] = (uint8_t)sym;
-                ++op;
-            } else if (sym == 256) {
-                break;
-            } else {
-                if (sym > 285) {
+            if (e == 0) {  // a codeword longer than the table's reach (or none)
+                e = pack_ll(decode_codeword((uint32_t)bitbuf, S.ll_sorted, S.ll_limit, S.ll_base));
+                if (e == 0) {
                     status = kInfBadSymbol;
                     break;
                 }
-                const uint32_t idx = sym - 257;
-                const uint32_t leb = length_extra_bits(idx);
-                const uint32_t len = length_base(idx) + ((uint32_t)bitbuf & ((1u << leb) - 1));
+            }
+            MKW_TAKE(e & 15u);
+            if (e < 0x1000u) {  // a literal (every lane stores the same byte to the same place)
+                S.ring[op & kRingMask] = (uint8_t)(e >> 4);
+                ++op;
+                if (op < flush_at) continue;
+            } else if (e < 0x8000u) {  // 256: the end of the block
+                break;
+            } else {
+                const uint32_t leb = (e >> 4) & 7u;
+                const uint32_t len = ((e >> 7) & 255u) + 3u + ((uint32_t)bitbuf & ((1u << leb) - 1));
                 MKW_TAKE(leb);
                 MKW_NEED32();
                 uint32_t d = S.d_fast[(uint32_t)bitbuf & ((1u << kFastD) - 1)];
-                if (d == 0) d = decode_codeword((uint32_t)bitbuf, S.d_sorted, S.d_limit, S.d_base);
-                MKW_TAKE(d & 15u);
-                const uint32_t dsym = d >> 4;
-                if (d == 0 || dsym > 29) {
-                    status = kInfBadSymbol;
-                    break;
+                if (d == 0) {
+                    d = pack_d(decode_codeword((uint32_t)bitbuf, S.d_sorted, S.d_limit, S.d_base));
+                    if (d == 0) {
+                        status = kInfBadSymbol;
+                        break;
+                    }
                 }
-                const uint32_t deb = distance_extra_bits(dsym);
-                const uint32_t dist = distance_base(dsym) + ((uint32_t)bitbuf & ((1u << deb) - 1));
+                MKW_TAKE(d & 15u);
+                const uint32_t deb = (d >> 4) & 15u;
+                const uint32_t dist = (d >> 8) + ((uint32_t)bitbuf & ((1u << deb) - 1));
                 MKW_TAKE(deb);
                 if (dist > op) {
                     status = kInfBadDistance;
-                    break;
-                }
-                if (len > n_out - op) {
-                    status = kInfOutputOverrun;
                     break;
                 }
                 // byte i of the match = byte (i mod distance) of the `distance` bytes in front of it: every source byte exists already
@@ -374,9 +393,21 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t 
                     for (uint32_t i = lane; i < len; i += 64) S.ring[(op + i) & kRingMask] = S.ring[(src0 + i % dist) & kRingMask];
                 }
                 op += len;
+                if (op < flush_at) continue;
             }
-            if (op - flushed >= kFlush) flush_blocks();
+            // a flush point: the questions that were put off
+            if (op > n_out) {
+                status = kInfOutputOverrun;
+                break;
+            }
+            if (MKW_RAN_OUT()) {
+                status = kInfTruncated;
+                break;
+            }
+            flush_blocks();
+            flush_at = flushed + kFlush;
         }
+        if (status == 0 && op > n_out) status = kInfOutputOverrun;
         if (status == 0 && MKW_RAN_OUT()) status = kInfTruncated;
     }
     // bits consumed must lie inside the stream; the text must be exactly ISIZE bytes
