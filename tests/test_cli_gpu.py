@@ -781,6 +781,33 @@ def test_tag_bam_records_resident_on_the_device(tmp_path):
         assert p.returncode == 1 and b"Invalid tag value format. Expected string value." in p.stderr
         if extra == ["--window-mb", "1"]:
             assert b"left to the host reader (existing tag)" in p.stderr
+    # a BAM without records, and one whose records are longer than a window (1 MB windows, records of 2.5 MB: a window then holds no
+    # whole record and its text is carried on as the next window's head)
+    import struct
+    hdr_only = raw_in[:cut_at]
+    (tmp_path / "empty.bam").write_bytes(_bgzf(hdr_only))
+    def long_record(name, n_bases, seed):
+        r2 = random.Random(seed)
+        seq = bytes(r2.choice(b"ACGT") for _ in range(n_bases))
+        packed = bytearray((n_bases + 1) // 2)
+        for k, ch in enumerate(seq):
+            packed[k >> 1] |= b"=ACMGRSVTWYHKDBN".index(ch) << (4 if k % 2 == 0 else 0)
+        body = struct.pack("<iiBBHHHiiii", 0, 5, len(name) + 1, 60, 4680, 0, 4, n_bases, -1, -1, 0) + name + b"\0" + bytes(packed) + bytes([20]) * n_bases
+        return struct.pack("<i", len(body)) + body, seq
+    big = []
+    for k in range(4):
+        rec, seq = long_record(b"long%d" % k, 1_700_000, k)
+        big.append(rec)
+    (tmp_path / "big.bam").write_bytes(_bgzf(hdr_only + b"".join(big)))
+    for name in ("empty", "big"):
+        for extra, tagd in (([], "d"), (["--window-mb", "1"], "w"), (["--host-ingest"], "h")):
+            p = subprocess.run([BIN, "tag", "-i", str(tmp_path / f"{name}.bam"), "-f", str(tmp_path / "k.txt"), "-o", str(tmp_path / f"{name}_{tagd}.bam"), *extra],
+                               capture_output=True, env=dict(os.environ, MERKURIO_TIMING="1"))
+            assert p.returncode == 0, p.stderr.decode()
+            if tagd != "h":
+                assert b"left to the host reader" not in p.stderr
+        assert _bam_stream(tmp_path / f"{name}_d.bam") == _bam_stream(tmp_path / f"{name}_h.bam") == _bam_stream(tmp_path / f"{name}_w.bam")
+    assert len(_bam_stream(tmp_path / "empty_d.bam")) == 0 and len(_bam_stream(tmp_path / "big_d.bam")) > 4 * 2_500_000
     # a truncated file: both paths end with the host reader's message
     raw = open(tmp_path / "in.bam", "rb").read()
     text = gzip.decompress(raw)
