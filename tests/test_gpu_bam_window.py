@@ -444,3 +444,69 @@ def test_fuzz_windows_against_the_oracle(mk, seed):
         assert sum(x["counters"]["hits"][0] for x in res) == c["hits"][0] and sum(x["counters"]["records_hit"][0] for x in res) == c["records_hit"][0]
         assert np.array_equal(np.sum([x["counters"]["pattern_hit_counts"] for x in res], axis=0), c["pattern_hit_counts"])
     codec.close()
+
+
+def _serial_walk(text, last):
+    """the CLI's serial parser (cli/io.cpp: parse_bam_records_serial) in Python: -> (records, bytes used) or None where it bails"""
+    recs, p, n = [], 0, len(text)
+    while p < n:
+        if n - p < 4:
+            break
+        block = struct.unpack_from("<i", text, p)[0]
+        if block < 32:
+            return None
+        if n - p - 4 < block:
+            break
+        l_name, n_cig, l_seq = text[p + 12], struct.unpack_from("<H", text, p + 16)[0], struct.unpack_from("<i", text, p + 20)[0]
+        if l_seq < 0 or 32 + l_name + 4 * n_cig + (l_seq + 1) // 2 + l_seq > block:
+            return None
+        recs.append(text[p:p + 4 + block])
+        p += 4 + block
+    if last and p != n:
+        return None
+    return recs, p
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_damaged_and_random_windows_never_yield_a_wrong_table(mk, seed):
+    """windows of damaged BAM text (random bytes flipped in a valid record stream, a stream cut anywhere, pure noise): whatever the piece
+    starts guess, the call either refuses the window (the host reader's business) or returns exactly the serial parser's records --
+    and never reads or writes outside its buffers (the kernels bound every access by the window and the record they are in)"""
+    rnd = random.Random(500 + seed)
+    pats = patterns31(mk, 20)
+    m, codec = mk.Matcher(pats, device=0), mk.Codec(0)
+    om = ob.Matcher(pats, True, 0, False)
+    recs = make_records(rnd, 400, pats, lens=(0, 50, 150, 900), hit=0.3)
+    text = bytearray(b"".join(recs))
+    kind = seed % 4
+    if kind == 0:    # a few flipped bytes anywhere
+        for _ in range(rnd.randrange(1, 6)):
+            text[rnd.randrange(len(text))] ^= 1 << rnd.randrange(8)
+    elif kind == 1:  # fixed fields of some records overwritten
+        at, k = 0, 0
+        while at + 36 < len(text) and k < 3:
+            b = struct.unpack_from("<i", text, at)[0]
+            if rnd.random() < 0.02:
+                struct.pack_into("<i", text, at + rnd.choice((0, 20)), rnd.choice((-5, 7, 31, 1 << 20, 1 << 30)))
+                k += 1
+            at += 4 + max(b, 32) if 32 <= b < (1 << 20) else 40
+    elif kind == 2:  # cut anywhere
+        del text[rnd.randrange(1, len(text)):]
+    else:            # noise
+        text = bytearray(rnd.getrandbits(8) for _ in range(60000))
+    text = bytes(text)
+    blob = _bgzf(text, block=rnd.choice((3000, 65280)))
+    members, _, _ = mk.bgzf_members(blob)
+    for last in (True, False):
+        want = _serial_walk(text, last)
+        r = m.tag_bam_window(codec, b"", blob, members, last=last, logging=False, piece_bytes=rnd.choice((64, 1000, 0)))
+        if want is None:
+            assert r["status"] != 0, (seed, last)
+            continue
+        if r["status"] != 0:  # (optional fields that no longer parse, a chain the proof gave up on: refusals are always allowed)
+            continue
+        good, used = want
+        assert r["n_rec"] == len(good) and r["n_used"] == used and r["tail"] == text[used:]
+        keep, rows, c, out = expected(om, pats, good, b"km", False, False, False)
+        assert (gzip.decompress(r["out"] + mk.bgzf_eof()) if r["out"] else b"") == out
+    codec.close()
