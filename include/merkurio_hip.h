@@ -626,7 +626,8 @@ int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inf
 /* (v6) Tuning / test hook: which inflate kernel the handle's calls use -- 0 (default) by the number of members in the call,
  * 1 one lane per member (many members in flight, each slow), 2 one wave per member with the member's recent text in LDS (few in
  * flight, each fast), 3 / 4 / 5 / 6 the same with only the most recent 8 / 16 / 4 / 2 KiB of the member's text in LDS (12 / 7 / 19 / 25 waves per
- * CU instead of 4; matches that reach further read the text back from device memory).  Results do not depend on it. */
+ * CU instead of 4; matches that reach further read the text back from device memory).  mk_gzip_inflate_device gives a piece of
+ * the stream to a wave, with 1 to a lane.  Results do not depend on it. */
 int mk_codec_set_inflate_kernel(mk_codec *c, int which);
 /* milliseconds of the handle's last call: [0] upload, [1] kernels, [2] download */
 int mk_codec_times(const mk_codec *c, float ms[3]);

@@ -59,6 +59,7 @@ def _units():
     units.append(("codec_bgzf_inflate.o", "codec/bgzf_inflate.hip", []))
     units.append(("codec_bgzf_inflate_wave.o", "codec/bgzf_inflate_wave.hip", []))
     units.append(("codec_gzip_inflate.o", "codec/gzip_inflate.hip", []))
+    units.append(("codec_gzip_segments_wave.o", "codec/gzip_segments_wave.hip", []))
     units.append(("codec_host.o", "codec/codec_host.cpp", []))
     units += [(s.replace(".cpp", ".o"), s, []) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     return units

@@ -408,7 +408,8 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
         MKC_HIP(hipMemcpyAsync(d_bits, seg_bits.data(), (J + 1) * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the segment table");
         MKC_HIP(hipMemcpyAsync(d_off, seg_off.data(), J * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the segment table");
         MKC_HIP(hipMemcpyAsync(d_cap, seg_cap.data(), J * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the segment table");
-        mkz::launch_gzip_segments((const uint8_t *)c->d_gz_in, n_in, d_bits, d_off, d_cap, J, (uint16_t *)c->d_gz_sym, d_nout, d_status, c->num_cus, c->stream);
+        mkz::launch_gzip_segments((const uint8_t *)c->d_gz_in, n_in, d_bits, d_off, d_cap, J, (uint16_t *)c->d_gz_sym, d_nout, d_status, c->num_cus, c->stream,
+                                  c->inflate_kernel == 1);
         MKC_HIP(hipGetLastError(), "gzip segment decode");
         MKC_HIP(hipMemcpyAsync(n_out.data(), d_nout, J * 8ull, hipMemcpyDeviceToHost, c->stream), "download");
         MKC_HIP(hipMemcpyAsync(status.data(), d_status, J * 4ull, hipMemcpyDeviceToHost, c->stream), "download");

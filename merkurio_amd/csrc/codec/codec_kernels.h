@@ -61,7 +61,10 @@ void launch_gzip_find(const uint8_t *in, uint64_t n_in, uint64_t chunk_bytes, ui
 // at most seg_cap[j] of them; n_out[j], status[j]
 void launch_gzip_segments(const uint8_t *in, uint64_t n_in, const unsigned long long *seg_bits, const unsigned long long *seg_off,
                           const unsigned long long *seg_cap, uint32_t n_seg, uint16_t *sym, unsigned long long *n_out, int32_t *status, int num_cus,
-                          hipStream_t s);
+                          hipStream_t s, bool lane_per_segment = false);
+// (the same with a wave per segment: gzip_segments_wave.hip; the place-holders must lie in front of every segment already)
+void launch_gzip_segments_wave(const uint8_t *in, uint64_t n_in, const unsigned long long *seg_bits, const unsigned long long *seg_off,
+                               const unsigned long long *seg_cap, uint32_t n_seg, uint16_t *sym, unsigned long long *n_out, int32_t *status, hipStream_t s);
 // contexts (n_seg x 32 KiB) and the text: text[text_off[j] ...] = segment j's bytes; *bad != 0: a symbol that is neither
 void launch_gzip_resolve(const uint16_t *sym, const unsigned long long *seg_off, const unsigned long long *n_out, const unsigned long long *text_off,
                          uint32_t n_seg, uint8_t *ctx, uint8_t *text, uint32_t *bad, hipStream_t s);

@@ -200,9 +200,13 @@ void launch_gzip_find(const uint8_t *in, uint64_t n_in, uint64_t chunk_bytes, ui
 
 void launch_gzip_segments(const uint8_t *in, uint64_t n_in, const unsigned long long *seg_bits, const unsigned long long *seg_off,
                           const unsigned long long *seg_cap, uint32_t n_seg, uint16_t *sym, unsigned long long *n_out, int32_t *status, int num_cus,
-                          hipStream_t s) {
+                          hipStream_t s, bool lane_per_segment) {
     if (!n_seg) return;
     hipLaunchKernelGGL(mk_gzip_prefix_kernel, dim3(kSegPrefix / 256, n_seg), dim3(256), 0, s, sym, seg_off, n_seg);
+    if (!lane_per_segment) {
+        launch_gzip_segments_wave(in, n_in, seg_bits, seg_off, seg_cap, n_seg, sym, n_out, status, s);
+        return;
+    }
     const uint32_t lanes = inflate_lanes(n_seg, num_cus);
     hipLaunchKernelGGL(mk_gzip_segments_kernel, dim3((n_seg + lanes - 1) / lanes), dim3(lanes), lanes * (kLaneTableU16 / 2) * 4, s, in, n_in, seg_bits, seg_off,
                        seg_cap, n_seg, sym, n_out, status);

@@ -40,6 +40,16 @@ def plain_codec():
     c.close()
 
 
+@pytest.fixture(scope="module", params=[0, 1], ids=["wave-per-piece", "lane-per-piece"])
+def gunzip_codec(request):
+    """the parallel gunzip's tests run twice: a piece of the stream decoded by a wave (gzip_segments_wave.hip, the default) and by a
+    lane (inflate_segment() of gzip_segments.hpp, the function the CPU harness checks against zlib)"""
+    c = mk.Codec()
+    c.set_inflate_kernel(request.param)
+    yield c
+    c.close()
+
+
 def check_members(data, blob, block_bytes):
     """every member: header fields, zlib inflates its payload to the block it stands for, CRC-32 and ISIZE agree"""
     bb = block_bytes or 65280
@@ -333,8 +343,8 @@ def _fastq_text(n, seed=3):
     return "".join(out).encode()
 
 
-def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(plain_codec):
-    codec = plain_codec
+def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(gunzip_codec):
+    codec = gunzip_codec
     """tests/data/sample.fasta.gz (the reference's own: one small member, a single piece) and 30 MB of FASTQ as gzip -1 / -6 / -9 wrote
     it (hundreds of pieces: block starts found on the device, pieces decoded side by side, place-holders resolved): the text zlib gives"""
     blob = open(os.path.join(GOLDEN, "data/sample.fasta.gz"), "rb").read()
@@ -356,8 +366,53 @@ def test_gunzip_of_the_reference_sample_and_of_gzip_written_fastq(plain_codec):
     assert L.mk_gzip_text_read(codec._h, n - 3, out.ctypes.data, 4) == mk.MK_E_INVALID_ARG
 
 
-def test_gunzip_shapes_the_device_takes_or_hands_back(plain_codec):
-    codec = plain_codec
+def test_gunzip_pieces_by_wave_and_by_lane_take_the_same_streams():
+    """text whose matches reach far back (a wave keeps 2 048 symbols of a piece in LDS and reads older ones from device memory; the
+    32 KiB in front of a piece are place-holders), runs (distance 1 .. 3), stored blocks between compressed ones: both decoders give
+    zlib's text, and take or hand back the same streams"""
+    rnd = random.Random(77)
+    wave, lane = mk.Codec(), mk.Codec()
+    lane.set_inflate_kernel(1)
+    try:
+        for case in range(10):
+            parts = []
+            pool = [bytes(rnd.choice(b"ACGTN") for _ in range(rnd.randrange(2000, 30000))) for _ in range(4)]
+            while sum(map(len, parts)) < 3_000_000:
+                r = rnd.random()
+                if r < 0.5:
+                    blk = rnd.choice(pool)
+                    a = rnd.randrange(len(blk) - 300)
+                    parts.append(blk[a:a + rnd.randrange(3, 300)])
+                elif r < 0.7:
+                    parts.append(bytes(rnd.choice(b"ACGT") for _ in range(rnd.randrange(1, 400))))
+                elif r < 0.8:
+                    parts.append(bytes([rnd.choice(b"#F:")]) * rnd.randrange(1, 600))
+                elif r < 0.9:
+                    parts.append(bytes(rnd.choice(b"AB") for _ in range(2)) * rnd.randrange(1, 200))
+                else:
+                    parts.append(os.urandom(rnd.randrange(1, 3000)))
+            data = b"".join(parts)
+            co = zlib.compressobj(rnd.choice([1, 4, 6, 9]), zlib.DEFLATED, 31, rnd.choice([1, 8, 9]))
+            gz, at = [], 0
+            while at < len(data):
+                step = rnd.choice([40_000, 200_000, 900_000])
+                gz.append(co.compress(data[at:at + step]))
+                if rnd.random() < 0.3:
+                    gz.append(co.flush(zlib.Z_FULL_FLUSH))
+                at += step
+            gz.append(co.flush())
+            gz = b"".join(gz)
+            a, b = wave.gunzip(gz), lane.gunzip(gz)
+            assert (a is None) == (b is None), (case, wave.gzip_info, lane.gzip_info)
+            assert a is None or a == data, case
+            assert b is None or b == data, case
+            assert wave.gzip_info[0] == lane.gzip_info[0], case  # the same pieces
+    finally:
+        wave.close(), lane.close()
+
+
+def test_gunzip_shapes_the_device_takes_or_hands_back(gunzip_codec):
+    codec = gunzip_codec
     """streams of every block type and of many flush points; what is not for this path comes back as 'not taken' (None) and never as a
     wrong text: several members, a damaged stream, a stream the buffers do not hold"""
     rnd = random.Random(8)

@@ -23,15 +23,17 @@ for level in levels:
     t_z = time.time() - t0
     assert ref == data
     del ref
-    best = None
-    for rep in range(3):
-        text = codec.gunzip(gz)
-        assert text is not None, codec.gzip_info
-        if best is None or codec.last_call_s < best[0]:
-            best = (codec.last_call_s, codec.last_read_s, codec.gzip_info)
-        assert text == data
-        del text
-    seg, ms = best[2]
-    print(f"gzip -{level}: {len(data) / 1e6:.0f} MB of FASTQ in {len(gz) / 1e6:.0f} MB (ratio {len(data) / len(gz):.2f}; written in {t_c:.0f} s); zlib inflate on one thread "
-          f"{t_z:.2f} s = {len(data) / t_z / 1e9:.2f} GB/s; device: {best[0] * 1e3:.0f} ms = {len(data) / best[0] / 1e9:.1f} GB/s of text in {seg} pieces "
-          f"(upload {ms[0]}, block search {ms[1]}, pieces {ms[2]}, resolution {ms[3]}, CRC {ms[4]} ms); + text to the host {best[1] * 1e3:.0f} ms", flush=True)
+    for which, label in ((0, "a wave per piece"), (1, "a lane per piece")):
+        codec.set_inflate_kernel(which)
+        best = None
+        for rep in range(3):
+            text = codec.gunzip(gz)
+            assert text is not None, codec.gzip_info
+            if best is None or codec.last_call_s < best[0]:
+                best = (codec.last_call_s, codec.last_read_s, codec.gzip_info)
+            assert text == data
+            del text
+        seg, ms = best[2]
+        print(f"gzip -{level}, {label}: {len(data) / 1e6:.0f} MB of FASTQ in {len(gz) / 1e6:.0f} MB (ratio {len(data) / len(gz):.2f}; written in {t_c:.0f} s); zlib inflate on one thread "
+              f"{t_z:.2f} s = {len(data) / t_z / 1e9:.2f} GB/s; device: {best[0] * 1e3:.0f} ms = {len(data) / best[0] / 1e9:.1f} GB/s of text in {seg} pieces "
+              f"(upload {ms[0]}, block search {ms[1]}, pieces {ms[2]}, resolution {ms[3]}, CRC {ms[4]} ms); + text to the host {best[1] * 1e3:.0f} ms", flush=True)
