@@ -431,7 +431,8 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
     if ((uint32_t)total != want_isize) return MK_OK;
     // ---- contexts, text, CRC-32
     t0 = now_ms();
-    if ((rc = mk::ensure_device(&c->d_gz_ctx, &c->gz_ctx_cap, (size_t)J * mkz::kSegPrefix + 16))) return rc;
+    // (the contexts, and behind them two sets of J - 1 maps of 32 768 16-bit elements: launch_gzip_resolve)
+    if ((rc = mk::ensure_device(&c->d_gz_ctx, &c->gz_ctx_cap, (size_t)J * mkz::kSegPrefix * 5 + 16))) return rc;
     if ((rc = mk::ensure_device(&c->d_gz_text, &c->gz_text_cap, total + 64))) return rc;
     MKC_HIP(hipMemcpyAsync(d_toff, text_off.data(), J * 8ull, hipMemcpyHostToDevice, c->stream), "upload of the text offsets");
     MKC_HIP(hipMemsetAsync(d_bad, 0, 4, c->stream), "hipMemsetAsync");

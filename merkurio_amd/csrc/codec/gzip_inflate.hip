@@ -3,19 +3,21 @@
 // (src/cmd_extract.rs:281-282) for files plain gzip wrote; mk_gzip_inflate_device (codec_host.cpp) drives it.
 //
 //   mk_gzip_find_kernel      a wave per nominal chunk of the stream: 64 bit positions per step through the three levels of the header
-//                            test, each level on full waves (survivors queued in LDS), the rare survivor of all three confirmed by ONE
-//                            lane that decodes its block dry and looks for the next header (LDS: one decoder's tables per wave)
+//                            test, each level on full waves (survivors queued in LDS), the rare survivor of all three confirmed by the
+//                            WAVE, which decodes its block dry (gzip_segments_wave.hpp) and looks for the next header
 //   mk_gzip_prefix_kernel    the place-holders in front of every segment's symbol buffer
+//   mk_gzip_segments_wave_kernel (gzip_segments_wave.hip) a wave per segment: the default
 //   mk_gzip_segments_kernel  a lane per segment (1 .. 64 per wave, as few as the part's residency allows: the lanes of a wave move in
 //                            lockstep): inflate_segment into 16-bit symbols; tables in LDS, 836 B per lane
-//   mk_gzip_context_kernel   ONE workgroup walks the segments in order: the 32 KiB context in front of segment j + 1 from the context in
-//                            front of segment j (in LDS) and segment j's last symbols -- the only sequential step, ~2 us per segment
+//   mk_gzip_maps_*_kernel    the 32 KiB context in front of every segment: "context j + 1 in terms of context j" composed over
+//                            doubling distances, log2(segments) rounds over all segments at once
 //   mk_gzip_translate_kernel a workgroup per segment: symbols -> bytes through the segment's context, coalesced
 // Bound: latency of the serial decode per segment, hidden by the number of segments in flight (thousands) -- not HBM, not MFMA.
 #include <hip/hip_runtime.h>
 
 #include "codec_kernels.h"
 #include "gzip_segments.hpp"
+#include "gzip_segments_wave.hpp"
 
 namespace mkz {
 
@@ -29,7 +31,7 @@ constexpr uint32_t kFindQueue = 192, kDeepEvery = 128;
 
 __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restrict__ in, uint64_t n_in, uint64_t chunk_bytes, uint32_t n_chunks,
                                                           uint64_t search_bytes, unsigned long long *__restrict__ starts) {
-    __shared__ uint16_t t[kLaneTableU16];
+    __shared__ SegWaveTables S;                          // (the confirmation's decode tables)
     __shared__ uint32_t q1[kFindQueue], q2[kFindQueue];  // bit positions relative to bit0
     const uint32_t c = blockIdx.x + 1;  // (chunk 0 starts where the stream does)
     if (c >= n_chunks) return;
@@ -56,13 +58,11 @@ __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restr
             const uint64_t bit = bit0 + rel;
             const bool pass = have && seg_header_plausible(in, n_in, bit);
             uint64_t m = __ballot(pass);
-            while (m && found == ~0ull) {  // the survivors, lowest queue slot first: confirmed by their own lane, one at a time
+            while (m && found == ~0ull) {  // the survivors, lowest queue slot first: confirmed by the whole wave, one at a time
                 const uint32_t l = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
-                int ok = 0;
-                if (lane == l) ok = seg_confirm_block_start(in, n_in, bit, t) ? 1 : 0;
-                ok = __shfl(ok, (int)l);
-                if (ok) found = bit0 + (uint32_t)__shfl((int)rel, (int)l);
+                const uint64_t at = bit0 + (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)l);
+                if (wave_confirm_block_start(in, n_in, at, S)) found = at;
             }
             __builtin_amdgcn_wave_barrier();
             const uint32_t rest = n2 - take;
@@ -140,34 +140,55 @@ __global__ __launch_bounds__(64, 4) void mk_gzip_segments_kernel(const uint8_t *
     status[j] = rc;
 }
 
-// ctx[j] = the 32 KiB of text in front of segment j (ctx[0]: nothing, zeros).  One workgroup of 1024; the running context lives in LDS.
-__global__ __launch_bounds__(1024) void mk_gzip_context_kernel(const uint16_t *__restrict__ sym, const unsigned long long *__restrict__ seg_off,
-                                                               const unsigned long long *__restrict__ n_out, uint32_t n_seg, uint8_t *__restrict__ ctx) {
-    __shared__ uint8_t cur[2][kSegPrefix];
-    for (uint32_t k = threadIdx.x; k < kSegPrefix; k += 1024) cur[0][k] = 0, ctx[k] = 0;
-    __syncthreads();
-    int b = 0;
-    for (uint32_t j = 0; j + 1 < n_seg; ++j, b ^= 1) {
-        const uint16_t *o = sym + seg_off[j] + kSegPrefix;
-        const uint64_t n = n_out[j];
-        uint8_t *next = ctx + (uint64_t)(j + 1) * kSegPrefix;
-        // the last 32 KiB of (context ++ segment's text): what the segment does not cover comes from the old context, shifted
-        const uint64_t keep = n >= kSegPrefix ? 0 : kSegPrefix - n;  // bytes of the old context that survive
-        uint16_t v[kSegPrefix / 1024];
+// ---- contexts: ctx[j] = the 32 KiB of text in front of segment j (ctx[0]: nothing, zeros).
+// ctx[j + 1] is the last 32 KiB of (ctx[j] ++ segment j's text) -- a chain through every segment, and in FASTQ a real one: a read
+// name's prefix is a match to the previous read's, back to the first read of the file.  Walked in order (one workgroup, the running
+// context in LDS: the first version) it costs ~5 us per segment, 19-22 ms of a 108 ms call.  Here the chain is cut by composing MAPS:
+// map j (32 768 16-bit elements) says what ctx[j + 1] is in terms of an EARLIER context -- element k is a byte, or the place-holder
+// of an element of that context.  Map j starts out in terms of ctx[j] (segment j's last symbols; where the segment is shorter than
+// 32 KiB, place-holders of the context's own tail); composing it with map j - r (which gives ctx[j] when r = 1) puts it in terms of
+// a context r segments further back.  With r = 1, 2, 4, ... every map is in terms of ctx[0] after log2(segments) rounds: 12 rounds
+// of ~0.75 GB of traffic for 3 700 segments.
+__global__ __launch_bounds__(256) void mk_gzip_maps_init_kernel(const uint16_t *__restrict__ sym, const unsigned long long *__restrict__ seg_off,
+                                                                const unsigned long long *__restrict__ n_out, uint16_t *__restrict__ maps) {
+    const uint32_t j = blockIdx.y;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // (gridDim.x = kSegPrefix / 256)
+    const uint16_t *o = sym + seg_off[j] + kSegPrefix;
+    const uint64_t n = n_out[j];
+    const uint64_t keep = n >= kSegPrefix ? 0 : kSegPrefix - n;  // elements of the old context that survive
+    maps[(uint64_t)j * kSegPrefix + k] = k >= keep ? o[n - (kSegPrefix - k)] : (uint16_t)(kSegUnknown | (uint32_t)(k + n));
+}
+// dst[j] = src[j] composed with src[j - r] (j >= r), else src[j].  8 elements per thread.
+__global__ __launch_bounds__(256) void mk_gzip_maps_step_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, uint32_t r) {
+    const uint32_t j = blockIdx.y;
+    const uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 8;  // (gridDim.x = kSegPrefix / 2048)
+    const uint4 v = *reinterpret_cast<const uint4 *>(src + (uint64_t)j * kSegPrefix + k);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (j >= r) {
+        const uint16_t *back = src + (uint64_t)(j - r) * kSegPrefix;
 #pragma unroll
-        for (uint32_t q = 0; q < kSegPrefix / 1024; ++q) {
-            const uint32_t k = q * 1024 + threadIdx.x;
-            v[q] = k >= keep ? o[n - (kSegPrefix - k)] : (uint16_t)0;
+        for (int q = 0; q < 4; ++q) {
+            uint32_t lo = w[q] & 0xffffu, hi = w[q] >> 16;
+            if (lo & kSegUnknown) lo = back[lo & 0x7fffu];
+            if (hi & kSegUnknown) hi = back[hi & 0x7fffu];
+            w[q] = lo | hi << 16;
         }
-#pragma unroll
-        for (uint32_t q = 0; q < kSegPrefix / 1024; ++q) {
-            const uint32_t k = q * 1024 + threadIdx.x;
-            const uint8_t byte = k < keep ? cur[b][k + n] : ((v[q] & kSegUnknown) ? cur[b][v[q] & 0x7fffu] : (uint8_t)v[q]);
-            cur[b ^ 1][k] = byte;
-            next[k] = byte;
-        }
-        __syncthreads();
     }
+    *reinterpret_cast<uint4 *>(dst + (uint64_t)j * kSegPrefix + k) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// ctx[j + 1] from map j, now in terms of ctx[0] = zeros (blockIdx.y = 0: ctx[0] itself).  8 elements per thread.
+__global__ __launch_bounds__(256) void mk_gzip_maps_final_kernel(const uint16_t *__restrict__ maps, uint8_t *__restrict__ ctx) {
+    const uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 8;
+    uint2 bytes = make_uint2(0, 0);
+    if (blockIdx.y) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(maps + (uint64_t)(blockIdx.y - 1) * kSegPrefix + k);
+        auto two = [](uint32_t w) -> uint32_t {  // two elements -> two bytes (a place-holder of ctx[0]: 0)
+            const uint32_t lo = w & 0xffffu, hi = w >> 16;
+            return ((lo & kSegUnknown) ? 0u : lo & 0xffu) | ((hi & kSegUnknown) ? 0u : hi & 0xffu) << 8;
+        };
+        bytes = make_uint2(two(v.x) | two(v.y) << 16, two(v.z) | two(v.w) << 16);
+    }
+    *reinterpret_cast<uint2 *>(ctx + (uint64_t)blockIdx.y * kSegPrefix + k) = bytes;
 }
 
 // text[text_off[j] + i] = the byte symbol i of segment j stands for
@@ -215,7 +236,16 @@ void launch_gzip_segments(const uint8_t *in, uint64_t n_in, const unsigned long 
 void launch_gzip_resolve(const uint16_t *sym, const unsigned long long *seg_off, const unsigned long long *n_out, const unsigned long long *text_off,
                          uint32_t n_seg, uint8_t *ctx, uint8_t *text, uint32_t *bad, hipStream_t s) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(mk_gzip_context_kernel, dim3(1), dim3(1024), 0, s, sym, seg_off, n_out, n_seg, ctx);
+    // ctx: n_seg x 32 KiB of contexts, then two sets of n_seg - 1 maps (gzip_resolve_bytes)
+    uint16_t *maps[2] = {reinterpret_cast<uint16_t *>(ctx + (uint64_t)n_seg * kSegPrefix), nullptr};
+    maps[1] = maps[0] + (uint64_t)(n_seg - 1) * kSegPrefix;
+    int cur = 0;
+    if (n_seg > 1) {
+        hipLaunchKernelGGL(mk_gzip_maps_init_kernel, dim3(kSegPrefix / 256, n_seg - 1), dim3(256), 0, s, sym, seg_off, n_out, maps[0]);
+        for (uint32_t r = 1; r < n_seg - 1; r *= 2, cur ^= 1)
+            hipLaunchKernelGGL(mk_gzip_maps_step_kernel, dim3(kSegPrefix / 2048, n_seg - 1), dim3(256), 0, s, maps[cur], maps[cur ^ 1], r);
+    }
+    hipLaunchKernelGGL(mk_gzip_maps_final_kernel, dim3(kSegPrefix / 2048, n_seg), dim3(256), 0, s, maps[cur], ctx);
     hipLaunchKernelGGL(mk_gzip_translate_kernel, dim3(n_seg), dim3(1024), 0, s, sym, seg_off, n_out, text_off, ctx, n_seg, text, bad);
 }
 
