@@ -879,9 +879,48 @@ def codec_configs(mk, megabytes=1024, reps=3):
         del fq, bam
         out.append(bgzf_window_config(mk, codec, reps))
         out.append(bam_window_config(mk, codec, reps))
+        out.append(gunzip_config(mk, reps))
     finally:
         codec.close()
     return out
+
+
+def gunzip_config(mk, reps, n_reads=1_500_000):
+    """ONE gzip member (what plain `gzip` writes: one DEFLATE stream, no member boundaries to split at) inflated in parallel pieces on
+    the device: mk_gzip_inflate_device -- block starts found by trying every bit position, a wave per piece decoding into
+    16-bit symbols with place-holders for the unknown 32 KiB in front, contexts by composing maps, CRC-32 / ISIZE checked.  Checked in
+    the run against the text that went in; zlib on one host thread inflates the same stream beside it."""
+    import zlib
+    data = _fastq_binned(n_reads)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(data) + co.flush()
+    t0 = time.perf_counter()
+    ok = zlib.decompress(gz, 31) == data
+    t_z = time.perf_counter() - t0
+    codec = mk.Codec()
+    try:
+        best = None
+        for _ in range(reps + 1):
+            text = codec.gunzip(gz)
+            if text is None:
+                raise RuntimeError(f"mk_gzip_inflate_device did not take a gzip-written FASTQ: {codec.gzip_info}")
+            ok = ok and text == data
+            del text
+            if best is None or codec.last_call_s < best[0]:
+                best = (codec.last_call_s, codec.gzip_info)
+    finally:
+        codec.close()
+    if not ok:
+        raise RuntimeError("mk_gzip_inflate_device: the text differs from what was compressed")
+    pieces, ms = best[1]
+    return {"workload": f"one-member gzip (gzip -6): {n_reads} x 150 bp FASTQ reads = {len(data) / 1e6:.0f} MB of text in ONE DEFLATE stream of {len(gz) / 1e6:.0f} MB, "
+                        f"inflated in {pieces} parallel pieces; the text stays on the device (extract's windows are ranges of it)",
+            "kernel": "mk_gzip_find_kernel + mk_gzip_segments_wave_kernel + mk_gzip_maps_* + mk_gzip_translate_kernel + mk_bgzf_crc_kernel",
+            "ms_per_call": round(best[0] * 1e3, 1), "text_gb_per_s_call": round(len(data) / best[0] / 1e9, 2),
+            "phases_ms": dict(zip(("upload", "block_search", "pieces", "contexts_and_text", "crc"), ms)), "pieces": pieces, "round_trip_equal": True,
+            "cpu_baseline": {"value": round(len(data) / t_z / 1e9, 3), "unit": "GB/s of text", "cores": 1, "kind": "zlib inflate of the same stream", "sample": "the whole stream"},
+            "bound": "the CUs' scalar units (wave-uniform decode); not HBM, not MFMA", "kernel_ms": None, "frac": None, "traffic": None,
+            "traffic_source": "a host-buffer call, not a kernel: end-to-end figure"}
 
 
 def bam_window_config(mk, codec, reps, n_rec=3_000_000, L=150, n_pat=10_000):

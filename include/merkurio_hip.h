@@ -629,6 +629,9 @@ int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inf
  * CU instead of 4; matches that reach further read the text back from device memory).  mk_gzip_inflate_device gives a piece of
  * the stream to a wave, with 1 to a lane.  Results do not depend on it. */
 int mk_codec_set_inflate_kernel(mk_codec *c, int which);
+/* (v7) Tuning / test hook of mk_gzip_inflate_device: the nominal distance between two cuts of the stream, in compressed bytes -- a
+ * power of two, 4 KiB ... 1 MiB; 0 (default): by the size of the stream (16 KiB up to ~200 MB of it, 64 KiB above).  A piece starts at the first DEFLATE block found behind a cut.  Results do not depend on it. */
+int mk_codec_set_gzip_chunk(mk_codec *c, uint64_t chunk_bytes);
 /* milliseconds of the handle's last call: [0] upload, [1] kernels, [2] download */
 int mk_codec_times(const mk_codec *c, float ms[3]);
 

@@ -192,6 +192,13 @@ int mk_codec_set_pass_limits(mk_codec *c, uint64_t deflate_members, uint64_t inf
     return MK_OK;
 }
 
+int mk_codec_set_gzip_chunk(mk_codec *c, uint64_t chunk_bytes) {
+    if (!c || (chunk_bytes && (chunk_bytes < 4096 || chunk_bytes > (1u << 20) || (chunk_bytes & (chunk_bytes - 1)))))
+        return mk::fail(MK_E_INVALID_ARG, "mk_codec_set_gzip_chunk: handle / a power of two of 4 KiB ... 1 MiB");
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->gzip_chunk = chunk_bytes;
+    return MK_OK;
+}
 int mk_codec_set_inflate_kernel(mk_codec *c, int which) {
     if (!c || which < 0 || which > 6) return mk::fail(MK_E_INVALID_ARG, "mk_codec_set_inflate_kernel: handle / selector");
     std::lock_guard<std::mutex> lock(c->mu);
@@ -351,9 +358,13 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
     memcpy(&want_crc, gz + n - 8, 4), memcpy(&want_isize, gz + n - 4, 4);
     MKC_HIP(hipSetDevice(c->device), "hipSetDevice");
     int rc;
-    // nominal chunks of 64 KiB of compressed bytes (a block of zlib's is 15-40 KiB of them): the segments that come out hold one to
-    // a few blocks each.  At most 32 768 chunks (the prefix kernel's grid; a stream of more than 2 GiB gets larger chunks).
-    uint64_t chunk = 64u << 10;
+    // nominal chunks of compressed bytes (a block of zlib's is 15-40 KiB of them).  A piece is decoded by one wave at that wave's pace
+    // (~13 MB/s of text), so what counts is the largest piece and how many rounds of the device's decoder slots (17 per CU) the
+    // pieces make.  Cuts every 16 KiB give every block its own piece (no piece can be smaller); up to a round and a half of them
+    // that is the fastest (61 MB of stream: 27 ms against 37); above, cuts every 64 KiB (pieces of ~2 blocks, a third of the
+    // search waves) are (245 MB: 63 ms against 67).  At most 32 768 chunks (the prefix kernel's grid; a stream of more than 2 GiB
+    // gets larger chunks).
+    uint64_t chunk = c->gzip_chunk ? c->gzip_chunk : (n_in / (32u << 10) <= (uint64_t)c->num_cus * 17 * 3 / 2 ? 16u << 10 : 64u << 10);
     while (n_in / chunk > 32768) chunk *= 2;
     const uint32_t n_chunks = (uint32_t)std::max<uint64_t>(1, n_in / chunk);
     if ((rc = mk::ensure_device(&c->d_gz_in, &c->gz_in_cap, n_in + mkz::kPad + 16))) return rc;
@@ -369,7 +380,7 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
     // ---- block starts
     t0 = now_ms();
     std::vector<unsigned long long> starts(n_chunks, ~0ull);
-    mkz::launch_gzip_find((const uint8_t *)c->d_gz_in, n_in, chunk, n_chunks, 3 * chunk, d_starts, c->stream);
+    mkz::launch_gzip_find((const uint8_t *)c->d_gz_in, n_in, chunk, n_chunks, chunk, d_starts, c->stream);  // (a start behind the next cut is the next chunk's to find)
     MKC_HIP(hipGetLastError(), "gzip block search");
     if (n_chunks > 1) MKC_HIP(hipMemcpyAsync(starts.data() + 1, d_starts + 1, (n_chunks - 1) * 8ull, hipMemcpyDeviceToHost, c->stream), "download of the block starts");
     MKC_HIP(hipStreamSynchronize(c->stream), "gzip block search");
@@ -377,23 +388,29 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
     std::vector<unsigned long long> seg_bits{0ull};
     for (uint32_t k = 1; k < n_chunks; ++k)
         if (starts[k] != ~0ull && starts[k] > seg_bits.back()) seg_bits.push_back(starts[k]);
-    const uint32_t J = (uint32_t)seg_bits.size();
+    uint32_t J = (uint32_t)seg_bits.size();
     seg_bits.push_back(~0ull);
-    c->gz_segments = J;
-    // ---- segments -> symbols.  Room per segment: 12 x its compressed bytes (FASTQ / FASTA / text: 3-6 x), then 48 x once more
-    std::vector<unsigned long long> seg_off(J), seg_cap(J), n_out(J), text_off(J);
-    std::vector<int32_t> status(J);
-    unsigned long long *d_bits = d_starts + n_chunks, *d_off = d_bits + (J + 1), *d_cap = d_off + J, *d_nout = d_cap + J, *d_toff = d_nout + J;
-    int32_t *d_status = (int32_t *)(d_toff + J);
-    uint32_t *d_bad = (uint32_t *)(d_status + J + (J & 1));
+    // ---- segments -> symbols.  Room per segment: 12 x its compressed bytes (FASTQ / FASTA / text: 3-6 x), then 48 x once more.
+    // A start the search took for one and that is none (as good as never: gzip_segments.hpp) shows here: the piece in front of it
+    // runs over it (kSegDesync, and says at which block boundary it stands).  Such starts are dropped and the pieces decoded
+    // again, a few times at most.
+    std::vector<unsigned long long> seg_off, seg_cap, n_out, text_off;
+    std::vector<int32_t> status;
+    unsigned long long *d_bits = nullptr, *d_off = nullptr, *d_cap = nullptr, *d_nout = nullptr, *d_toff = nullptr;
+    int32_t *d_status = nullptr;
+    uint32_t *d_bad = nullptr;
     uint64_t total = 0;
     bool done = false;
     t0 = now_ms();
     // (ISIZE says how much text there is in all -- below 4 GiB of it: the first guess per piece is half as much again as the stream's
     // own ratio, which spares a 1.27 GB FASTQ two thirds of a 6 GB allocation; a stream of 4 GiB of text or more starts at 12)
     const uint64_t whole_ratio = n_in ? (uint64_t)want_isize / n_in + 1 : 1;
-    const uint64_t first_ratio = (n_in < (1ull << 29) && want_isize > n_in) ? std::min<uint64_t>(12, whole_ratio + whole_ratio / 2 + 1) : 12;
-    for (uint64_t ratio : {first_ratio, (uint64_t)48}) {
+    uint64_t ratio = (n_in < (1ull << 29) && want_isize > n_in) ? std::min<uint64_t>(12, whole_ratio + whole_ratio / 2 + 1) : 12;
+    for (int attempt = 0, dropped_rounds = 0; attempt < 6 && !done; ++attempt) {
+        seg_off.assign(J, 0), seg_cap.assign(J, 0), n_out.assign(J, 0), status.assign(J, 0);
+        d_bits = d_starts + n_chunks, d_off = d_bits + (J + 1), d_cap = d_off + J, d_nout = d_cap + J, d_toff = d_nout + J;
+        d_status = (int32_t *)(d_toff + J);
+        d_bad = (uint32_t *)(d_status + J + (J & 1));
         uint64_t elems = 0;
         for (uint32_t j = 0; j < J; ++j) {
             const uint64_t b0 = seg_bits[j] >> 3, b1 = j + 1 < J ? seg_bits[j + 1] >> 3 : n_in;
@@ -414,19 +431,37 @@ int mk_gzip_inflate_device(mk_codec *c, const uint8_t *gz, uint64_t n, uint64_t 
         MKC_HIP(hipMemcpyAsync(n_out.data(), d_nout, J * 8ull, hipMemcpyDeviceToHost, c->stream), "download");
         MKC_HIP(hipMemcpyAsync(status.data(), d_status, J * 4ull, hipMemcpyDeviceToHost, c->stream), "download");
         MKC_HIP(hipStreamSynchronize(c->stream), "gzip segment decode");
+        // the chain from the stream's first bit: a piece that ends on the next start proves that start; the first piece that runs
+        // over its end disproves every start in front of the block boundary it stands at (what lies behind is looked at next time)
         bool overflow = false, failed = false;
-        for (uint32_t j = 0; j < J; ++j) {
-            overflow = overflow || status[j] == mkz::kSegOverflow;
-            failed = failed || (status[j] != 0 && status[j] != mkz::kSegOverflow);
+        uint32_t bad_from = J;
+        for (uint32_t j = 0; j < J && bad_from == J; ++j) {
+            if (status[j] == mkz::kSegDesync && j + 1 < J) bad_from = j;
+            else if (status[j] == mkz::kSegOverflow) overflow = true;
+            else if (status[j] != 0) failed = true;
         }
-        if (failed) return MK_OK;  // (a segment that does not decode or does not meet its neighbour: zlib will say what this file is)
-        if (!overflow) {
-            done = true;
-            break;
+        if (failed) return MK_OK;  // (a segment that does not decode, or a stream without its final block: zlib will say what this file is)
+        if (bad_from < J) {
+            if (++dropped_rounds > 3) return MK_OK;
+            const unsigned long long stands_at = n_out[bad_from];
+            std::vector<unsigned long long> kept(seg_bits.begin(), seg_bits.begin() + bad_from + 1);
+            for (uint32_t j = bad_from + 1; j < J; ++j)
+                if (seg_bits[j] >= stands_at) kept.push_back(seg_bits[j]);
+            if (kept.size() == J) return MK_OK;  // (nothing to drop: not what this is for)
+            J = (uint32_t)kept.size();
+            kept.push_back(~0ull);
+            seg_bits.swap(kept);
+            continue;
         }
+        for (uint32_t j = 0; j < J; ++j) overflow = overflow || status[j] == mkz::kSegOverflow;
+        if (!overflow) done = true;
+        else if (ratio == 48) break;
+        else ratio = 48;
     }
+    c->gz_segments = J;
     c->gz_ms[2] = (float)(now_ms() - t0);
     if (!done) return MK_OK;
+    text_off.assign(J, 0);
     for (uint32_t j = 0; j < J; ++j) text_off[j] = total, total += n_out[j];
     if ((uint32_t)total != want_isize) return MK_OK;
     // ---- contexts, text, CRC-32

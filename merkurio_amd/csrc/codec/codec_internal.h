@@ -29,6 +29,7 @@ struct mk_codec {
     float gz_ms[5] = {0, 0, 0, 0, 0};  // upload, block search, segments, resolve + translate, CRC
     int inflate_kernel = 0;  // mk_codec_set_inflate_kernel: 0 = chosen per call, 1 = a lane per member, 2 = a wave per member
     float ms[3] = {0, 0, 0};
+    uint64_t gzip_chunk = 0;  // mk_codec_set_gzip_chunk; 0 = by the stream's size
     uint64_t deflate_pass_blocks = 0, inflate_pass_text = 0;  // mk_codec_set_pass_limits; 0 = the defaults below
 };
 

@@ -3,8 +3,8 @@
 // (src/cmd_extract.rs:281-282) for files plain gzip wrote; mk_gzip_inflate_device (codec_host.cpp) drives it.
 //
 //   mk_gzip_find_kernel      a wave per nominal chunk of the stream: 64 bit positions per step through the three levels of the header
-//                            test, each level on full waves (survivors queued in LDS), the rare survivor of all three confirmed by the
-//                            WAVE, which decodes its block dry (gzip_segments_wave.hpp) and looks for the next header
+//                            test, each level on full waves (survivors queued in LDS); a survivor of all three is the chunk's start if the
+//                            first 2 048 symbols of its block decode (by the wave, dry: gzip_segments_wave.hpp)
 //   mk_gzip_prefix_kernel    the place-holders in front of every segment's symbol buffer
 //   mk_gzip_segments_wave_kernel (gzip_segments_wave.hip) a wave per segment: the default
 //   mk_gzip_segments_kernel  a lane per segment (1 .. 64 per wave, as few as the part's residency allows: the lanes of a wave move in
@@ -25,19 +25,19 @@ namespace mkz {
 // lane of 64 is in the expensive one at any time and the others wait for it (53-58 ms of a 156 ms call).  Here the levels are run
 // on FULL waves: level 1 on all 64 positions of a step from three wave-uniform dwords (no per-lane stream reader), its survivors
 // queued in LDS; level 2 (the code-length code) on 64 queued positions at a time, its survivors queued again; level 3 (all code
-// lengths) + confirmation on what gathers there, at the latest every kDeepEvery steps.  Any confirmed start in the range will do:
+// lengths) on what gathers there, at the latest every kDeepEvery steps.  Any start in the range will do:
 // the pieces are cut wherever starts were found.
 constexpr uint32_t kFindQueue = 192, kDeepEvery = 128;
 
 __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restrict__ in, uint64_t n_in, uint64_t chunk_bytes, uint32_t n_chunks,
                                                           uint64_t search_bytes, unsigned long long *__restrict__ starts) {
-    __shared__ SegWaveTables S;                          // (the confirmation's decode tables)
+    __shared__ SegWaveTables S;                          // (the decode tables of the look at a candidate's block)
     __shared__ uint32_t q1[kFindQueue], q2[kFindQueue];  // bit positions relative to bit0
     const uint32_t c = blockIdx.x + 1;  // (chunk 0 starts where the stream does)
     if (c >= n_chunks) return;
     const uint32_t lane = threadIdx.x;
     const uint64_t bit0 = (uint64_t)c * chunk_bytes * 8;
-    const uint64_t bit1 = min(bit0 + search_bytes * 8, n_in * 8);
+    const uint64_t bit1 = c + 1 == n_chunks ? n_in * 8 : min(bit0 + search_bytes * 8, n_in * 8);  // (the last one: to the stream's end)
     unsigned long long found = ~0ull;
     uint32_t n1 = 0, n2 = 0, steps = 0;  // (wave-uniform)
     auto push = [&](uint32_t *q, uint32_t &n, bool mine, uint32_t value) {
@@ -51,14 +51,14 @@ __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restr
     bool draining = false, deep_due = false;
     while (found == ~0ull) {
         if (n2 >= 64 || (n2 && (draining ? n1 == 0 : deep_due))) {
-            // level 3 + confirmation of the positions in q2 (at most 127 are there: the first 64 now)
+            // level 3 on the positions in q2 (at most 127 are there: the first 64 now)
             const uint32_t take = min(n2, 64u);
             const bool have = lane < take;
             const uint32_t rel = have ? q2[lane] : 0u;
             const uint64_t bit = bit0 + rel;
             const bool pass = have && seg_header_plausible(in, n_in, bit);
             uint64_t m = __ballot(pass);
-            while (m && found == ~0ull) {  // the survivors, lowest queue slot first: confirmed by the whole wave, one at a time
+            while (m && found == ~0ull) {  // the survivors, lowest queue slot first: the wave decodes the first symbols of the block
                 const uint32_t l = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
                 const uint64_t at = bit0 + (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)l);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64, 4) void mk_gzip_segments_kernel(const uint8_t *
     int rc = inflate_segment(in, n_in, seg_bits[j], end, 0, sym + seg_off[j] + kSegPrefix, seg_cap[j], t, &produced, &stop, &fin);
     // both ends must be what the search said they are: the next start reached exactly (and not behind the final block), or the stream's end
     if (rc == 0 && (end != ~0ull ? (stop != end || fin) : !fin)) rc = kSegDesync;
-    n_out[j] = produced;
+    n_out[j] = rc == kSegDesync ? stop : produced;  // (a piece that ran over its end: where it stands, a block boundary)
     status[j] = rc;
 }
 

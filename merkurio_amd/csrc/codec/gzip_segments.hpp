@@ -8,9 +8,13 @@
 // restated for a GPU):
 //   1. block starts.  A dynamic block opens with a header that almost no bit position satisfies: HLIT / HDIST in range, a COMPLETE
 //      code-length code, code lengths that decode to a complete literal / length code with an end-of-block codeword and a usable
-//      distance code.  seg_header_plausible() tests one bit position with registers only; a position that passes is confirmed by
-//      decoding the whole block (dry: no output) and finding another plausible header right behind its end-of-block codeword
-//      (seg_confirm_block_start).  The kernels try 64 positions per wave and step, one wave per nominal chunk of the stream.
+//      distance code.  seg_header_plausible() tests one bit position with registers only.  Over 5.7 G bit positions of gzip -1 / -6
+//      / -9 FASTQ streams and of random bytes it passed at the 22 000 block starts and at 3 other places; those give codes whose
+//      first codewords are no symbols, or a block that ends after a handful of symbols in front of something that is no header -- so a
+//      position that passes is looked at by decoding the first 2 048 symbols of its block dry (gzip_segments_wave.hpp; the first
+//      version decoded the whole block, seg_confirm_block_start: a second decode of a quarter to all of the stream).  What PROVES
+//      a start is step 2 -- the piece in front of it ends exactly there -- and a start that a piece runs over is dropped and the
+//      pieces are decoded again.  The kernel tries 64 positions per wave and step, one wave per nominal chunk of the stream.
 //   2. segments.  The stream is cut at the confirmed starts; inflate_segment() decodes [start, next start) into 16-bit symbols: a
 //      value below 256 is a byte; a match that reaches back beyond the segment's start copies from a 32 768-element prefix that the
 //      caller has filled with place-holders 0x8000 | k ("byte k of the 32 KiB in front of this segment") -- so every match is a plain
@@ -214,7 +218,10 @@ MKZ_HD int inflate_segment(const uint8_t *in, uint64_t n_in, uint64_t bit0, uint
     for (;;) {
         const uint64_t at = sr_bitpos(r);
         if (at == bit_end || (max_blocks && blocks == max_blocks)) break;
-        if (at > bit_end) return kSegDesync;
+        if (at > bit_end) {  // passed over bit_end: it is not a block start (*bit_stop: the block boundary behind it)
+            *n_out = op, *bit_stop = at;
+            return kSegDesync;
+        }
         sr_need32(r);
         if (sr_ran_out(r)) return kInfTruncated;
         const uint32_t final_block = (uint32_t)r.bitbuf & 1u, type = ((uint32_t)r.bitbuf >> 1) & 3u;

@@ -21,11 +21,11 @@ __global__ __launch_bounds__(64) void mk_gzip_segments_wave_kernel(const uint8_t
     const uint64_t bit_end = seg_bits[j + 1];
     uint64_t produced = 0, stop = 0;
     bool fin = false;
-    int status = wave_inflate_segment<false>(in, n_in, seg_bits[j], bit_end, 0, sym + seg_off[j] + kSegPrefix, seg_cap[j], ring, S, &produced, &stop, &fin);
+    int status = wave_inflate_segment<false>(in, n_in, seg_bits[j], bit_end, 0, sym + seg_off[j] + kSegPrefix, seg_cap[j], ring, S, 0, &produced, &stop, &fin);
     // both ends must be what the search said they are: the next start reached exactly (and not behind the final block), or the stream's end
     if (status == 0 && (bit_end != ~0ull ? (stop != bit_end || fin) : !fin)) status = kSegDesync;
     if (lane_id() == 0) {
-        n_out[j] = produced;
+        n_out[j] = status == kSegDesync ? stop : produced;  // (a piece that ran over its end: where it stands, a block boundary)
         status_out[j] = status;
     }
 }

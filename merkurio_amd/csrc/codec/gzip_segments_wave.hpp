@@ -6,8 +6,8 @@
 // behind the final block, or -- max_blocks -- after that many blocks); a match may reach up to 32 768 symbols in front of the piece,
 // where the caller has laid place-holders; and only the most recent 2 048 symbols live in LDS (4 KiB: 9.3 KiB per wave, 17 waves per
 // CU) -- a match that reaches further reads symbols back from global memory, where they went with a flush (or where the place-holders
-// lie).  kDry: nothing is stored or copied, the bit stream alone is checked (the block-start search confirms a candidate with it).
-// Users: gzip_segments_wave.hip (the pieces), gzip_inflate.hip (the search).  RFC 1951.
+// lie).  kDry: nothing is stored or copied, the bit stream alone is checked, max_symbols of it at most (the block-start search looks at
+// a candidate with it).  Users: gzip_segments_wave.hip (the pieces), gzip_inflate.hip (the search).  RFC 1951.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,6 +18,8 @@ namespace mkz {
 namespace {
 
 constexpr uint32_t kSegRing = 2048, kSegRingMask = kSegRing - 1, kSegFlush = kSegRing / 2;  // (16-bit elements)
+constexpr int kSegCutShort = 1;                // (dry) max_symbols were decoded without an error: not an error
+constexpr uint64_t kSegConfirmSymbols = 2048;  // what the search decodes of a candidate's block (a multiple of kSegFlush)
 
 struct SegWaveTables {
     uint16_t ll_fast[1 << kFastLl];
@@ -33,8 +35,8 @@ static_assert(sizeof(SegWaveTables) + 2 * kSegRing <= 9728, "seventeen waves per
 // *n_out = symbols produced, *bit_stop = the bit position behind the last block decoded, *final_seen: that block was the final one.
 template <bool kDry>
 __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ in, uint64_t n_in, uint64_t bit0, uint64_t bit_end, uint32_t max_blocks,
-                                    uint16_t *__restrict__ out, uint64_t cap, uint16_t *ring, SegWaveTables &S, uint64_t *n_out, uint64_t *bit_stop,
-                                    bool *final_seen) {
+                                    uint16_t *__restrict__ out, uint64_t cap, uint16_t *ring, SegWaveTables &S, uint64_t max_symbols, uint64_t *n_out,
+                                    uint64_t *bit_stop, bool *final_seen) {
     const uint32_t lane = lane_id();
     // ---- the compressed stream: lane k holds dword (sbase + k) of the stream that starts at byte s0; `nxt` the 64 dwords behind
     uint64_t s0 = 0;
@@ -283,6 +285,12 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
                     status = kInfTruncated;
                     break;
                 }
+                if constexpr (kDry) {
+                    if (max_symbols && op >= max_symbols) {
+                        status = kSegCutShort;
+                        break;
+                    }
+                }
                 flush_blocks();
                 flush_at = flushed + kSegFlush;
             }
@@ -311,12 +319,17 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
 #undef MKS_RAN_OUT
 }
 
-// a plausible header at `bit` (the same on every lane): is it a block start?  seg_confirm_block_start() of gzip_segments.hpp with the
-// block decoded (dry) by the whole wave.
+// a plausible header at `bit` (the same on every lane): is it a block start?  The block is decoded dry by the whole wave, kSegConfirmSymbols
+// symbols of it at most: the few headers that pass seg_header_plausible() without being one (3 in 5.7 G bit positions of gzip-written
+// FASTQ) give codes whose first codewords are no symbols, or whose block ends after a handful of symbols in front of something that
+// is no header.  A block that ends within the bound is asked what seg_confirm_block_start() of gzip_segments.hpp asks.  (The first
+// version decoded every candidate's WHOLE block: a second decode of a quarter to all of the stream, 8-16 ms of the search.)
 __device__ __forceinline__ bool wave_confirm_block_start(const uint8_t *__restrict__ in, uint64_t n_in, uint64_t bit, SegWaveTables &S) {
     uint64_t n_out = 0, stop = 0;
     bool fin = false;
-    if (wave_inflate_segment<true>(in, n_in, bit, ~0ull, 1, nullptr, ~0ull, nullptr, S, &n_out, &stop, &fin) != 0) return false;
+    const int rc = wave_inflate_segment<true>(in, n_in, bit, ~0ull, 1, nullptr, ~0ull, nullptr, S, kSegConfirmSymbols, &n_out, &stop, &fin);
+    if (rc == kSegCutShort) return true;
+    if (rc != 0) return false;
     if (n_out == 0 || fin) return false;  // (the block at a nominal cut is neither empty nor the last one)
     if (stop + 3 > n_in * 8) return false;
     SegReader r;

@@ -54,7 +54,7 @@ EXPORTS = [
     "mk_synth_reads_host", "mk_synth_reads_device_range", "mk_reduce_counters", "mk_reduce_prepare", "mk_comm_available", "mk_comm_unique_id", "mk_comm_init",
     "mk_comm_reduce_counters", "mk_comm_size", "mk_comm_destroy",
     "mk_codec_create", "mk_codec_destroy", "mk_bgzf_deflate_bound", "mk_bgzf_deflate", "mk_bgzf_deflate_pieces", "mk_bgzf_inflate", "mk_bgzf_members", "mk_bgzf_eof",
-    "mk_codec_times", "mk_codec_set_pass_limits", "mk_codec_set_inflate_kernel", "mk_gzip_inflate_device", "mk_gzip_text_read", "mk_gzip_text_device", "mk_gzip_text_release", "mk_gzip_info", "mk_extract_fastq_bgzf", "mk_extract_window",
+    "mk_codec_times", "mk_codec_set_pass_limits", "mk_codec_set_inflate_kernel", "mk_codec_set_gzip_chunk", "mk_gzip_inflate_device", "mk_gzip_text_read", "mk_gzip_text_device", "mk_gzip_text_release", "mk_gzip_info", "mk_extract_fastq_bgzf", "mk_extract_window",
     "mk_tag_bam_window", "mk_matcher_set_bam_piece",
 ]
 
@@ -238,6 +238,7 @@ def load(build_if_missing=True):
     L.mk_bgzf_eof.restype = C.POINTER(C.c_uint8 * 28)
     L.mk_codec_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mk_codec_set_pass_limits.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.mk_codec_set_gzip_chunk.argtypes = [C.c_void_p, C.c_uint64]
     L.mk_codec_set_inflate_kernel.argtypes = [C.c_void_p, C.c_int]
     L.mk_gzip_inflate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.mk_gzip_text_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
@@ -944,6 +945,10 @@ class Codec:
     def set_inflate_kernel(self, which=0):
         """0 = chosen per call, 1 = a lane per member, 2 = a wave per member (mk_codec_set_inflate_kernel)"""
         _check(self._L.mk_codec_set_inflate_kernel(self._h, which))
+
+    def set_gzip_chunk(self, chunk_bytes=0):
+        """nominal distance between two cuts of a gzip stream (mk_codec_set_gzip_chunk); 0 = by the stream's size"""
+        _check(self._L.mk_codec_set_gzip_chunk(self._h, chunk_bytes))
 
     def set_pass_limits(self, deflate_members=0, inflate_text_bytes=0):
         _check(self._L.mk_codec_set_pass_limits(self._h, deflate_members, inflate_text_bytes))

@@ -411,6 +411,47 @@ def test_gunzip_pieces_by_wave_and_by_lane_take_the_same_streams():
         wave.close(), lane.close()
 
 
+def test_gunzip_text_does_not_depend_on_where_the_stream_is_cut(gunzip_codec):
+    """mk_codec_set_gzip_chunk: cuts every 4 KiB (far more cuts than blocks: most find the same start), 16 KiB, 1 MiB (a few pieces of
+    many blocks each) -- the same text; a value that is not a power of two in range is refused"""
+    codec = gunzip_codec
+    data = _fastq_text(60_000, seed=3)
+    gz = gzip.compress(data, 6)
+    pieces = []
+    try:
+        for chunk in (4096, 16384, 1 << 20, 0):
+            codec.set_gzip_chunk(chunk)
+            assert codec.gunzip(gz) == data, chunk
+            pieces.append(codec.gzip_info[0])
+        assert pieces[0] >= pieces[1] > pieces[2] and pieces[2] <= len(gz) // (1 << 20) + 1, pieces
+        for bad in (1000, 2048, 3 << 20, 12288):
+            with pytest.raises(mk.MerkurioError):
+                codec.set_gzip_chunk(bad)
+    finally:
+        codec.set_gzip_chunk(0)
+
+
+def test_gunzip_drops_a_start_that_is_none(gunzip_codec):
+    """a DEFLATE stream stored inside the stream (incompressible to gzip: it lies verbatim in stored blocks): its first block's header
+    passes every test of the search, and with cuts every 4 KiB one of them is sure to find it -- but no block of the outer stream
+    starts there.  The piece in front runs over it, the start is dropped, the pieces are decoded again: still zlib's text (without
+    that the call could only hand the file back)"""
+    codec = gunzip_codec
+    rnd = random.Random(5)
+    inner = zlib.compressobj(6, zlib.DEFLATED, -15)
+    inner = inner.compress(_fastq_text(40, seed=1)) + inner.flush(zlib.Z_FULL_FLUSH) + inner.compress(_fastq_text(40, seed=2)) + inner.flush()
+    assert inner[0] & 7 == 4  # not final, dynamic: what the search looks for
+    data = _fastq_text(900, seed=3) + rnd.randbytes(100_000) + inner + rnd.randbytes(100_000) + _fastq_text(900, seed=4)
+    gz = gzip.compress(data, 6)
+    assert gz.find(inner) > 0  # verbatim
+    try:
+        for chunk in (4096, 0):
+            codec.set_gzip_chunk(chunk)
+            assert codec.gunzip(gz) == data, chunk
+    finally:
+        codec.set_gzip_chunk(0)
+
+
 def test_gunzip_shapes_the_device_takes_or_hands_back(gunzip_codec):
     codec = gunzip_codec
     """streams of every block type and of many flush points; what is not for this path comes back as 'not taken' (None) and never as a

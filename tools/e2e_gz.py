@@ -41,7 +41,7 @@ def run(label, args, outs, bases, timing=False):
     dt = time.time() - t0
     assert r.returncode == 0, r.stderr[-2000:]
     sizes = [os.path.getsize(os.path.join(tmp, o)) for o in outs]
-    gz = [ln.strip() for ln in r.stderr.splitlines() if "gzip input" in ln]
+    gz = [ln.strip() for ln in r.stderr.splitlines() if "gzip input" in ln or (os.environ.get("E2E_ALL_TIMING") and "[timing]" in ln)]
     print(f"{label}: {dt:.2f} s wall -> {bases / dt / 1e9:.2f} Gbases/s end to end; output {'+'.join(map(str, sizes))} bytes" + ("".join("\n      " + g for g in gz)), flush=True)
     return sizes
 

@@ -10,7 +10,11 @@ from merkurio_amd import native as mk
 sys.argv = sys.argv[:1] + sys.argv[1:]
 from bench import _fastq_binned
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
-levels = [int(x) for x in sys.argv[2:]] or [1, 6]
+levels = [int(x) for x in sys.argv[2:] if not x.startswith("--")] or [1, 6]
+chunks = []
+for a in sys.argv[2:]:
+    if a.startswith("--chunks="):
+        chunks = [int(k) for k in a[9:].split(",")]
 data = _fastq_binned(n)
 codec = mk.Codec()
 for level in levels:
@@ -23,8 +27,9 @@ for level in levels:
     t_z = time.time() - t0
     assert ref == data
     del ref
-    for which, label in ((0, "a wave per piece"), (1, "a lane per piece")):
+    for which, chunk, label in [(0, 0, "a wave per piece, cuts by the stream's size")] + [(0, k << 10, f"a wave per piece, cuts every {k} KiB") for k in chunks] + [(1, 0, "a lane per piece")]:
         codec.set_inflate_kernel(which)
+        codec.set_gzip_chunk(chunk)
         best = None
         for rep in range(3):
             text = codec.gunzip(gz)
