@@ -847,7 +847,7 @@ def codec_configs(mk, megabytes=1024, reps=3):
               {"compression_ratio": round(len(bam) / len(blob), 2),
                "cpu_baseline": {"value": round(z_def / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib level 6, 65 280-byte members",
                                 "compression_ratio": round(z_ratio, 2), "sample": "the first 16.7 MB of the same text"}})
-        inflate_kernels = "mk_bgzf_inflate_wave_kernel<4096> (a wave per member, its recent 4 KiB in LDS: calls of up to ~19 000 members) or mk_bgzf_inflate_kernel (a lane per member) + mk_bgzf_crc_check_kernel"
+        inflate_kernels = "mk_bgzf_inflate_wave_kernel<4096 / 2048> (a wave per member, its recent 4 / 2 KiB in LDS: calls of up to ~2 000 / ~24 000 members) or mk_bgzf_inflate_kernel (a lane per member) + mk_bgzf_crc_check_kernel"
         cpu_inf = {"value": round(z_inf / 1e3, 4), "unit": "GB/s of text", "cores": 1, "kind": "zlib inflate of its own level 6 members",
                    "sample": "the first 16.7 MB of the BAM text"}
         text, best = timed(lambda: codec.inflate(blob))

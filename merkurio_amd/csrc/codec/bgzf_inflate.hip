@@ -43,13 +43,14 @@ uint32_t inflate_lanes(uint32_t n_members, int num_cus) {
 }
 
 // Which decoder a call gets (r05).  A wave per member (bgzf_inflate_wave.hip) finishes a member in 2-5 ms; with only the most recent
-// 4 KiB of the member's text in LDS seventeen of them fit a CU (4 352 on the part): its time grows with the members per slot -- and
-// with them per CU: the kernel is bound by its scalar instructions (~770 000 per member on one scalar unit per CU).  A lane per
-// member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands of members.
-// zlib level-6 members of BAM records: 64 MB 5.2 against 21-24 ms, 256 MB 10.4 against 23.3, 1 GiB 30.8 against 40.4, 2 GiB ~62
-// against 41.3 -- they cross at about four rounds of the wave kernel's slots (profiles/r05_codec_real_rings.txt; rings of 2, 8, 16
-// and 32 KiB are in the same table: 4 KiB is the best or within 12 % of it at every size).
-constexpr uint32_t kWaveRounds = 4, kWaveSlotsPerCu = 17, kWaveRing = 4096;
+// 4 KiB of the member's text in LDS seventeen of them fit a CU (4 352 on the part), with 2 KiB twenty-five: its time grows with the
+// members per slot -- and with them per CU: the kernel is bound by its scalar instructions (~770 000 per member on one scalar unit
+// per CU).  A lane per member takes 15-25 ms for its slowest lane whatever the call holds and stays there up to tens of thousands
+// of members.  zlib level-6 members of BAM records (FASTQ), kernels: 64 MB 5.3 (3.4) ms with the 4 KiB ring, 5.4 (3.5) with 2 KiB,
+// 21 (14) with a lane per member; 256 MB 10.2 (6.7) / 9.0 (5.6) / 23 (16); 1 GiB 30.4 (19.6) / 26.9 (17.3) / 40.5 (25.0); at 2 GiB
+// the lane kernel's 41 (25) ms win (profiles/r05_codec_real_rings2.txt; once a flush stopped writing the L2 back -- see the
+// fence in bgzf_inflate_wave.hip -- the 2 KiB ring, which flushes twice as often, became the better one for all but small calls).
+constexpr uint32_t kWaveMembersPerCuSmall = 8, kWaveMembersPerCuMax = 96;  // (<= 2 048 members: the 4 KiB ring; <= 24 576: 2 KiB)
 
 void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uint32_t n_members, uint8_t *out, int32_t *status, int num_cus,
                     hipStream_t s, int which) {
@@ -62,8 +63,8 @@ void launch_inflate(const uint8_t *in, uint64_t n_in, const Member *members, uin
         launch_inflate_wave(in, n_in, members, n_members, out, status, s);
         return;
     }
-    if (which == 0 && n_members <= (uint32_t)num_cus * kWaveSlotsPerCu * kWaveRounds) {
-        launch_inflate_wave(in, n_in, members, n_members, out, status, s, kWaveRing);
+    if (which == 0 && n_members <= (uint32_t)num_cus * kWaveMembersPerCuMax) {
+        launch_inflate_wave(in, n_in, members, n_members, out, status, s, n_members <= (uint32_t)num_cus * kWaveMembersPerCuSmall ? 4096u : 2048u);
         return;
     }
     const uint32_t lanes = inflate_lanes(n_members, num_cus);

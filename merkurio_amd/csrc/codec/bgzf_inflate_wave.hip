@@ -19,8 +19,9 @@
 // ~150 (literal) to ~500 (match) cycles of dependent LDS latency.  The kernel is a template on the ring's size: with the most
 // recent 8 KiB (12.4 KiB per wave, 12 waves per CU, 3 072 members in flight on an MI355X) the same member takes as long but three
 // times as many run beside it (4 KiB: 9.3 KiB per wave, 17 per CU, 4 352 in flight); matches that reach behind the ring come back
-// from global memory (see WaveLds).  launch_inflate (bgzf_inflate.hip) takes the 4 KiB ring for calls of up to ~17 000 members; above
-// that the lane-per-member kernel's sheer parallelism wins (profiles/r05_codec_real_rings.txt).
+// from global memory (see WaveLds).  launch_inflate (bgzf_inflate.hip) takes the 4 KiB ring for calls of up to ~2 000 members, the 2 KiB ring
+// (7.3 KiB per wave, 25 per CU) up to ~24 000; above that the lane-per-member kernel's sheer parallelism wins
+// (profiles/r05_codec_real_rings2.txt).
 // RFC 1951; the reference's inflate is flate2 under `bam 0.1.4` (src/cmd_tag.rs:503-506) and needletail (src/cmd_extract.rs:281).
 #include <hip/hip_runtime.h>
 
@@ -115,7 +116,12 @@ __global__ __launch_bounds__(64) void mk_bgzf_inflate_wave_kernel(const uint8_t 
             flushed += kFlush;
         }
         // (a shorter ring reads flushed text back: the stores above must have arrived before such a load is issued)
-        if (kRing < 32768) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // (this wave alone reads them, past the CU's L1: they need to have reached the L2, not to be written back from it -- an agent-scope
+        // release is a write-back of the whole L2, `buffer_wbl2`, per flush)
+        if (kRing < 32768) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        }
     };
 
     for (bool last_block = false; !last_block && status == 0;) {

@@ -47,7 +47,12 @@ __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restr
     };
     // One loop, one place per level (each of the two expensive tests is instantiated once): what to do next is decided from the
     // queues' fill -- the deepest level that has a full wave of work (or, once the range is exhausted, any work) goes first.
-    uint64_t base = bit0;
+    uint64_t base = bit0, buf_bit = bit0;  // (bit0 is a multiple of 32: cuts are multiples of 4 KiB)
+    uint32_t look;
+    {
+        const uint64_t byte = (bit0 >> 3) + 4 * lane;
+        look = byte <= n_in + 8 ? load_le32(in + byte) : 0u;
+    }
     bool draining = false, deep_due = false;
     while (found == ~0ull) {
         if (n2 >= 64 || (n2 && (draining ? n1 == 0 : deep_due))) {
@@ -93,10 +98,16 @@ __global__ __launch_bounds__(64) void mk_gzip_find_kernel(const uint8_t *__restr
             continue;
         }
         if (base < bit1) {
-            // level 1: the 13 bits at (base + lane) out of the 96 bits that hold all 64 of them
-            const uint64_t byte = base >> 3;
-            const uint32_t w0 = byte <= n_in + 8 ? load_le32(in + byte) : 0u, w1 = byte + 4 <= n_in + 8 ? load_le32(in + byte + 4) : 0u,
-                           w2 = byte + 8 <= n_in + 8 ? load_le32(in + byte + 8) : 0u;
+            // level 1: the 13 bits at (base + lane) out of the 96 bits that hold all 64 of them -- three dwords out of the 64 the wave
+            // holds in registers (a dword per lane, loaded in a row every 31 steps: a step does not wait for memory)
+            if (base - buf_bit > 61 * 32) {
+                buf_bit = base;
+                const uint64_t byte = (base >> 3) + 4 * lane;
+                look = byte <= n_in + 8 ? load_le32(in + byte) : 0u;
+            }
+            const uint32_t k = uni((uint32_t)((base - buf_bit) >> 5));
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)look, (int)k), w1 = (uint32_t)__builtin_amdgcn_readlane((int)look, (int)k + 1),
+                           w2 = (uint32_t)__builtin_amdgcn_readlane((int)look, (int)k + 2);
             const uint32_t sh = (uint32_t)(base & 7) + lane;  // 0 .. 70
             const uint64_t lo = (uint64_t)w0 | (uint64_t)w1 << 32, hi = (uint64_t)w1 | (uint64_t)w2 << 32;
             const uint32_t v = (uint32_t)((sh < 32 ? lo >> sh : hi >> (sh - 32)) & 0x1fffu);

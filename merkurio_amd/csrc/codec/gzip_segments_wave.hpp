@@ -11,27 +11,41 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gzip_segments.hpp"
 #include "inflate_wave_common.hpp"
 
 namespace mkz {
 namespace {
 
+// MK_SEG_PAIRS=1 (a measurement build): table entries of 32 bits that hold TWO literals where the entry's bits do, taken in one turn.
+// Measured on gzip -6 FASTQ: 14 instead of 17 waves per CU, pieces 31 -> 43 ms.  DNA text is not literals to DEFLATE: three tokens of
+// four are matches of ~12 bases found thousands of positions back (any 8-mer has occurred in the last 32 KiB), and what a wave waits
+// for is those matches' sources coming back from device memory -- hidden by the other waves of the CU, so waves per CU count.
+#ifndef MK_SEG_PAIRS
+#define MK_SEG_PAIRS 0
+#endif
+constexpr bool kSegPairs = MK_SEG_PAIRS != 0;
 constexpr uint32_t kSegRing = 2048, kSegRingMask = kSegRing - 1, kSegFlush = kSegRing / 2;  // (16-bit elements)
+constexpr uint64_t kSegCapMax = 0xfff00000ull;  // (the decoder counts symbols in 32 bits)
 constexpr int kSegCutShort = 1;                // (dry) max_symbols were decoded without an error: not an error
 constexpr uint64_t kSegConfirmSymbols = 2048;  // what the search decodes of a candidate's block (a multiple of kSegFlush)
 
 struct SegWaveTables {
-    uint16_t ll_fast[1 << kFastLl];
+    // ll_fast as bgzf_inflate_wave.hip has it (one codeword); kSegPairs: that is the low half, and the high half, if not 0, says that
+    // the stream bits of this entry hold TWO literals -- second literal << 4 | length of both codewords
+    std::conditional_t<kSegPairs, uint32_t, uint16_t> ll_fast[1 << kFastLl];
     uint32_t d_fast[1 << kFastD];
     uint16_t ll_limit[16], ll_base[16], d_limit[16], d_base[16];
     uint16_t ll_sorted[288], d_sorted[32];
     uint8_t lens[320];
 };
-static_assert(sizeof(SegWaveTables) + 2 * kSegRing <= 9728, "seventeen waves per CU");
+static_assert(sizeof(SegWaveTables) + 2 * kSegRing <= (kSegPairs ? 11648 : 9728), "fourteen (without pairs: seventeen) waves per CU");
 
 // All lanes call it with the same arguments and get the same results.  ring: kSegRing elements of LDS, 16-byte aligned (kDry: unused).
-// out[-kSegPrefix .. -1]: the caller's place-holders; cap elements may be written.  Returns 0 or a negative code (kInf*, kSeg*);
+// out[-kSegPrefix .. -1]: the caller's place-holders; cap elements may be written (what counts is min(cap, kSegCapMax): a piece of more
+// symbols than that is reported as one that does not fit).  Returns 0 or a negative code (kInf*, kSeg*);
 // *n_out = symbols produced, *bit_stop = the bit position behind the last block decoded, *final_seen: that block was the final one.
 template <bool kDry>
 __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ in, uint64_t n_in, uint64_t bit0, uint64_t bit_end, uint32_t max_blocks,
@@ -72,7 +86,8 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
     MKS_NEED32();
     MKS_TAKE((uint32_t)bit0 & 7u);
 
-    uint64_t op = 0, flushed = 0;  // symbols produced / symbols that have left for global memory
+    uint32_t op = 0, flushed = 0;  // symbols produced / symbols that have left for global memory
+    const uint32_t cap32 = (uint32_t)(cap < kSegCapMax ? cap : kSegCapMax);
     int status = 0;
     bool fin = false;
     auto flush_blocks = [&]() {  // whole pieces of kSegFlush symbols: 8 symbols (16 bytes) per lane and step
@@ -80,7 +95,7 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
             if constexpr (!kDry) {
 #pragma unroll
                 for (uint32_t k = 0; k < kSegFlush; k += 512) {
-                    const uint64_t at = flushed + k + 8 * lane;
+                    const uint32_t at = flushed + k + 8 * lane;
                     const uint4 v = *reinterpret_cast<const uint4 *>(&ring[at & kSegRingMask]);
                     __builtin_memcpy(out + at, &v, 16);
                 }
@@ -88,7 +103,12 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
             flushed += kSegFlush;
         }
         // (far matches read flushed symbols back: the stores above must have arrived before such a load is issued)
-        if constexpr (!kDry) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // (this wave alone reads them, past the CU's L1: they need to have reached the L2, not to be written back from it -- an agent-scope
+        // release is a write-back of the whole L2, `buffer_wbl2`, per flush)
+        if constexpr (!kDry) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        }
     };
 
     for (uint32_t blocks = 0;; ++blocks) {
@@ -118,7 +138,7 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
             const uint64_t pos = MKS_BITPOS() >> 3;  // (byte-aligned here)
             if ((len ^ nlen) != 0xffffu) status = kInfBadStored;
             else if (MKS_RAN_OUT() || pos > n_in || len > n_in - pos) status = kInfTruncated;
-            else if (len > cap - op) status = kSegOverflow;
+            else if (len > cap32 - op) status = kSegOverflow;
             if (status) break;
             for (uint32_t done = 0; done < len;) {
                 const uint32_t piece = min(len - done, kSegFlush);
@@ -215,69 +235,97 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
                 break;
             }
             __builtin_amdgcn_wave_barrier();
-            wave_fill_fast_ll(S.ll_fast, S.ll_sorted, S.ll_limit, S.ll_base);
+            // one codeword per entry ...
+            for (uint32_t e = lane; e < (1u << kFastLl); e += 64) {
+                const uint32_t r = decode_codeword(e, S.ll_sorted, S.ll_limit, S.ll_base);
+                S.ll_fast[e] = (r & 15u) <= (uint32_t)kFastLl ? pack_ll(r) : 0u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (kSegPairs) {
+                // ... and where that is a literal and what follows it in the entry's bits is a whole literal too, the two of them (only
+                // the high halves are written here, only the low halves read)
+                for (uint32_t e = lane; e < (1u << kFastLl); e += 64) {
+                    const uint32_t a = reinterpret_cast<const uint16_t *>(S.ll_fast)[2 * e];
+                    const uint32_t la = a & 15u;
+                    if (a != 0 && a < 0x1000u && la < (uint32_t)kFastLl) {
+                        const uint32_t b = reinterpret_cast<const uint16_t *>(S.ll_fast)[2 * (e >> la)];  // (the bits behind the first, zeros above)
+                        if (b != 0 && b < 0x1000u && la + (b & 15u) <= (uint32_t)kFastLl) reinterpret_cast<uint16_t *>(S.ll_fast)[2 * e + 1] = (uint16_t)((b & 0xff0u) | (la + (b & 15u)));
+                    }
+                }
+            }
             wave_fill_fast_d(S.d_fast, S.d_sorted, S.d_limit, S.d_base);
             __builtin_amdgcn_wave_barrier();
 
             // ---- the symbols of the block (the turn of bgzf_inflate_wave.hip; capacity and stream end are asked at the flush points)
-            uint64_t flush_at = flushed + kSegFlush;
+            uint32_t flush_at = flushed + kSegFlush;
             for (;;) {
                 MKS_NEED32();
                 uint32_t e = S.ll_fast[(uint32_t)bitbuf & ((1u << kFastLl) - 1)];
-                if (e == 0) {
+                if (kSegPairs && e > 0xffffu) {  // two literals
+                    if constexpr (!kDry) {
+                        ring[op & kSegRingMask] = (uint16_t)((e >> 4) & 0xffu);
+                        ring[(op + 1) & kSegRingMask] = (uint16_t)(e >> 20);
+                    }
+                    MKS_TAKE((e >> 16) & 15u);
+                    op += 2;
+                    if (op < flush_at) continue;
+                    e = 0x10000u;  // (the flush point's questions, then on)
+                } else if (e == 0) {
                     e = pack_ll(decode_codeword((uint32_t)bitbuf, S.ll_sorted, S.ll_limit, S.ll_base));
                     if (e == 0) {
                         status = kInfBadSymbol;
                         break;
                     }
                 }
-                MKS_TAKE(e & 15u);
-                if (e < 0x1000u) {
-                    if constexpr (!kDry) ring[op & kSegRingMask] = (uint16_t)(e >> 4);
-                    ++op;
-                    if (op < flush_at) continue;
-                } else if (e < 0x8000u) {
-                    break;
-                } else {
-                    const uint32_t leb = (e >> 4) & 7u;
-                    const uint32_t len = ((e >> 7) & 255u) + 3u + ((uint32_t)bitbuf & ((1u << leb) - 1));
-                    MKS_TAKE(leb);
-                    MKS_NEED32();
-                    uint32_t d = S.d_fast[(uint32_t)bitbuf & ((1u << kFastD) - 1)];
-                    if (d == 0) {
-                        d = pack_d(decode_codeword((uint32_t)bitbuf, S.d_sorted, S.d_limit, S.d_base));
+                if (e != 0x10000u) {
+                    MKS_TAKE(e & 15u);
+                    if (e < 0x1000u) {
+                        if constexpr (!kDry) ring[op & kSegRingMask] = (uint16_t)(e >> 4);
+                        ++op;
+                        if (op < flush_at) continue;
+                    } else if (e < 0x8000u) {
+                        break;
+                    } else {
+                        const uint32_t leb = (e >> 4) & 7u;
+                        const uint32_t len = ((e >> 7) & 255u) + 3u + ((uint32_t)bitbuf & ((1u << leb) - 1));
+                        MKS_TAKE(leb);
+                        MKS_NEED32();
+                        uint32_t d = S.d_fast[(uint32_t)bitbuf & ((1u << kFastD) - 1)];
                         if (d == 0) {
-                            status = kInfBadSymbol;
-                            break;
-                        }
-                    }
-                    MKS_TAKE(d & 15u);
-                    const uint32_t deb = (d >> 4) & 15u;
-                    const uint32_t dist = (d >> 8) + ((uint32_t)bitbuf & ((1u << deb) - 1));
-                    MKS_TAKE(deb);
-                    if constexpr (!kDry) {
-                        // symbol i of the match = symbol (i mod distance) of the `distance` symbols in front of it.  A distance is at most
-                        // 32 768 = kSegPrefix: a source in front of the piece is a place-holder the caller has laid there
-                        const long long src0 = (long long)op - (long long)dist;
-                        if (dist + len > kSegRing || src0 < 0) {
-                            // the source has (partly) left the ring, or never was in it: symbols below `flushed` come from global memory
-                            // (past the CU's L1: a line may have been cached before its last symbols were stored), the rest from the ring
-                            for (uint32_t i = lane; i < len; i += 64) {
-                                const long long p = src0 + (dist >= len ? i : i % dist);
-                                const uint16_t v = p < (long long)flushed ? __hip_atomic_load(out + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                                           : ring[(uint64_t)p & kSegRingMask];
-                                ring[(op + i) & kSegRingMask] = v;
+                            d = pack_d(decode_codeword((uint32_t)bitbuf, S.d_sorted, S.d_limit, S.d_base));
+                            if (d == 0) {
+                                status = kInfBadSymbol;
+                                break;
                             }
-                        } else if (dist >= len) {
-                            for (uint32_t i = lane; i < len; i += 64) ring[(op + i) & kSegRingMask] = ring[(uint64_t)(src0 + i) & kSegRingMask];
-                        } else {
-                            for (uint32_t i = lane; i < len; i += 64) ring[(op + i) & kSegRingMask] = ring[(uint64_t)(src0 + i % dist) & kSegRingMask];
                         }
+                        MKS_TAKE(d & 15u);
+                        const uint32_t deb = (d >> 4) & 15u;
+                        const uint32_t dist = (d >> 8) + ((uint32_t)bitbuf & ((1u << deb) - 1));
+                        MKS_TAKE(deb);
+                        if constexpr (!kDry) {
+                            // symbol i of the match = symbol (i mod distance) of the `distance` symbols in front of it.  A distance is at most
+                            // 32 768 = kSegPrefix: a source in front of the piece is a place-holder the caller has laid there
+                            const uint32_t src0 = op - dist;  // (wraps where the source lies in front of the piece: the far path's case)
+                            if (dist + len > kSegRing || dist > op) {
+                                // the source has (partly) left the ring, or never was in it: symbols below `flushed` come from global memory
+                                // (past the CU's L1: a line may have been cached before its last symbols were stored), the rest from the ring
+                                for (uint32_t i = lane; i < len; i += 64) {
+                                    const long long p = (long long)op - (long long)dist + (dist >= len ? i : i % dist);
+                                    const uint16_t v = p < (long long)flushed ? __hip_atomic_load(out + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                                               : ring[(uint64_t)p & kSegRingMask];
+                                    ring[(op + i) & kSegRingMask] = v;
+                                }
+                            } else if (dist >= len) {
+                                for (uint32_t i = lane; i < len; i += 64) ring[(op + i) & kSegRingMask] = ring[(src0 + i) & kSegRingMask];
+                            } else {
+                                for (uint32_t i = lane; i < len; i += 64) ring[(op + i) & kSegRingMask] = ring[(src0 + i % dist) & kSegRingMask];
+                            }
+                        }
+                        op += len;
+                        if (op < flush_at) continue;
                     }
-                    op += len;
-                    if (op < flush_at) continue;
                 }
-                if (op > cap) {
+                if (op > cap32) {
                     status = kSegOverflow;
                     break;
                 }
@@ -294,7 +342,7 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
                 flush_blocks();
                 flush_at = flushed + kSegFlush;
             }
-            if (status == 0 && op > cap) status = kSegOverflow;
+            if (status == 0 && op > cap32) status = kSegOverflow;
             if (status == 0 && MKS_RAN_OUT()) status = kInfTruncated;
             if (status) break;
         }
@@ -306,7 +354,7 @@ __device__ __forceinline__ int wave_inflate_segment(const uint8_t *__restrict__ 
     if constexpr (!kDry) {
         if (status == 0) {
             flush_blocks();
-            for (uint64_t i = flushed + lane; i < op; i += 64) out[i] = ring[i & kSegRingMask];
+            for (uint32_t i = flushed + lane; i < op; i += 64) out[i] = ring[i & kSegRingMask];
         }
     }
     *n_out = op;

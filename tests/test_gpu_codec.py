@@ -24,8 +24,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=[0, 1, 2, 3, 4, 5, 6], ids=["kernel-by-size", "lane-per-member", "wave-per-member", "wave-8k-ring", "wave-16k-ring", "wave-4k-ring", "wave-2k-ring"])
 def codec(request):
-    """every inflate test runs seven times: the inflate kernel chosen per call (a wave per member with a 4 KiB ring for calls of up to
-    ~19 000 members, a lane per member above: bgzf_inflate.hip), and each of the six variants forced (mk_codec_set_inflate_kernel)"""
+    """every inflate test runs seven times: the inflate kernel chosen per call (a wave per member with a 4 / 2 KiB ring for calls of up to
+    ~2 000 / ~24 000 members, a lane per member above: bgzf_inflate.hip), and each of the six variants forced (mk_codec_set_inflate_kernel)"""
     c = mk.Codec()
     c.set_inflate_kernel(request.param)
     yield c
