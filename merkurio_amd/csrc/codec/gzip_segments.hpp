@@ -310,7 +310,8 @@ MKZ_HD int inflate_segment(const uint8_t *in, uint64_t n_in, uint64_t bit0, uint
 }
 
 // a plausible header at `bit`: is it a block start?  Its block decodes cleanly (dry) and another block header follows at once --
-// a stored or fixed block (any BFINAL) or a plausible dynamic one, or the stream's end behind a final block.
+// a stored block or a plausible dynamic one.  The whole-block form: the host harness cuts its streams with it (and the search
+// kernel's first version did); the kernel now decodes the first symbols only (wave_confirm_block_start, gzip_segments_wave.hpp).
 MKZ_HD bool seg_confirm_block_start(const uint8_t *in, uint64_t n_in, uint64_t bit, uint16_t *t) {
     uint64_t n_out = 0, stop = 0;
     bool fin = false;
