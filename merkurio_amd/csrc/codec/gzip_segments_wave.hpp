@@ -27,7 +27,10 @@ namespace {
 #define MK_SEG_PAIRS 0
 #endif
 constexpr bool kSegPairs = MK_SEG_PAIRS != 0;
-constexpr uint32_t kSegRing = 2048, kSegRingMask = kSegRing - 1, kSegFlush = kSegRing / 2;  // (16-bit elements)
+#ifndef MK_SEG_RING
+#define MK_SEG_RING 2048  // (a measurement build may take another power of two >= 1024; 1024 = 21 waves per CU: pieces 31.2 -> 32.7 ms, small streams 15.5 -> 16.6)
+#endif
+constexpr uint32_t kSegRing = MK_SEG_RING, kSegRingMask = kSegRing - 1, kSegFlush = kSegRing / 2;  // (16-bit elements)
 constexpr uint64_t kSegCapMax = 0xfff00000ull;  // (the decoder counts symbols in 32 bits)
 constexpr int kSegCutShort = 1;                // (dry) max_symbols were decoded without an error: not an error
 constexpr uint64_t kSegConfirmSymbols = 2048;  // what the search decodes of a candidate's block (a multiple of kSegFlush)
@@ -41,7 +44,8 @@ struct SegWaveTables {
     uint16_t ll_sorted[288], d_sorted[32];
     uint8_t lens[320];
 };
-static_assert(sizeof(SegWaveTables) + 2 * kSegRing <= (kSegPairs ? 11648 : 9728), "fourteen (without pairs: seventeen) waves per CU");
+static_assert(kSegRing != 2048 || sizeof(SegWaveTables) + 2 * kSegRing <= (kSegPairs ? 11648 : 9728), "fourteen (without pairs: seventeen) waves per CU");
+static_assert(kSegRing >= 1024 && (kSegRing & (kSegRing - 1)) == 0, "the flush writes 512 symbols a step");
 
 // All lanes call it with the same arguments and get the same results.  ring: kSegRing elements of LDS, 16-byte aligned (kDry: unused).
 // out[-kSegPrefix .. -1]: the caller's place-holders; cap elements may be written (what counts is min(cap, kSegCapMax): a piece of more
